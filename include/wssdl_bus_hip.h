@@ -1,0 +1,203 @@
+/*
+ * wssdl_bus_hip.h -- C ABI of libwssdl_bus_hip.so, the MI355X (gfx950) implementation
+ * of the wssdl_bus Faster-R-CNN detection hot path.
+ *
+ * Every entry point replaces one native/NumPy routine of the reference
+ * (paths relative to code/lib of syshin1014/wssdl_bus, cited per function) and is
+ * what the reference-side FFI for that routine would bind (INTEGRATION.md shows
+ * the ctypes / tf.load_op_library-side stubs).
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only; no torch / HIP types in signatures.
+ *     `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - all data pointers are DEVICE pointers unless the name ends in `_host`.
+ *   - outputs and workspaces are caller-allocated (the PyTorch caching allocator
+ *     in the shipped host layer); `*_workspace_bytes` functions size them.
+ *   - nothing here allocates, frees, copies to host or synchronises: every call
+ *     only enqueues kernels on `stream`, so calls are hipGraph-capturable.
+ *   - return value: 0 = WSSDL_OK, otherwise a wssdl_status code; never exit(),
+ *     never prints (the reference's CUDA launcher prints and exit(-1)s on a
+ *     launch error, roi_pooling_op_gpu.cu.cc:102-107 -- deliberately not kept).
+ *   - layouts are the reference's: feature maps NHWC f32, rois [R,5] f32
+ *     (batch_idx,x1,y1,x2,y2), gt_boxes [N,MAX_GT,5] f32 (x1,y1,x2,y2,cls).
+ */
+#ifndef WSSDL_BUS_HIP_H
+#define WSSDL_BUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *wssdl_stream_t;
+
+#if defined(__GNUC__)
+#define WSSDL_API __attribute__((visibility("default")))
+#else
+#define WSSDL_API
+#endif
+
+enum wssdl_status {
+    WSSDL_OK = 0,
+    WSSDL_ERR_INVALID_ARGUMENT = 1,   /* bad shape / null pointer / unsupported size */
+    WSSDL_ERR_WORKSPACE = 2,          /* workspace too small */
+    WSSDL_ERR_LAUNCH = 3              /* hipGetLastError() != hipSuccess after a launch */
+};
+
+/* bin-boundary rounding of RoI pooling */
+enum wssdl_roi_rounding {
+    WSSDL_ROI_ROUND_CUDA = 0,  /* floor(ph*bin), ceil((ph+1)*bin): roi_pooling_op_gpu.cu.cc:51-58 (canonical) */
+    WSSDL_ROI_ROUND_CPU = 1    /* (int)(ph*bin), (int)((ph+1)*bin): roi_pooling_op.cc:167-170 */
+};
+
+/* dataset switch of the anchor-target layer, anchor_target_layer_tf_bus.py:120-199 */
+enum wssdl_dataset {
+    WSSDL_DATASET_SNUBH = 0,     /* gt holds positive boxes first, then background boxes */
+    WSSDL_DATASET_SNUBH_FG = 1,  /* same layout, background boxes ignored */
+    WSSDL_DATASET_FG_ONLY = 2    /* e.g. 'UDIAT': every gt box is a positive */
+};
+
+#define WSSDL_MAX_ANCHORS 32     /* base anchors per cell (reference uses 9 or 12) */
+#define WSSDL_MAX_GT 64          /* gt boxes per image (reference: MAX_GT_PER_IMAGE = 20) */
+
+/* library / build identification: returns a static string */
+WSSDL_API const char *wssdl_version(void);
+/* name of the last HIP error seen by this library on the calling thread ("" if none) */
+WSSDL_API const char *wssdl_last_error(void);
+
+/* ------------------------------------------------------------------ a1, a2 ---
+ * generate_anchors: rpn_msr/generate_anchors.py:37-97.  Host-side (9 boxes);
+ * writes n_ratios*n_scales rows of 4 doubles to anchors_host, ratio-major.
+ * Returns the number of anchors, or a negative wssdl_status. */
+WSSDL_API int wssdl_generate_anchors_host(int base_size, const double *ratios_host, int n_ratios,
+                                const double *scales_host, int n_scales, double *anchors_host);
+
+/* shifted anchor grid: anchor_target_layer_tf_bus.py:59-73 == proposal_layer_tf_bus.py:55-71.
+ * out [H*W*A, 4] f64, row (h*W+w)*A+a = base[a] + stride*(w,h,w,h). */
+WSSDL_API int wssdl_shifted_anchors(const double *base_anchors_host, int A, int H, int W, int feat_stride,
+                          double *out, wssdl_stream_t stream);
+
+/* ------------------------------------------------------------------ a3, a4 ---
+ * bbox_overlaps: utils/bbox.pyx:15-55.  boxes [N, box_stride>=4] f64, query
+ * [K, query_stride>=4] f64 (only columns 0..3 are read), out [N,K] f64.  Bit-exact. */
+WSSDL_API int wssdl_bbox_overlaps(const double *boxes, int64_t N, int box_stride, const double *query,
+                        int64_t K, int query_stride, double *out, wssdl_stream_t stream);
+/* bbox_overlaps_ui: utils/bbox_ui.pyx:12-47 (intersection / area of boxes[n]). */
+WSSDL_API int wssdl_bbox_overlaps_ui(const double *boxes, int64_t N, int box_stride, const double *query,
+                           int64_t K, int query_stride, double *out, wssdl_stream_t stream);
+
+/* ---------------------------------------------------------------------- a8 ---
+ * nms: fast_rcnn/nms_wrapper.py:13-21 -> nms/cpu_nms.pyx:17-68.
+ * dets [n,5] f32 (x1,y1,x2,y2,score), any order (sorted internally by score
+ * descending; equal scores: higher input index first).  f32 box arithmetic,
+ * suppression when (double)iou >= thresh -- the vendored build's rule.
+ * keep [max_keep] i32 receives kept indices into dets in score order (the
+ * reference's caller truncates keep[:post_nms_topN]; pass max_keep = n for
+ * all); *num_keep (device i32) receives the count written.  n == 0 -> count 0. */
+WSSDL_API size_t wssdl_nms_workspace_bytes(int n);
+WSSDL_API int wssdl_nms(const float *dets, int n, double thresh, int max_keep, int32_t *keep,
+              int32_t *num_keep, void *workspace, size_t workspace_bytes, wssdl_stream_t stream);
+
+/* ------------------------------------------------------------ a6, a7, a8, a9 ---
+ * proposal_layer: rpn_msr/proposal_layer_tf_bus.py:19-148 for all N images in
+ * one call.  rpn_cls_prob [N,H,W,2A] f32 (fg prob = channels A..2A-1),
+ * rpn_bbox_pred [N,H,W,4A] f32, im_info [N,im_info_stride] f32 (h,w,scale,...).
+ * Decode (bbox_transform_inv, f32) -> clip -> min-size filter -> sort by score
+ * -> top pre_nms_topN -> NMS -> top post_nms_topN.
+ * Outputs: rois_padded [N, post_nms_topN, 5] f32 (batch_idx,x1,y1,x2,y2; rows
+ * beyond the image's count are zero), roi_counts [N] i32.  Optional (may be
+ * NULL) debug outputs used by the parity tests: decoded [N,H*W*A,4] f32 (after
+ * clip), sorted_index [N, pre_nms_topN] i32 (anchor index of each pre-NMS
+ * candidate in score order, -1 padded), sorted_count [N] i32. */
+WSSDL_API size_t wssdl_proposal_workspace_bytes(int N, int H, int W, int A, int pre_nms_topN);
+WSSDL_API int wssdl_proposal_layer(const float *rpn_cls_prob, const float *rpn_bbox_pred,
+                         const float *im_info, int im_info_stride, int N, int H, int W,
+                         const double *base_anchors_host, int A, int feat_stride,
+                         int pre_nms_topN, int post_nms_topN, double nms_thresh, float min_size,
+                         float *rois_padded, int32_t *roi_counts,
+                         float *decoded, int32_t *sorted_index, int32_t *sorted_count,
+                         void *workspace, size_t workspace_bytes, wssdl_stream_t stream);
+/* gathers the per-image lists into the reference's contiguous blob [sum counts, 5]
+ * (proposal_layer_tf_bus.py:144-146).  total_host must equal sum(roi_counts). */
+WSSDL_API int wssdl_proposal_compact(const float *rois_padded, const int32_t *roi_counts, int N,
+                           int post_nms_topN, float *rois_out, int total_host,
+                           wssdl_stream_t stream);
+
+/* ---------------------------------------------------------------------- a5 ---
+ * anchor-target layer, rpn_msr/anchor_target_layer_tf_bus.py:19-303 / :328-628,
+ * split at the two random sub-samplings (:202-217) so that the host layer can
+ * either draw them from numpy's legacy RandomState (bit-identical to the
+ * reference) or let the device do it.
+ *
+ * Stage 1  wssdl_anchor_labels: for each of the first n_images images: inside
+ *   filter (:100-105), f64 IoU vs positive gt / intersection ratio vs background
+ *   gt, labels before sub-sampling (:115-199).
+ *   labels_pre [n_images, H*W*A] i8 in anchor order (h,w,a): -1/0/1 (outside = -1)
+ *   argmax_gt  [n_images, H*W*A] i32: row of gt_boxes the targets regress to (-1 outside)
+ *   counts     [n_images, 4] i32: (#inside, #fg, #bg, 0)
+ * Stage 2a wssdl_anchor_subsample_device: random sub-sampling on the device
+ *   (counter-based hash of (seed, image, anchor); same distribution as
+ *   npr.choice(replace=False), not the same stream).  In place on labels_pre.
+ * Stage 2b (reference RNG) happens on the host: see
+ *   wssdl_bus_amd/rpn_msr/anchor_target_layer_tf_bus.py.
+ * Stage 3  wssdl_anchor_targets: final labels -> the four output blobs
+ *   (:219-299): rpn_labels [n_out,1,A*H,W] f32, bbox_targets / inside / outside
+ *   weights [n_out,4A,H,W] f32.  Images n_images..n_out-1 are the all-ignore
+ *   weak images of the joint layer (:613-626) / anchor_target_layer_ws (:306-325). */
+WSSDL_API size_t wssdl_anchor_workspace_bytes(int n_images);
+WSSDL_API int wssdl_anchor_labels(const float *gt_boxes, int max_gt, const int32_t *num_gt_boxes,
+                        const float *im_info, int im_info_stride, int n_images, int H, int W,
+                        const double *base_anchors_host, int A, int feat_stride, int dataset,
+                        double positive_overlap, double negative_overlap, int clobber_positives,
+                        int8_t *labels_pre, int32_t *argmax_gt, int32_t *counts,
+                        void *workspace, size_t workspace_bytes, wssdl_stream_t stream);
+WSSDL_API int wssdl_anchor_subsample_device(int8_t *labels, int n_images, int total_anchors,
+                                  int rpn_batchsize, double fg_fraction, uint64_t seed,
+                                  wssdl_stream_t stream);
+WSSDL_API int wssdl_anchor_targets(const int8_t *labels, const int32_t *argmax_gt, const float *gt_boxes,
+                         int max_gt, int n_images, int n_out, int H, int W,
+                         const double *base_anchors_host, int A, int feat_stride,
+                         const float *inside_weights_host /* [4] */, double positive_weight,
+                         float *rpn_labels, float *bbox_targets, float *inside_w, float *outside_w,
+                         wssdl_stream_t stream);
+
+/* --------------------------------------------------------------------- a10 ---
+ * proposal-target layer, rpn_msr/proposal_target_layer_tf_bus.py:15-295.
+ * Stage 1  wssdl_roi_gt_assign: rois [R,5] f32 x positive gt of each roi's image:
+ *   f64 IoU (utils/bbox.pyx), max_overlap [R] f64, assignment [R] i32 (row of
+ *   gt_boxes of that image; first maximum, numpy argmax).  (:233-238)
+ * Stage 2  sampling: host (reference RNG) or torch ops in the host layer.
+ * Stage 3  wssdl_roi_targets: for the kept rows: labels (bg clamped to 0, :265),
+ *   bbox_transform in f32 (:220), expansion to 4*num_classes with inside/outside
+ *   weights (:187-210, :89).  keep [n_keep] i32 indexes rois; is_fg [n_keep] u8. */
+WSSDL_API int wssdl_roi_gt_assign(const float *rois, int R, const float *gt_boxes, int max_gt,
+                        const int32_t *num_pos_boxes, int n_images, double *max_overlap,
+                        int32_t *assignment, wssdl_stream_t stream);
+WSSDL_API int wssdl_roi_targets(const float *rois, const int32_t *keep, const uint8_t *is_fg, int n_keep,
+                      const int32_t *assignment, const float *gt_boxes, int max_gt, int num_classes,
+                      const float *inside_weights_host /* [4] */, float *rois_out, float *labels,
+                      float *bbox_targets, float *inside_w, float *outside_w,
+                      wssdl_stream_t stream);
+
+/* ---------------------------------------------------------------- a11, a12 ---
+ * RoiPool forward: roi_pooling_op.cc:31-52 (op), kernels roi_pooling_op_gpu.cu.cc:20-85
+ * (rounding CUDA) / roi_pooling_op.cc:137-196 (rounding CPU).
+ * bottom [N,H,W,C] f32, rois [R,5] f32, top [R,PH,PW,C] f32, argmax [R,PH,PW,C] i32
+ * (flat NHWC index within the roi's image, -1 for an empty bin). */
+WSSDL_API int wssdl_roi_pool_forward(const float *bottom, int N, int H, int W, int C, const float *rois,
+                           int R, int pooled_h, int pooled_w, float spatial_scale, int rounding,
+                           float *top, int32_t *argmax, wssdl_stream_t stream);
+/* RoiPoolGrad: roi_pooling_op.cc:54-63 (op), roi_pooling_op_gpu.cu.cc:114-190 ==
+ * roi_pooling_op.cc:383-458.  bottom_diff [N,H,W,C] f32 is fully written (no
+ * pre-zeroing needed).  Deterministic: per element the f32 sum runs in the
+ * reference's order roi^, ph^, pw^, so results are bit-identical to it. */
+WSSDL_API int wssdl_roi_pool_backward(const float *top_diff, const int32_t *argmax, const float *rois,
+                            int R, int N, int H, int W, int C, int pooled_h, int pooled_w,
+                            float spatial_scale, float *bottom_diff, wssdl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WSSDL_BUS_HIP_H */

@@ -1,0 +1,421 @@
+"""Parity of the HIP path (through the C ABI, via the host mirror) against the CPU
+oracle and the committed golden vectors.  Needs a real MI355X: run with -m gpu.
+
+Bars: bit-exact for integer / index / label work and for f32/f64 arithmetic that does
+not go through exp/log; RoI-pool activations and gradients bit-exact (<= 1e-5 is the
+north-star tolerance); decoded boxes and regression targets within a few ulp (the
+reference's own np.exp / np.log are not correctly rounded)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import c_oracle, np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+STRIDE = [16, ]
+SCALES = [8, 16, 32]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    from wssdl_bus_amd import _lib
+    _lib.lib()          # fail loudly if the HIP library is missing
+    return torch
+
+
+def groups(npz):
+    return sorted({k.split("/")[0] for k in npz.files if "/" in k})
+
+
+def ulp_diff_f32(a, b):
+    a = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, np.int64(-2 ** 31) - a, a)
+    b = np.where(b < 0, np.int64(-2 ** 31) - b, b)
+    return np.abs(a - b)
+
+
+# ------------------------------------------------------------------- anchors ---
+
+def test_shifted_anchors(torch_cuda):
+    from wssdl_bus_amd.rpn_msr.generate_anchors import generate_anchors, shifted_anchors
+    base = generate_anchors(scales=np.array(SCALES))
+    for H, W in ((37, 62), (38, 63), (63, 100), (1, 1)):
+        got = shifted_anchors(H, W, STRIDE, base).cpu().numpy()
+        assert np.array_equal(got, O.shifted_anchors(H, W, 16, O.generate_anchors(scales=SCALES)))
+
+
+# ----------------------------------------------------------------------- IoU ---
+
+def test_bbox_overlaps_golden_and_random(torch_cuda):
+    from wssdl_bus_amd.utils.cython_bbox import bbox_overlaps
+    from wssdl_bus_amd.utils.cython_bbox_ui import bbox_overlaps_ui
+    g = load_golden("bbox_overlaps")
+    assert np.array_equal(bbox_overlaps(g["boxes"], g["query"]), g["iou"])
+    assert np.array_equal(bbox_overlaps_ui(g["boxes"], g["query"]), g["ui"])
+    rs = np.random.RandomState(0)
+    for n, k in ((1, 1), (8151, 3), (32276, 20), (3000, 300)):
+        xy = rs.uniform(-50, 1500, size=(n, 2))
+        b = np.hstack((xy, xy + rs.uniform(0, 600, size=(n, 2))))
+        q = b[rs.choice(n, k)] + rs.uniform(-8, 8, size=(k, 4))
+        assert np.array_equal(bbox_overlaps(b, q), O.bbox_overlaps(b, q))
+        assert np.array_equal(bbox_overlaps_ui(b, q), O.bbox_overlaps_ui(b, q))
+    # 5-column gt rows: only columns 0..3 are read
+    q5 = np.hstack((q, np.ones((q.shape[0], 1))))
+    assert np.array_equal(bbox_overlaps(b, q5), O.bbox_overlaps(b, q))
+    assert bbox_overlaps(np.zeros((0, 4)), q).shape == (0, q.shape[0])
+    assert bbox_overlaps(b, np.zeros((0, 4))).shape == (b.shape[0], 0)
+    t = torch_cuda.from_numpy(b).cuda()
+    out = bbox_overlaps(t, torch_cuda.from_numpy(q).cuda())
+    assert out.is_cuda and np.array_equal(out.cpu().numpy(), O.bbox_overlaps(b, q))
+
+
+# ----------------------------------------------------------------------- NMS ---
+
+def test_nms_golden(torch_cuda):
+    from wssdl_bus_amd.fast_rcnn.nms_wrapper import nms
+    g = load_golden("nms")
+    for name in groups(g):
+        dets = g[name + "/dets"]
+        for key, th in (("keep_07", 0.7), ("keep_03", 0.3)):
+            if name + "/" + key in g.files:
+                assert nms(dets, th) == g[name + "/" + key].tolist(), (name, key)
+    assert nms(np.zeros((0, 5), np.float32), 0.7) == []
+
+
+def test_nms_threshold_rule_and_max_keep(torch_cuda):
+    from wssdl_bus_amd.nms.hip_nms import hip_nms
+    d = np.array([[10, 10, 19, 19, 0.9], [10, 10, 19, 16, 0.8]], dtype=np.float32)
+    assert hip_nms(d, 0.7) == [0, 1]                       # (double)0.7f < 0.7: kept
+    assert hip_nms(d, float(np.float32(0.7))) == [0]
+    g = load_golden("nms")
+    dets = g["n12000/dets"]
+    full = g["n12000/keep_07"].tolist()
+    assert hip_nms(dets, 0.7, max_keep=2000) == full[:2000]
+    assert hip_nms(dets, 0.7, max_keep=1) == full[:1]
+    keep = hip_nms(torch_cuda.from_numpy(dets).cuda(), 0.7)
+    assert keep.is_cuda and keep.cpu().tolist() == full
+
+
+def test_nms_random_vs_oracle(torch_cuda):
+    from wssdl_bus_amd.nms.hip_nms import hip_nms
+    rs = np.random.RandomState(1)
+    for n in (3, 63, 64, 65, 129, 1000, 4097):
+        c = rs.uniform(0, 400, size=(n, 2))
+        wh = rs.uniform(5, 150, size=(n, 2))
+        d = np.hstack((c, c + wh, rs.permutation(n)[:, None] / float(n))).astype(np.float32)
+        for th in (0.3, 0.7):
+            assert hip_nms(d, th) == O.nms(d, th), (n, th)
+
+
+# ------------------------------------------------------------------ RoI pool ---
+
+def _random_rois(rs, R, N, im_h, im_w):
+    x1 = rs.uniform(0, im_w - 20, R)
+    y1 = rs.uniform(0, im_h - 20, R)
+    w = np.exp(rs.uniform(np.log(16), np.log(im_w), R))
+    h = np.exp(rs.uniform(np.log(16), np.log(im_h), R))
+    rois = np.stack([rs.randint(0, N, R), x1, y1, np.minimum(x1 + w, im_w - 1),
+                     np.minimum(y1 + h, im_h - 1)], axis=1).astype(np.float32)
+    return rois
+
+
+def test_roi_pool_known_answers(torch_cuda):
+    from wssdl_bus_amd.roi_pooling_layer.roi_pooling_op import roi_pool
+    n, h, w, c = np.meshgrid(np.arange(32), np.arange(100), np.arange(100), np.arange(1), indexing="ij")
+    f = (10000.0 * n + 100.0 * h + w).astype(np.float32)
+    rois = np.array([[0, 10, 10, 20, 20], [31, 30, 30, 40, 40]], np.float32)   # roi_pooling_op_test.py:18
+    top, arg = roi_pool(f, rois, 6, 6, 1.0 / 3)
+    last = np.array([3, 4, 5, 6, 7, 7])
+    assert np.array_equal(top[0, :, :, 0], (100.0 * last[:, None] + last[None, :]).astype(np.float32))
+    assert np.array_equal(arg[0, :, :, 0], last[:, None] * 100 + last[None, :])
+    for mode in ("cuda", "cpu"):
+        et, ea = c_oracle.roi_pool_forward(f, rois, 6, 6, 1.0 / 3, mode)
+        top, arg = roi_pool(f, rois, 6, 6, 1.0 / 3, rounding=mode)
+        assert np.array_equal(top, et) and np.array_equal(arg, ea)
+    f4 = f[:1, :4, :4]
+    top, arg = roi_pool(f4, np.array([[0, 16, 16, 16, 16]], np.float32), 7, 7, 1.0 / 16, rounding="cpu")
+    assert (arg == -1).sum() == 48 and top[0, 6, 6, 0] == 101.0
+
+
+@pytest.mark.parametrize("C", [256, 512, 1024, 6])
+@pytest.mark.parametrize("mode", ["cuda", "cpu"])
+def test_roi_pool_forward_vs_oracle(torch_cuda, C, mode):
+    from wssdl_bus_amd.roi_pooling_layer.roi_pooling_op import roi_pool
+    rs = np.random.RandomState(C)
+    N, H, W = 2, 38, 63
+    f = np.maximum(rs.normal(size=(N, H, W, C)), 0).astype(np.float32)      # post-ReLU: ties at 0
+    rois = _random_rois(rs, 300, N, 600, 1000)
+    rois[:10, 3:] = rois[:10, 1:3] + rs.uniform(0, 60, (10, 2))              # smaller than 7x7 cells
+    et, ea = c_oracle.roi_pool_forward(f, rois, 7, 7, 1.0 / 16, mode, threads=8)
+    top, arg = roi_pool(f, rois, 7, 7, 1.0 / 16, rounding=mode)
+    assert np.array_equal(arg, ea)
+    assert np.array_equal(top, et)      # max of f32 values: exact, well inside the 1e-5 bar
+
+
+@pytest.mark.parametrize("C", [256, 1024, 6, 70])
+def test_roi_pool_backward_vs_oracle_bitwise(torch_cuda, C):
+    from wssdl_bus_amd.roi_pooling_layer.roi_pooling_op import roi_pool, roi_pool_grad
+    rs = np.random.RandomState(100 + C)
+    N, H, W = 3, 38, 63
+    f = np.maximum(rs.normal(size=(N, H, W, C)), 0).astype(np.float32)
+    rois = _random_rois(rs, 400, N, 600, 1000)
+    rois = rois[rs.permutation(400)]                      # RoIs NOT grouped by image
+    rois[:10, 3:] = rois[:10, 1:3] + rs.uniform(0, 60, (10, 2))
+    for mode in ("cuda", "cpu"):
+        top, arg = roi_pool(f, rois, 7, 7, 1.0 / 16, rounding=mode)
+        diff = rs.normal(size=top.shape).astype(np.float32)
+        want = c_oracle.roi_pool_backward(diff, arg, rois, f.shape, 7, 7, 1.0 / 16)
+        got = roi_pool_grad(f, rois, arg, diff, 7, 7, 1.0 / 16)
+        assert np.array_equal(got, want), (C, mode)       # same f32 summation order as the reference
+
+
+def test_roi_pool_backward_literal_gather_small(torch_cuda):
+    # against the literal restatement of the reference's gather (O(NHWC*R))
+    from wssdl_bus_amd.roi_pooling_layer.roi_pooling_op import roi_pool, roi_pool_grad
+    rs = np.random.RandomState(5)
+    f = np.maximum(rs.normal(size=(2, 9, 13, 8)), 0).astype(np.float32)
+    rois = _random_rois(rs, 50, 2, 140, 200)
+    top, arg = roi_pool(f, rois, 7, 7, 1.0 / 16)
+    diff = rs.normal(size=top.shape).astype(np.float32)
+    want = c_oracle.roi_pool_backward(diff, arg, rois, f.shape, 7, 7, 1.0 / 16, literal=True)
+    assert np.array_equal(roi_pool_grad(f, rois, arg, diff, 7, 7, 1.0 / 16), want)
+
+
+def test_roi_pool_full_size_properties(torch_cuda):
+    """BASELINE config 3 size (R = 4*128 + 4*2000 = 8512, C = 1024, 8 images 38x63):
+    size-independent properties instead of a full oracle run."""
+    torch = torch_cuda
+    from wssdl_bus_amd.roi_pooling_layer.roi_pooling_op import roi_pool, roi_pool_grad
+    rs = np.random.RandomState(3)
+    N, H, W, C, R = 8, 38, 63, 1024, 8512
+    f = torch.relu(torch.randn((N, H, W, C), device="cuda", generator=torch.Generator("cuda").manual_seed(3)))
+    rois_np = _random_rois(rs, R, N, 600, 1000)
+    rois_np = rois_np[np.argsort(rois_np[:, 0], kind="stable")]
+    rois = torch.from_numpy(rois_np).cuda()
+    top, arg = roi_pool(f, rois, 7, 7, 1.0 / 16)
+    # (1) argmax names an element of the right image holding exactly the pooled value
+    b = rois[:, 0].long().view(R, 1, 1, 1).expand_as(arg)
+    nz = arg >= 0
+    flat = f.reshape(N, -1)
+    assert torch.equal(flat[b[nz], arg[nz].long()], top[nz])
+    assert bool((top[~nz] == 0).all())
+    assert bool(((arg[nz] % C) == torch.arange(C, device="cuda").view(1, 1, 1, C).expand_as(arg)[nz]).all())
+    # (2) a sample of RoIs agrees with the oracle bit for bit
+    sel = rs.choice(R, 64, replace=False)
+    et, ea = c_oracle.roi_pool_forward(f.cpu().numpy(), rois_np[sel], 7, 7, 1.0 / 16, "cuda", threads=8)
+    assert np.array_equal(top[sel].cpu().numpy(), et) and np.array_equal(arg[sel].cpu().numpy(), ea)
+    # (3) backward: mass conservation in f64 and linearity / determinism
+    d1 = torch.randn(top.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(4))
+    g1 = roi_pool_grad(f, rois, arg, d1, 7, 7, 1.0 / 16)
+    g1b = roi_pool_grad(f, rois, arg, d1, 7, 7, 1.0 / 16)
+    assert torch.equal(g1, g1b)                                     # deterministic (no atomics)
+    routed = torch.where(nz, d1, torch.zeros_like(d1)).double().sum().item()
+    assert abs(g1.double().sum().item() - routed) < 1e-2 * max(1.0, abs(routed)) + 5.0
+    g2 = roi_pool_grad(f, rois, arg, 2.0 * d1, 7, 7, 1.0 / 16)
+    assert torch.equal(g2, 2.0 * g1)                                # scaling by 2 is exact in f32
+    # (4) the same sample, backward, against the oracle on one image's RoIs
+    img0 = np.where(rois_np[:, 0] == 0)[0][:200]
+    want = c_oracle.roi_pool_backward(d1[img0].cpu().numpy(), arg[img0].cpu().numpy(), rois_np[img0],
+                                      (1, H, W, C), 7, 7, 1.0 / 16)
+    got = roi_pool_grad(f[:1], rois[img0], arg[img0], d1[img0], 7, 7, 1.0 / 16)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_roi_pool_autograd_function(torch_cuda):
+    torch = torch_cuda
+    from wssdl_bus_amd.roi_pooling_layer.roi_pooling_op import roi_pool_autograd
+    rs = np.random.RandomState(8)
+    f_np = rs.normal(size=(2, 12, 15, 16)).astype(np.float32)
+    rois_np = _random_rois(rs, 30, 2, 190, 240)
+    f = torch.from_numpy(f_np).cuda().requires_grad_(True)
+    top, arg = roi_pool_autograd(f, torch.from_numpy(rois_np).cuda(), 7, 7, 1.0 / 16)
+    w = torch.from_numpy(rs.normal(size=tuple(top.shape)).astype(np.float32)).cuda()
+    (top * w).sum().backward()
+    want = c_oracle.roi_pool_backward(w.cpu().numpy(), arg.cpu().numpy(), rois_np, f_np.shape, 7, 7, 1.0 / 16)
+    assert np.array_equal(f.grad.cpu().numpy(), want)
+
+
+# ------------------------------------------------------------- anchor target ---
+
+@pytest.mark.parametrize("shape", ["vgg_37x62", "res_38x63", "res_63x100"])
+def test_anchor_target_golden(torch_cuda, shape):
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.rpn_msr.anchor_target_layer_tf_bus import anchor_target_layer
+    g = load_golden("anchor_target_" + shape)
+    H, W = int(g["H"]), int(g["W"])
+    score = np.zeros((1, H, W, 18), np.float32)
+    cfg.SAMPLING_RNG = "reference"
+    for name in groups(g):
+        gt = g[name + "/gt_boxes"][None]
+        ng = g[name + "/num_gt"]
+        ii = g[name + "/im_info"][None]
+        ds = str(g[name + "/dataset"])
+        cfg.TRAIN.RPN_BATCHSIZE = 10 ** 9
+        try:
+            pre = anchor_target_layer(score, gt, ng, ii, None, STRIDE, SCALES, ds)
+        finally:
+            cfg.TRAIN.RPN_BATCHSIZE = 256
+        assert np.array_equal(pre[0].astype(np.int8), g[name + "/labels_pre"]), name   # bit-identical labels
+        assert ulp_diff_f32(pre[1], g[name + "/targets_pre"]).max() <= 1, name
+        rng = np.random.RandomState(int(g[name + "/seed"]))
+        fin = anchor_target_layer(score, gt, ng, ii, None, STRIDE, SCALES, ds, rng=rng)
+        assert np.array_equal(fin[0].astype(np.int8), g[name + "/labels"]), name
+        assert ulp_diff_f32(fin[1], g[name + "/targets"]).max() <= 1, name
+        assert np.array_equal(fin[2], g[name + "/inside_w"]), name
+        assert np.array_equal(fin[3], g[name + "/outside_w"]), name
+        # dx, dy go through IEEE ops only: exact
+        A = 9
+        t = fin[1].reshape(A, 4, H, W)
+        e = g[name + "/targets"].reshape(A, 4, H, W)
+        assert np.array_equal(t[:, :2], e[:, :2]), name
+
+
+def test_anchor_target_joint_ws_golden(torch_cuda):
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.rpn_msr.anchor_target_layer_tf_bus import (
+        anchor_target_layer_joint, anchor_target_layer_ws)
+    g = load_golden("anchor_target_joint")
+    gt, ng, ii = g["gt_boxes"], g["num_gt"], g["im_info"]
+    score = np.zeros((3, 38, 63, 18), np.float32)
+    cfg.SAMPLING_RNG = "reference"
+    cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.WS_IMS_PER_BATCH = 1, 2
+    jt = anchor_target_layer_joint(score, gt, ng, ii, None, True, STRIDE, SCALES, "SNUBH",
+                                   rng=np.random.RandomState(int(g["seed"])))
+    assert jt[0].shape == (3, 1, 342, 63)
+    assert np.array_equal(jt[0].astype(np.int8), g["train_labels"])
+    assert ulp_diff_f32(jt[1], g["train_targets"]).max() <= 1
+    assert np.array_equal(jt[2], g["train_inside"]) and np.array_equal(jt[3], g["train_outside"])
+    jf = anchor_target_layer_joint(score[:1], gt[:1], ng[:1], ii[:1], None, False, STRIDE, SCALES,
+                                   "SNUBH", rng=np.random.RandomState(int(g["seed"])))
+    assert jf[0].shape[0] == 1 and np.array_equal(jf[0].astype(np.int8), g["test_labels"])
+    ws = anchor_target_layer_ws(score[1:], gt[1:], ng[1:], ii[1:], None, STRIDE, SCALES)
+    assert np.array_equal(ws[0].astype(np.int8), g["ws_labels"])
+    assert tuple(g["ws_shape"]) == ws[1].shape and not ws[1].any() and not ws[2].any() and not ws[3].any()
+
+
+def test_anchor_target_device_sampling_invariants(torch_cuda):
+    torch = torch_cuda
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.rpn_msr.anchor_target_layer_tf_bus import anchor_target_layer
+    g = load_golden("anchor_target_res_38x63")
+    score = np.zeros((1, 38, 63, 18), np.float32)
+    cfg.SAMPLING_RNG = "device"
+    try:
+        for name in ("FILE04254", "outside_quirk", "big_pos", "twenty"):
+            gt = torch.from_numpy(g[name + "/gt_boxes"][None]).cuda()
+            ng = torch.from_numpy(g[name + "/num_gt"]).cuda()
+            ii = torch.from_numpy(g[name + "/im_info"][None]).cuda()
+            outs = [anchor_target_layer(torch.from_numpy(score).cuda(), gt, ng, ii, None, STRIDE,
+                                        SCALES, str(g[name + "/dataset"])) for _ in range(2)]
+            pre = g[name + "/labels_pre"]
+            for lab, tg, inw, outw in outs:
+                lab = lab.cpu().numpy().astype(np.int8)
+                n_fg_pre, n_bg_pre = int((pre == 1).sum()), int((pre == 0).sum())
+                n_fg, n_bg = int((lab == 1).sum()), int((lab == 0).sum())
+                assert n_fg == min(n_fg_pre, 128)                       # :202-207
+                assert n_bg == min(n_bg_pre, 256 - n_fg)                # :212-217
+                assert np.all(pre[lab == 1] == 1) and np.all(pre[lab == 0] == 0)   # subset of pre
+                w = outw.cpu().numpy()
+                assert np.allclose(w[w > 0], 1.0 / (n_fg + n_bg))
+            if (pre == 0).sum() > 256:      # two calls draw different subsets
+                assert not torch.equal(outs[0][0], outs[1][0])
+    finally:
+        cfg.SAMPLING_RNG = "reference"
+
+
+# ------------------------------------------------------------ proposal layer ---
+
+@pytest.mark.parametrize("case", ["res_38x63_train", "res_38x63_test", "vgg_37x62_train",
+                                  "res_63x100_test"])
+def test_proposal_layer_golden(torch_cuda, case):
+    torch = torch_cuda
+    from wssdl_bus_amd.rpn_msr.proposal_layer_tf_bus import proposal_layer, proposal_layer_padded
+    g = load_golden("proposal_layer")
+    prob, pred, info = g[case + "/prob"], g[case + "/pred"], g[case + "/im_info"]
+    train = bool(g[case + "/is_training"])
+    N, H, W = prob.shape[:3]
+    pre, post = (12000, 2000) if train else (6000, 300)
+    rois_p, counts, dec, sidx, scnt = proposal_layer_padded(prob, pred, info, train, STRIDE, SCALES,
+                                                            debug=True)
+    rois_p, counts, dec, sidx, scnt = [t.cpu().numpy() for t in (rois_p, counts, dec, sidx, scnt)]
+    anchors = O.shifted_anchors(H, W, 16, O.generate_anchors(scales=SCALES))
+    blob = proposal_layer(prob, pred, info, train, False, STRIDE, SCALES)
+    assert blob.dtype == np.float32 and blob.shape[1] == 5
+    off = 0
+    for i in range(N):
+        st = O.proposal_stages_one_image(prob[i], pred[i], info[i], anchors, 9, pre, post, 0.7, 16)
+        # a6: decoded + clipped boxes: exp-limited tolerance (np.exp is ~2.5 ulp accurate)
+        assert np.allclose(dec[i], st["decoded"], rtol=2e-6, atol=2e-4)
+        # a7: identical candidate order (scores are pairwise distinct by construction)
+        n = int(scnt[i])
+        assert n == len(st["order"])
+        assert np.array_equal(sidx[i, :n], st["order"])
+        # a8: NMS on the GPU-decoded boxes, checked by the oracle NMS on those same boxes
+        dets = np.hstack((dec[i][sidx[i, :n]], st["sorted_scores"][:, None])).astype(np.float32)
+        keep = np.asarray(O.nms(dets, 0.7)[:post], dtype=np.int64)
+        c = int(counts[i])
+        assert c == len(keep)
+        assert np.array_equal(rois_p[i, :c, 1:], dets[keep, :4])
+        assert np.all(rois_p[i, :c, 0] == i) and not rois_p[i, c:].any()
+        assert np.array_equal(blob[off:off + c], rois_p[i, :c])
+        off += c
+    assert off == blob.shape[0]
+    # a9 end to end vs the reference's own output: same rois up to exp rounding;
+    # a flipped NMS decision at the threshold would shift rows, so require >= 99.5 %
+    ref = g[case + "/rois"]
+    m = min(len(ref), len(blob))
+    close = np.all(np.abs(ref[:m] - blob[:m]) <= 1e-3, axis=1)
+    assert abs(len(ref) - len(blob)) <= max(2, len(ref) // 200)
+    assert close.mean() >= 0.995
+
+
+def test_proposal_layer_gpu_tensor_io_and_empty_image(torch_cuda):
+    torch = torch_cuda
+    from wssdl_bus_amd.rpn_msr.proposal_layer_tf_bus import proposal_layer
+    g = load_golden("proposal_layer")
+    prob = torch.from_numpy(g["res_38x63_test/prob"]).cuda()
+    pred = torch.from_numpy(g["res_38x63_test/pred"]).cuda()
+    info = torch.from_numpy(g["res_38x63_test/im_info"]).cuda()
+    out = proposal_layer(prob, pred, info, False, False, STRIDE, SCALES)
+    assert out.is_cuda and out.shape == (300, 5)
+    # an image too small for any box to pass the min-size filter -> zero rois
+    tiny = torch.tensor([[10.0, 10.0, 1.0, 1.0]], device="cuda")
+    out = proposal_layer(prob, pred, tiny, False, False, STRIDE, SCALES)
+    assert out.shape == (0, 5)
+
+
+# ----------------------------------------------------------- proposal target ---
+
+def test_proposal_target_golden(torch_cuda):
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.rpn_msr.proposal_target_layer_tf_bus import (
+        proposal_target_layer, proposal_target_layer_joint)
+    g = load_golden("proposal_target")
+    rois, gt, ng = g["rois_in"], g["gt_boxes"], g["num_gt"]
+    names = ("rois", "labels", "targets", "inside", "outside")
+
+    def check(o, tag):
+        for k, nm in enumerate(names):
+            e = g["%s/%s" % (tag, nm)]
+            assert o[k].shape == e.shape, (tag, nm, o[k].shape, e.shape)
+            if nm == "targets":
+                assert ulp_diff_f32(o[k], e).max() <= 4, (tag, nm)     # np.log f32 is ~3.8 ulp accurate
+            else:
+                assert np.array_equal(o[k], e), (tag, nm)
+
+    for tag, args in (("alt_train", (True, False)), ("alt_ws", (True, True)), ("alt_test", (False, False))):
+        o = proposal_target_layer(rois, gt, ng, 3, args[0], args[1],
+                                  rng=np.random.RandomState(int(g["seed_alt"])))
+        check(o, tag)
+    cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.WS_IMS_PER_BATCH = 1, 1
+    try:
+        for tag, tr in (("joint_train", True), ("joint_test", False)):
+            o = proposal_target_layer_joint(rois, gt, ng, 3, tr,
+                                            rng=np.random.RandomState(int(g["seed_joint"])))
+            check(o, tag)
+    finally:
+        cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.WS_IMS_PER_BATCH = 1, 2

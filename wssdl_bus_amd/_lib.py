@@ -1,0 +1,133 @@
+"""ctypes binding of ``libwssdl_bus_hip.so`` (C ABI: ``include/wssdl_bus_hip.h``).
+
+The product path has NO fallback: if the library is missing this module raises,
+and every op in this package goes through it.  PyTorch is only used here for
+device memory (``tensor.data_ptr()``) and the current HIP stream.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwssdl_bus_hip.so")
+
+OK, ERR_INVALID_ARGUMENT, ERR_WORKSPACE, ERR_LAUNCH = 0, 1, 2, 3
+ROUND_CUDA, ROUND_CPU = 0, 1
+DATASET_SNUBH, DATASET_SNUBH_FG, DATASET_FG_ONLY = 0, 1, 2
+MAX_ANCHORS, MAX_GT = 32, 64
+
+# every symbol include/wssdl_bus_hip.h declares: (restype, argtypes)
+_vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+_sz, _u64 = ctypes.c_size_t, ctypes.c_uint64
+SYMBOLS = {
+    "wssdl_version": (ctypes.c_char_p, []),
+    "wssdl_last_error": (ctypes.c_char_p, []),
+    "wssdl_generate_anchors_host": (_i, [_i, _vp, _i, _vp, _i, _vp]),
+    "wssdl_shifted_anchors": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "wssdl_bbox_overlaps": (_i, [_vp, _i64, _i, _vp, _i64, _i, _vp, _vp]),
+    "wssdl_bbox_overlaps_ui": (_i, [_vp, _i64, _i, _vp, _i64, _i, _vp, _vp]),
+    "wssdl_nms_workspace_bytes": (_sz, [_i]),
+    "wssdl_nms": (_i, [_vp, _i, _d, _i, _vp, _vp, _vp, _sz, _vp]),
+    "wssdl_proposal_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "wssdl_proposal_layer": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _d, _f,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "wssdl_proposal_compact": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp]),
+    "wssdl_anchor_workspace_bytes": (_sz, [_i]),
+    "wssdl_anchor_labels": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _d, _d, _i,
+                                 _vp, _vp, _vp, _vp, _sz, _vp]),
+    "wssdl_anchor_subsample_device": (_i, [_vp, _i, _i, _i, _d, _u64, _vp]),
+    "wssdl_anchor_targets": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _d,
+                                  _vp, _vp, _vp, _vp, _vp]),
+    "wssdl_roi_gt_assign": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "wssdl_roi_targets": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp]),
+    "wssdl_roi_pool_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "wssdl_roi_pool_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipCallError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library.  Raises HipLibraryMissing when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                "%s not found: build it with `python -m wssdl_bus_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)        # AttributeError if the .so lacks a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+_STATUS = {1: "invalid argument", 2: "workspace too small", 3: "HIP launch error"}
+
+
+def check(rc, what):
+    if rc != OK:
+        err = lib().wssdl_last_error().decode()
+        raise HipCallError("%s failed: %s%s" % (what, _STATUS.get(rc, "status %d" % rc),
+                                                (" (%s)" % err) if err else ""))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def host_ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipCallError("expected a tensor on the GPU, got device %s" % t.device)
+
+
+def to_device(x, dtype, device=None):
+    """numpy array / tensor -> contiguous GPU tensor of `dtype` (the py_func
+    boundary of the reference hands the layers numpy copies, network.py:216)."""
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(x))
+    dev = device if device is not None else (t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device()))
+    return t.to(device=dev, dtype=dtype).contiguous()
+
+
+def wants_numpy(*xs):
+    """True when the caller passed numpy data (then outputs go back as numpy)."""
+    return not any(isinstance(x, torch.Tensor) for x in xs if x is not None)
+
+
+def generate_anchors_host(base_size, ratios, scales):
+    r = np.ascontiguousarray(ratios, dtype=np.float64).ravel()
+    s = np.ascontiguousarray(scales, dtype=np.float64).ravel()
+    out = np.zeros((len(r) * len(s), 4), dtype=np.float64)
+    n = lib().wssdl_generate_anchors_host(int(base_size), host_ptr(r), len(r), host_ptr(s), len(s),
+                                          host_ptr(out))
+    if n < 0:
+        check(-n, "wssdl_generate_anchors_host")
+    return out

@@ -1,0 +1,52 @@
+"""Build libwssdl_bus_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+    python -m wssdl_bus_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Flags that matter for parity:
+  -ffp-contract=off   no FMA contraction: IoU / NMS / decode arithmetic must round
+                      every multiply and add separately, like the reference's C.
+The output lives next to the sources (git-ignored; it travels to the GPU box).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libwssdl_bus_hip.so")
+SOURCES = ["api_common.hip", "bbox_overlaps.hip", "nms.hip", "proposal.hip", "anchor_target.hip",
+           "roi_targets.hip", "roi_pool.hip"]
+HEADERS = ["common.hip.h", "nms.hip.h", os.path.join("..", "..", "include", "wssdl_bus_hip.h")]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
+         "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def is_stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not is_stale():
+        return OUT
+    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp"]
+    if verbose:
+        print("[wssdl_bus_amd] " + " ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(OUT + ".tmp", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

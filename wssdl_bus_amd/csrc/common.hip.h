@@ -1,0 +1,56 @@
+// Shared helpers for the gfx950 kernels of libwssdl_bus_hip.so.
+// Built with -ffp-contract=off: parity with the reference depends on every
+// multiply and add being rounded separately (no FMA contraction).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/wssdl_bus_hip.h"
+
+#define WSSDL_WAVE 64
+
+namespace wssdl {
+
+// thread-local record of the last HIP error, surfaced by wssdl_last_error()
+void set_last_error(hipError_t e);
+
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error(e);
+        return WSSDL_ERR_LAUNCH;
+    }
+    return WSSDL_OK;
+}
+
+inline hipStream_t as_stream(wssdl_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// base anchors travel to kernels by value (<= 32 x 4 doubles = 1 KiB of kernarg)
+struct BaseAnchors {
+    double v[WSSDL_MAX_ANCHORS][4];
+};
+
+inline int load_base_anchors(const double *host, int A, BaseAnchors *out) {
+    if (!host || A < 1 || A > WSSDL_MAX_ANCHORS) return WSSDL_ERR_INVALID_ARGUMENT;
+    for (int a = 0; a < A; ++a)
+        for (int j = 0; j < 4; ++j) out->v[a][j] = host[a * 4 + j];
+    return WSSDL_OK;
+}
+
+// workspace carving: 256-byte aligned slices
+struct Carver {
+    char *base;
+    size_t off;
+    explicit Carver(void *p) : base(static_cast<char *>(p)), off(0) {}
+    template <typename T>
+    T *take(size_t n) {
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += (n * sizeof(T) + 255) & ~size_t(255);
+        return p;
+    }
+};
+
+}  // namespace wssdl

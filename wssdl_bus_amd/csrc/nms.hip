@@ -1,0 +1,288 @@
+// Greedy NMS + score ranking for gfx950 (MI355X), batched over images.
+//
+// Reference: code/lib/nms/cpu_nms.pyx:17-68 (the NMS the RPN actually uses:
+// fast_rcnn/config.py:321 USE_GPU_NMS=False) via fast_rcnn/nms_wrapper.py:13-21;
+// sort: rpn_msr/proposal_layer_tf_bus.py:129-133.
+//
+// Three kernels, each launched once for ALL images of a step:
+//   rank_topk   : position of every candidate in descending score order by
+//                 counting (key_j > key_i) over LDS-staged key tiles; 64-bit keys
+//                 = (order-preserving score bits << 32 | index) make the order
+//                 total (ties: higher index first) and the result deterministic.
+//   nms_mask    : 64x64 tiles of the upper triangle of the suppression matrix,
+//                 one u64 word per (row box, column block): 64 column boxes in
+//                 LDS, one row box per lane.  f32 arithmetic in cpu_nms.pyx's
+//                 operation order, test (double)iou >= thresh (vendored
+//                 cpu_nms.c:2495 compares PyFloat objects).
+//   nms_sweep   : one workgroup per image walks the 64-row chunks in order.
+//                 Wave 0 resolves a chunk against its diagonal word entirely in
+//                 scalar registers (v_readlane), appends the kept rows, then all
+//                 waves OR the kept rows' mask words into the LDS-resident
+//                 `removed` bitmap.  Stops as soon as max_keep boxes are kept
+//                 (the reference's caller truncates keep[:post_nms_topN]).
+#include "nms.hip.h"
+
+namespace wssdl {
+
+// ---------------------------------------------------------------- rank/top-k ---
+constexpr int RANK_BLOCK = 256;
+constexpr int RANK_TILE = 1024;
+
+__global__ __launch_bounds__(RANK_BLOCK) void rank_topk_kernel(
+    const unsigned long long *__restrict__ keys, int M, int topn, int *__restrict__ rank_out,
+    int *__restrict__ sorted_index, int *__restrict__ n_sorted) {
+    __shared__ unsigned long long tile[RANK_TILE];
+    const int img = blockIdx.y;
+    const unsigned long long *k = keys + (size_t)img * M;
+    const int i = blockIdx.x * RANK_BLOCK + threadIdx.x;
+    const unsigned long long mine = (i < M) ? k[i] : 0ull;
+    int cnt = 0;
+    for (int j0 = 0; j0 < M; j0 += RANK_TILE) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < RANK_TILE; t += RANK_BLOCK)
+            tile[t] = (j0 + t < M) ? k[j0 + t] : 0ull;
+        __syncthreads();
+#pragma unroll 8
+        for (int t = 0; t < RANK_TILE; ++t) cnt += (tile[t] > mine) ? 1 : 0;
+    }
+    if (i < M) {
+        if (rank_out) rank_out[(size_t)img * M + i] = (mine != 0ull) ? cnt : -1;
+        if (mine != 0ull && cnt < topn) sorted_index[(size_t)img * topn + cnt] = i;
+        // the element with the smallest valid key knows the number of valid keys
+        if (mine != 0ull) atomicMax(&n_sorted[img], min(cnt + 1, topn));
+    }
+}
+
+int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int topn, int *rank_out,
+                     int *sorted_index, int *n_sorted, hipStream_t st) {
+    // sorted_index must be pre-filled with -1 and n_sorted with 0 by the caller
+    hipLaunchKernelGGL(rank_topk_kernel, dim3(cdiv(M, RANK_BLOCK), n_images), dim3(RANK_BLOCK), 0,
+                       st, keys, M, topn, rank_out, sorted_index, n_sorted);
+    return check_launch();
+}
+
+// ------------------------------------------------------------------ nms mask ---
+__device__ __forceinline__ float fmax_ref(float a, float b) { return a >= b ? a : b; }  // cpu_nms.pyx:11
+__device__ __forceinline__ float fmin_ref(float a, float b) { return a <= b ? a : b; }  // cpu_nms.pyx:14
+
+__device__ __forceinline__ float box_area_ref(float x1, float y1, float x2, float y2) {
+    float w = x2 - x1;  w = w + 1.0f;       // numpy f32: (x2 - x1 + 1) * (y2 - y1 + 1), cpu_nms.pyx:24
+    float h = y2 - y1;  h = h + 1.0f;
+    return w * h;
+}
+
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ boxes,
+                                                      int box_stride_img,
+                                                      const int *__restrict__ n_dev, int n_max,
+                                                      double thresh,
+                                                      unsigned long long *__restrict__ mask,
+                                                      int ncb) {
+    const int cb = blockIdx.x, rb = blockIdx.y, img = blockIdx.z;
+    if (cb < rb) return;
+    const int n = min(n_dev[img], n_max);
+    if (rb * 64 >= n || cb * 64 >= n) return;
+    __shared__ float cx1[64], cy1[64], cx2[64], cy2[64], carea[64];
+    const float *b = boxes + (size_t)img * box_stride_img;
+    const int t = threadIdx.x;
+    const int col = cb * 64 + t;
+    if (col < n) {
+        float x1 = b[col * 4 + 0], y1 = b[col * 4 + 1], x2 = b[col * 4 + 2], y2 = b[col * 4 + 3];
+        cx1[t] = x1; cy1[t] = y1; cx2[t] = x2; cy2[t] = y2;
+        carea[t] = box_area_ref(x1, y1, x2, y2);
+    }
+    __syncthreads();
+    const int i = rb * 64 + t;
+    if (i >= n) return;
+    const float ix1 = b[i * 4 + 0], iy1 = b[i * 4 + 1], ix2 = b[i * 4 + 2], iy2 = b[i * 4 + 3];
+    const float iarea = box_area_ref(ix1, iy1, ix2, iy2);
+    const int jn = min(64, n - cb * 64);
+    unsigned long long bits = 0ull;
+    for (int j = 0; j < jn; ++j) {
+        if (cb * 64 + j <= i) continue;
+        float xx1 = fmax_ref(ix1, cx1[j]);
+        float yy1 = fmax_ref(iy1, cy1[j]);
+        float xx2 = fmin_ref(ix2, cx2[j]);
+        float yy2 = fmin_ref(iy2, cy2[j]);
+        float w = xx2 - xx1;  w = fmax_ref(0.0f, w + 1.0f);
+        float h = yy2 - yy1;  h = fmax_ref(0.0f, h + 1.0f);
+        float inter = w * h;
+        float den = iarea + carea[j];
+        den = den - inter;
+        float ovr = inter / den;
+        if ((double)ovr >= thresh) bits |= 1ull << j;
+    }
+    mask[((size_t)img * n_max + i) * ncb + cb] = bits;
+}
+
+int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, int n_max,
+                    int n_images, double thresh, unsigned long long *mask, hipStream_t st) {
+    int ncb = cdiv(n_max, 64);
+    if (ncb == 0 || n_images == 0) return WSSDL_OK;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(ncb, ncb, n_images), dim3(64), 0, st, boxes,
+                       box_stride_img, n_dev, n_max, thresh, mask, ncb);
+    return check_launch();
+}
+
+// ----------------------------------------------------------------- nms sweep ---
+constexpr int SWEEP_BLOCK = 256;
+
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int lane) {
+    unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, lane);
+    unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_kernel(
+    const unsigned long long *__restrict__ mask, const int *__restrict__ n_dev, int n_max, int ncb,
+    int max_keep, const int *__restrict__ order, int order_stride_img,
+    int *__restrict__ keep, int *__restrict__ num_keep,
+    const float *__restrict__ boxes, int box_stride_img, float *__restrict__ rois_padded) {
+    extern __shared__ unsigned long long removed[];   // [ncb]
+    __shared__ unsigned long long s_kept;
+    const int img = blockIdx.x;
+    const int n = min(n_dev[img], n_max);
+    const unsigned long long *m = mask + (size_t)img * n_max * ncb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int w = tid; w < ncb; w += SWEEP_BLOCK) removed[w] = 0ull;
+    __syncthreads();
+    int count = 0;
+    const int nchunks = (n + 63) / 64;
+    for (int c = 0; c < nchunks; ++c) {
+        if (wave == 0) {
+            const int row = c * 64 + lane;
+            unsigned long long diag = (row < n) ? m[(size_t)row * ncb + c] : 0ull;
+            unsigned long long cur = removed[c];
+            cur = readlane_u64(cur, 0);
+            const int nv = n - c * 64;
+            const unsigned long long valid = (nv >= 64) ? ~0ull : ((1ull << nv) - 1ull);
+            unsigned long long kept = 0ull;
+#pragma unroll
+            for (int b = 0; b < 64; ++b) {
+                unsigned long long d = readlane_u64(diag, b);
+                if (!((cur >> b) & 1ull) && ((valid >> b) & 1ull)) {
+                    kept |= 1ull << b;
+                    cur |= d;
+                }
+            }
+            if (lane == 0) s_kept = kept;
+            if ((kept >> lane) & 1ull) {
+                int pos = count + __popcll(kept & ((1ull << lane) - 1ull));
+                if (pos < max_keep) {
+                    if (keep)
+                        keep[(size_t)img * max_keep + pos] =
+                            order ? order[(size_t)img * order_stride_img + row] : row;
+                    if (rois_padded) {
+                        const float *bx = boxes + (size_t)img * box_stride_img + (size_t)row * 4;
+                        float *o = rois_padded + ((size_t)img * max_keep + pos) * 5;
+                        o[0] = (float)img; o[1] = bx[0]; o[2] = bx[1]; o[3] = bx[2]; o[4] = bx[3];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned long long kept = s_kept;
+        count += __popcll(kept);
+        if (count >= max_keep) break;
+        for (int w = c + 1 + tid; w < ncb; w += SWEEP_BLOCK) {
+            unsigned long long acc = removed[w];
+            unsigned long long k = kept;
+            while (k) {
+                int b = __ffsll((long long)k) - 1;
+                k &= k - 1ull;
+                acc |= m[(size_t)(c * 64 + b) * ncb + w];
+            }
+            removed[w] = acc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) num_keep[img] = min(count, max_keep);
+}
+
+int launch_nms_sweep(const unsigned long long *mask, const int *n_dev, int n_max, int n_images,
+                     int max_keep, const int *order, int order_stride_img, int *keep,
+                     int *num_keep, const float *boxes, int box_stride_img, float *rois_padded,
+                     hipStream_t st) {
+    int ncb = cdiv(n_max, 64);
+    if (n_images == 0) return WSSDL_OK;
+    size_t lds = (size_t)(ncb > 0 ? ncb : 1) * sizeof(unsigned long long);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(n_images), dim3(SWEEP_BLOCK), lds, st, mask, n_dev,
+                       n_max, ncb, max_keep, order, order_stride_img, keep, num_keep, boxes,
+                       box_stride_img, rois_padded);
+    return check_launch();
+}
+
+// ------------------------------------------------------- standalone nms entry ---
+__global__ void nms_prepare_kernel(const float *__restrict__ dets, int n,
+                                   unsigned long long *__restrict__ keys) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = score_key(dets[(size_t)i * 5 + 4], (unsigned)i);
+}
+
+__global__ void nms_gather_kernel(const float *__restrict__ dets, const int *__restrict__ order,
+                                  const int *__restrict__ n_sorted, int n,
+                                  float *__restrict__ boxes) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n && p < n_sorted[0]) {
+        const float *d = dets + (size_t)order[p] * 5;
+        boxes[p * 4 + 0] = d[0]; boxes[p * 4 + 1] = d[1]; boxes[p * 4 + 2] = d[2]; boxes[p * 4 + 3] = d[3];
+    }
+}
+
+struct NmsWs {
+    unsigned long long *keys, *mask;
+    int *order, *n_sorted;
+    float *boxes;
+};
+
+static size_t carve_nms(void *ws, int n, NmsWs *out) {
+    Carver c(ws);
+    int ncb = cdiv(n, 64);
+    NmsWs w;
+    w.keys = c.take<unsigned long long>(n);
+    w.order = c.take<int>(n);
+    w.n_sorted = c.take<int>(64);
+    w.boxes = c.take<float>((size_t)n * 4);
+    w.mask = c.take<unsigned long long>((size_t)n * ncb);
+    if (out) *out = w;
+    return c.off;
+}
+
+}  // namespace wssdl
+
+using namespace wssdl;
+
+extern "C" size_t wssdl_nms_workspace_bytes(int n) {
+    if (n <= 0) return 256;
+    return carve_nms(nullptr, n, nullptr);
+}
+
+extern "C" int wssdl_nms(const float *dets, int n, double thresh, int max_keep, int32_t *keep,
+                         int32_t *num_keep, void *workspace, size_t workspace_bytes,
+                         wssdl_stream_t stream) {
+    if (n < 0 || max_keep < 0 || !num_keep) return WSSDL_ERR_INVALID_ARGUMENT;
+    hipStream_t st = as_stream(stream);
+    if (n == 0 || max_keep == 0) {                     // nms_wrapper.py:16-17: empty -> []
+        if (hipMemsetAsync(num_keep, 0, sizeof(int32_t), st) != hipSuccess) return WSSDL_ERR_LAUNCH;
+        return WSSDL_OK;
+    }
+    if (!dets || !keep || !workspace) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (workspace_bytes < wssdl_nms_workspace_bytes(n)) return WSSDL_ERR_WORKSPACE;
+    NmsWs w;
+    carve_nms(workspace, n, &w);
+    if (hipMemsetAsync(w.order, 0xff, sizeof(int) * (size_t)n, st) != hipSuccess ||
+        hipMemsetAsync(w.n_sorted, 0, sizeof(int), st) != hipSuccess)
+        return WSSDL_ERR_LAUNCH;
+    hipLaunchKernelGGL(nms_prepare_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dets, n, w.keys);
+    int rc = check_launch();
+    if (rc) return rc;
+    rc = launch_rank_topk(w.keys, n, 1, n, nullptr, w.order, w.n_sorted, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(nms_gather_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dets, w.order,
+                       w.n_sorted, n, w.boxes);
+    rc = check_launch();
+    if (rc) return rc;
+    rc = launch_nms_mask(w.boxes, n * 4, w.n_sorted, n, 1, thresh, w.mask, st);
+    if (rc) return rc;
+    return launch_nms_sweep(w.mask, w.n_sorted, n, 1, max_keep, w.order, n, keep, num_keep,
+                            nullptr, 0, nullptr, st);
+}

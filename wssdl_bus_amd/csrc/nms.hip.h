@@ -1,0 +1,33 @@
+// Internal interface of nms.hip, shared with proposal.hip.
+#pragma once
+#include "common.hip.h"
+
+namespace wssdl {
+
+// Order-preserving 64-bit sort key: f32 score bits mapped so that unsigned
+// compare == float compare, index in the low word as the tie-break (equal
+// scores: higher index first).  0 is reserved for "not a candidate".
+__host__ __device__ __forceinline__ unsigned long long score_key(float score, unsigned idx) {
+    unsigned u = __builtin_bit_cast(unsigned, score);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)idx;
+}
+
+// keys [n_images, M]; sorted_index [n_images, topn] (pre-filled with -1) receives
+// the index of the element at each descending-score position < topn; n_sorted
+// [n_images] (pre-zeroed) receives min(#valid, topn); rank_out optional [n_images, M].
+int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int topn, int *rank_out,
+                     int *sorted_index, int *n_sorted, hipStream_t st);
+
+// boxes: per image [n_max, 4] f32 in score order (image stride box_stride_img floats);
+// mask: per image [n_max, ceil(n_max/64)] u64, upper triangle written.
+int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, int n_max,
+                    int n_images, double thresh, unsigned long long *mask, hipStream_t st);
+
+// keep (optional) [n_images, max_keep] i32; rois_padded (optional) [n_images, max_keep, 5].
+int launch_nms_sweep(const unsigned long long *mask, const int *n_dev, int n_max, int n_images,
+                     int max_keep, const int *order, int order_stride_img, int *keep,
+                     int *num_keep, const float *boxes, int box_stride_img, float *rois_padded,
+                     hipStream_t st);
+
+}  // namespace wssdl

@@ -1,0 +1,134 @@
+// Proposal-target layer kernels for gfx950 (MI355X).
+//
+// Reference: code/lib/rpn_msr/proposal_target_layer_tf_bus.py:228-280 (_sample_rois),
+// :187-226 (_get_bbox_regression_labels, _compute_targets), utils/bbox.pyx:15-55,
+// fast_rcnn/bbox_transform.py:10-28.
+//
+// roi_gt_assign : one lane per candidate RoI: f64 IoU against the positive gt boxes
+//                 of the RoI's image (bit-identical to the Cython kernel), maximum
+//                 and first arg-max.  The random fg/bg sampling between the two
+//                 kernels belongs to the host layer (it consumes numpy's legacy
+//                 RandomState stream in the reference).
+// roi_targets   : one lane per sampled RoI: label (background clamped to 0, :265),
+//                 all-f32 bbox_transform (:220), expansion into the 4*num_classes
+//                 layout with inside / outside weights (:199-209, :89).
+#include "common.hip.h"
+
+namespace wssdl {
+
+__global__ __launch_bounds__(256) void roi_gt_assign_kernel(
+    const float *__restrict__ rois, int R, const float *__restrict__ gt_boxes, int max_gt,
+    const int *__restrict__ num_pos, int n_images, double *__restrict__ max_overlap,
+    int *__restrict__ assignment) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float *b = rois + (size_t)r * 5;
+    const int img = (int)b[0];
+    double best = 0.0;
+    int arg = -1;
+    if (img >= 0 && img < n_images) {
+        const double bx1 = b[1], by1 = b[2], bx2 = b[3], by2 = b[4];
+        const int np = min(num_pos[img], max_gt);
+        const float *g = gt_boxes + (size_t)img * max_gt * 5;
+        for (int k = 0; k < np; ++k) {
+            const double qx1 = g[k * 5 + 0], qy1 = g[k * 5 + 1], qx2 = g[k * 5 + 2], qy2 = g[k * 5 + 3];
+            const double qarea = (qx2 - qx1 + 1) * (qy2 - qy1 + 1);
+            double ov = 0.0;
+            double iw = fmin(bx2, qx2) - fmax(bx1, qx1) + 1;
+            if (iw > 0) {
+                double ih = fmin(by2, qy2) - fmax(by1, qy1) + 1;
+                if (ih > 0) {
+                    double ua = (bx2 - bx1 + 1) * (by2 - by1 + 1) + qarea - iw * ih;
+                    ov = iw * ih / ua;
+                }
+            }
+            if (k == 0 || ov > best) { best = ov; arg = k; }   // numpy argmax: first maximum
+        }
+    }
+    max_overlap[r] = best;
+    assignment[r] = arg;
+}
+
+__global__ __launch_bounds__(256) void roi_targets_kernel(
+    const float *__restrict__ rois, const int *__restrict__ keep,
+    const unsigned char *__restrict__ is_fg, int n_keep, const int *__restrict__ assignment,
+    const float *__restrict__ gt_boxes, int max_gt, int num_classes, float iw0, float iw1,
+    float iw2, float iw3, float *__restrict__ rois_out, float *__restrict__ labels,
+    float *__restrict__ bbox_targets, float *__restrict__ inside_w, float *__restrict__ outside_w) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_keep) return;
+    const int r = keep[p];
+    const float *b = rois + (size_t)r * 5;
+    float *ro = rois_out + (size_t)p * 5;
+    ro[0] = b[0]; ro[1] = b[1]; ro[2] = b[2]; ro[3] = b[3]; ro[4] = b[4];
+    const int img = (int)b[0];
+    const int k = assignment[r];
+    const int width = 4 * num_classes;
+    float *to = bbox_targets + (size_t)p * width;
+    float *io = inside_w + (size_t)p * width;
+    float *oo = outside_w + (size_t)p * width;
+    for (int j = 0; j < width; ++j) { to[j] = 0.0f; io[j] = 0.0f; oo[j] = 0.0f; }
+    float label = 0.0f;
+    if (k >= 0 && is_fg[p]) {
+        const float *g = gt_boxes + ((size_t)img * max_gt + k) * 5;
+        label = g[4];
+        const int cls = (int)label;
+        if (label > 0.0f && cls < num_classes) {
+            // bbox_transform with f32 operands on both sides (:220)
+            float ew = b[3] - b[1];  ew = ew + 1.0f;
+            float eh = b[4] - b[2];  eh = eh + 1.0f;
+            float hew = 0.5f * ew, heh = 0.5f * eh;
+            const float ecx = b[1] + hew, ecy = b[2] + heh;
+            float gw = g[2] - g[0];  gw = gw + 1.0f;
+            float gh = g[3] - g[1];  gh = gh + 1.0f;
+            float hgw = 0.5f * gw, hgh = 0.5f * gh;
+            const float gcx = g[0] + hgw, gcy = g[1] + hgh;
+            const float t0 = (gcx - ecx) / ew;
+            const float t1 = (gcy - ecy) / eh;
+            const float t2 = (float)log((double)(gw / ew));
+            const float t3 = (float)log((double)(gh / eh));
+            const int s = 4 * cls;
+            to[s + 0] = t0; to[s + 1] = t1; to[s + 2] = t2; to[s + 3] = t3;
+            io[s + 0] = iw0; io[s + 1] = iw1; io[s + 2] = iw2; io[s + 3] = iw3;
+            oo[s + 0] = iw0 > 0.0f ? 1.0f : 0.0f;
+            oo[s + 1] = iw1 > 0.0f ? 1.0f : 0.0f;
+            oo[s + 2] = iw2 > 0.0f ? 1.0f : 0.0f;
+            oo[s + 3] = iw3 > 0.0f ? 1.0f : 0.0f;
+        }
+    }
+    labels[p] = label;
+}
+
+}  // namespace wssdl
+
+using namespace wssdl;
+
+extern "C" int wssdl_roi_gt_assign(const float *rois, int R, const float *gt_boxes, int max_gt,
+                                   const int32_t *num_pos_boxes, int n_images, double *max_overlap,
+                                   int32_t *assignment, wssdl_stream_t stream) {
+    if (R < 0 || max_gt < 1 || n_images < 0) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (R == 0) return WSSDL_OK;
+    if (!rois || !gt_boxes || !num_pos_boxes || !max_overlap || !assignment)
+        return WSSDL_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(roi_gt_assign_kernel, dim3(cdiv(R, 256)), dim3(256), 0, as_stream(stream),
+                       rois, R, gt_boxes, max_gt, num_pos_boxes, n_images, max_overlap, assignment);
+    return check_launch();
+}
+
+extern "C" int wssdl_roi_targets(const float *rois, const int32_t *keep, const uint8_t *is_fg,
+                                 int n_keep, const int32_t *assignment, const float *gt_boxes,
+                                 int max_gt, int num_classes, const float *inside_weights_host,
+                                 float *rois_out, float *labels, float *bbox_targets,
+                                 float *inside_w, float *outside_w, wssdl_stream_t stream) {
+    if (n_keep < 0 || max_gt < 1 || num_classes < 1 || !inside_weights_host)
+        return WSSDL_ERR_INVALID_ARGUMENT;
+    if (n_keep == 0) return WSSDL_OK;
+    if (!rois || !keep || !is_fg || !assignment || !gt_boxes || !rois_out || !labels ||
+        !bbox_targets || !inside_w || !outside_w)
+        return WSSDL_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(roi_targets_kernel, dim3(cdiv(n_keep, 256)), dim3(256), 0, as_stream(stream),
+                       rois, keep, is_fg, n_keep, assignment, gt_boxes, max_gt, num_classes,
+                       inside_weights_host[0], inside_weights_host[1], inside_weights_host[2],
+                       inside_weights_host[3], rois_out, labels, bbox_targets, inside_w, outside_w);
+    return check_launch();
+}

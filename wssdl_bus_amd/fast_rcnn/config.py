@@ -1,0 +1,95 @@
+"""Hot-path configuration constants.
+
+Mirrors the keys of the reference's global ``cfg`` (code/lib/fast_rcnn/config.py:28-31)
+that the detection hot path reads; values and line numbers are the reference's.
+``cfg`` is a plain attribute dict, mutable like the original.
+"""
+
+
+class AttrDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def has_key(self, k):
+        return k in self
+
+
+__C = AttrDict()
+cfg = __C
+
+__C.TRAIN = AttrDict()
+__C.TRAIN.WEIGHT_DECAY = 0.0005                     # config.py:46
+__C.TRAIN.WS_IMS_PER_BATCH = 2                      # :49
+__C.TRAIN.WS_LOSS_USE_ADAPTIVE_SCALE_FACTOR = True  # :51
+__C.TRAIN.WS_LOSS_SCALE_FACTOR = 0.5                # :52
+__C.TRAIN.WS_MAL_PCT = 0.2209                       # :60
+__C.TRAIN.MAX_GT_PER_IMAGE = 20                     # :92
+__C.TRAIN.SCALES = (600,)                           # :109
+__C.TRAIN.MAX_SIZE = 1000                           # :112
+__C.TRAIN.IMS_PER_BATCH = 1                         # :115
+__C.TRAIN.BATCH_SIZE = 128                          # :118
+__C.TRAIN.FG_FRACTION = 0.25                        # :121
+__C.TRAIN.FG_THRESH = 0.5                           # :124
+__C.TRAIN.BG_THRESH_HI = 0.5                        # :128
+__C.TRAIN.BG_THRESH_LO = 0.0                        # :130
+__C.TRAIN.BBOX_INSIDE_WEIGHTS = (1.0, 1.0, 1.0, 1.0)   # :178
+__C.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED = False   # :181
+__C.TRAIN.RPN_POSITIVE_OVERLAP = 0.7                # :196
+__C.TRAIN.RPN_NEGATIVE_OVERLAP = 0.3                # :198
+__C.TRAIN.RPN_CLOBBER_POSITIVES = False             # :200
+__C.TRAIN.RPN_FG_FRACTION = 0.5                     # :202
+__C.TRAIN.RPN_BATCHSIZE = 256                       # :204
+__C.TRAIN.RPN_NMS_THRESH = 0.7                      # :206
+__C.TRAIN.RPN_PRE_NMS_TOP_N = 12000                 # :208
+__C.TRAIN.RPN_POST_NMS_TOP_N = 2000                 # :210
+__C.TRAIN.RPN_MIN_SIZE = 16                         # :212
+__C.TRAIN.RPN_BBOX_INSIDE_WEIGHTS = (1.0, 1.0, 1.0, 1.0)   # :214
+__C.TRAIN.RPN_POSITIVE_WEIGHT = -1.0                # :218
+
+__C.TEST = AttrDict()
+__C.TEST.RPN_NMS_THRESH = 0.7                       # :257
+__C.TEST.RPN_PRE_NMS_TOP_N = 6000                   # :259
+__C.TEST.RPN_POST_NMS_TOP_N = 300                   # :262
+__C.TEST.RPN_MIN_SIZE = 16                          # :265
+
+__C.RNG_SEED = 3                                    # :290
+__C.EPS = 1e-14                                     # :293
+__C.USE_GPU_NMS = False                             # :321 (kept for API parity; the HIP NMS
+                                                    #  implements the cpu_nms rule either way)
+
+# --- additions of this implementation (not in the reference) -----------------
+# 'reference': anchor / RoI sub-sampling draws from numpy's global legacy RandomState
+#              exactly like the reference (bit-identical labels, one host round trip);
+# 'device'   : counter-based hash sampling on the GPU (no host sync; same distribution).
+__C.SAMPLING_RNG = "reference"
+__C.DEVICE_RNG_SEED = 3
+# RoI-pool bin rounding: 'cuda' (canonical, roi_pooling_op_gpu.cu.cc:51-58) or
+# 'cpu' (roi_pooling_op.cc:167-170)
+__C.ROI_POOL_ROUNDING = "cuda"
+
+
+def cfg_from_list(cfg_list):
+    """Set config keys via list (e.g., from command line), config.py:392-412."""
+    from ast import literal_eval
+    assert len(cfg_list) % 2 == 0
+    for k, v in zip(cfg_list[0::2], cfg_list[1::2]):
+        key_list = k.split(".")
+        d = __C
+        for subkey in key_list[:-1]:
+            assert subkey in d
+            d = d[subkey]
+        subkey = key_list[-1]
+        assert subkey in d
+        try:
+            value = literal_eval(v)
+        except Exception:
+            value = v
+        assert type(value) == type(d[subkey]), "type {} does not match original type {}".format(
+            type(value), type(d[subkey]))
+        d[subkey] = value

@@ -1,0 +1,91 @@
+"""proposal_layer on the GPU.
+
+Reference: code/lib/rpn_msr/proposal_layer_tf_bus.py:19-148.  Same call
+signature; inputs NHWC.  All images of the batch are processed by one
+``wssdl_proposal_layer`` call (decode -> rank/top-K -> NMS mask -> sweep), then one
+small device-to-host copy of the per-image counts sizes the output blob.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+from ..fast_rcnn.config import cfg
+from .generate_anchors import generate_anchors
+
+DEBUG = False
+
+
+def _rpn_params(is_training):
+    key = "TRAIN" if is_training else "TEST"                       # :42
+    c = cfg[key]
+    return c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, c.RPN_MIN_SIZE
+
+
+def proposal_layer_padded(rpn_cls_prob_reshape, rpn_bbox_pred, im_info, is_training,
+                          _feat_stride=[16, ], anchor_scales=[8, 16, 32], debug=False):
+    """Device-resident form: returns (rois_padded [N, post_nms_topN, 5], counts [N] i32)
+    without any host synchronisation (+ decoded / sorted_index / sorted_count when
+    `debug`)."""
+    prob = _lib.to_device(rpn_cls_prob_reshape, torch.float32)
+    pred = _lib.to_device(rpn_bbox_pred, torch.float32, prob.device)
+    info = _lib.to_device(im_info, torch.float32, prob.device)
+    if prob.dim() != 4 or pred.dim() != 4 or info.dim() != 2:
+        raise ValueError("expected rpn_cls_prob_reshape/rpn_bbox_pred [N,H,W,C] and im_info [N,k]")
+    pre, post, thresh, min_size = _rpn_params(bool(is_training))
+    anchors = generate_anchors(scales=np.array(anchor_scales))
+    A = anchors.shape[0]
+    N, H, W = prob.shape[:3]
+    if prob.shape[3] != 2 * A or pred.shape[3] != 4 * A or tuple(pred.shape[:3]) != (N, H, W):
+        raise ValueError("channel counts do not match %d anchors" % A)
+    if info.shape[0] != N:
+        raise ValueError("im_info rows must match the batch size")   # :40 loops im_info.shape[0]
+    M = H * W * A
+    topn = pre if 0 < pre < M else M
+    pitch = post if post > 0 else topn
+    stride = int(np.asarray(_feat_stride).ravel()[0])
+    L = _lib.lib()
+    dev = prob.device
+    with torch.cuda.device(dev):
+        ws = torch.empty((L.wssdl_proposal_workspace_bytes(N, H, W, A, pre),), dtype=torch.uint8,
+                         device=dev)
+        rois = torch.empty((N, pitch, 5), dtype=torch.float32, device=dev)
+        counts = torch.empty((N,), dtype=torch.int32, device=dev)
+        dec = sidx = scnt = None
+        if debug:
+            dec = torch.empty((N, M, 4), dtype=torch.float32, device=dev)
+            sidx = torch.empty((N, topn), dtype=torch.int32, device=dev)
+            scnt = torch.empty((N,), dtype=torch.int32, device=dev)
+        _lib.check(L.wssdl_proposal_layer(
+            _lib.ptr(prob), _lib.ptr(pred), _lib.ptr(info), info.shape[1], N, H, W,
+            _lib.host_ptr(anchors), A, stride, int(pre), int(post), float(thresh),
+            float(min_size), _lib.ptr(rois), _lib.ptr(counts), _lib.ptr(dec), _lib.ptr(sidx),
+            _lib.ptr(scnt), _lib.ptr(ws), ws.numel(), _lib.stream()), "wssdl_proposal_layer")
+    if debug:
+        return rois, counts, dec, sidx, scnt
+    return rois, counts
+
+
+def compact_rois(rois_padded, counts, counts_host=None):
+    """[N, P, 5] + counts -> the reference's contiguous blob [sum counts, 5]."""
+    N, P = rois_padded.shape[:2]
+    if counts_host is None:
+        counts_host = counts.cpu().numpy()
+    total = int(counts_host.sum())
+    out = torch.empty((total, 5), dtype=torch.float32, device=rois_padded.device)
+    with torch.cuda.device(rois_padded.device):
+        _lib.check(_lib.lib().wssdl_proposal_compact(_lib.ptr(rois_padded), _lib.ptr(counts), N, P,
+                                                     _lib.ptr(out), total, _lib.stream()),
+                   "wssdl_proposal_compact")
+    return out
+
+
+def proposal_layer(rpn_cls_prob_reshape, rpn_bbox_pred, im_info, is_training, is_ws,
+                   _feat_stride=[16, ], anchor_scales=[8, 16, 32]):
+    """Same contract as the reference: returns the rois blob [sum R_i, 5] f32 with
+    rows (batch_idx, x1, y1, x2, y2).  `is_ws` is accepted and unused, as in the
+    reference.  numpy in -> numpy out; GPU tensors in -> GPU tensor out."""
+    as_np = _lib.wants_numpy(rpn_cls_prob_reshape, rpn_bbox_pred, im_info)
+    rois, counts = proposal_layer_padded(rpn_cls_prob_reshape, rpn_bbox_pred, im_info,
+                                         is_training, _feat_stride, anchor_scales)
+    blob = compact_rois(rois, counts)
+    return blob.cpu().numpy() if as_np else blob
