@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of a full train step (600x1000 synthetic inputs) with the
+detection hot path on the HIP library, plus the hot path's roofline and a CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one optimiser step of the workload on this rank's images (weak scaling: every
+rank runs the same per-GPU batch; gradients are averaged with one RCCL all-reduce).  W
+untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; the time is
+the max over ranks; rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json `configs`):
+  resnet50_joint_b8   configs[2] -- ResNet-50, combined mini-batch (train.py), 4 supervised +
+                      4 weak images per GPU: R = 4*128 + 4*2000 RoIs through RoI pool (default:
+                      the largest single-GPU 600x1000 train configuration)
+  resnet18_sup_b2     configs[1] -- ResNet-18, batch 2 fully supervised
+  resnet50_alter      configs[3] -- ResNet-50, one alternating iteration (train_alter.py):
+                      a supervised step on 1 image then a weak step on 2 images
+  resnet101_1600_test configs[4] -- ResNet-101, 1000x1600, test-mode RPN (6000 -> 300), forward only
+  vgg16_joint         VGG-16 combined mini-batch 1 + 2 (the reference's default sizes)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured achievable
+
+WORKLOADS = {
+    "resnet50_joint_b8": dict(net="Resnet_train", depth=50, mode="joint", n_sup=4, n_ws=4,
+                              im=(600, 1000), baseline_config=2),
+    "resnet18_sup_b2": dict(net="Resnet_train_alter", depth=18, mode="sup", n_sup=2, n_ws=0,
+                            im=(600, 1000), baseline_config=1),
+    "resnet50_alter": dict(net="Resnet_train_alter", depth=50, mode="alter", n_sup=1, n_ws=2,
+                           im=(600, 1000), baseline_config=3),
+    "resnet101_1600_test": dict(net="Resnet_train", depth=101, mode="test", n_sup=1, n_ws=0,
+                                im=(1000, 1600), baseline_config=4),
+    "vgg16_joint": dict(net="VGGnet_train", depth=16, mode="joint", n_sup=1, n_ws=2,
+                        im=(600, 1000), baseline_config=0),
+}
+
+
+def alg_bytes(name, m):
+    """Algorithmic bytes of one launch (restated in DESIGN.md)."""
+    if name == "roi_pool_forward":
+        return m["N"] * m["H"] * m["W"] * m["C"] * 4 + m["R"] * 20 + m["R"] * 49 * m["C"] * 8
+    if name == "roi_pool_backward":
+        return m["R"] * 49 * m["C"] * 8 + m["N"] * m["H"] * m["W"] * m["C"] * 4
+    if name == "anchor_target_layer":
+        return m["n_out"] * 13 * 9 * m["H"] * m["W"] * 4
+    if name == "proposal_layer":
+        ka = m["H"] * m["W"] * m["A"]
+        nms = m["pre"] * 20 + m["pre"] * ((m["pre"] + 63) // 64) * 8
+        return m["N"] * (ka * 6 * 4 + ka * 5 * 4 + 2 * ka * 8 + nms)
+    return 0
+
+
+def cpu_baseline(wl, seed=3):
+    """The oracle (a port of the reference's CPU path; its NMS/IoU inner kernels are the
+    reference's own Cython when oracle/_ref is present) timed on this host for ONE supervised
+    and ONE weak image of the workload, extrapolated to the per-GPU batch."""
+    import numpy as np
+    from oracle import c_oracle, np_oracle as O, ref_kernels
+    H = -(-wl["im"][0] // 16)
+    W = -(-wl["im"][1] // 16)
+    C = {18: 256, 16: 512}.get(wl["depth"], 1024)
+    train = wl["mode"] != "test"
+    rs = np.random.RandomState(seed)
+    logits = rs.normal(size=(1, H, W, 9, 2)).astype(np.float32)
+    e = np.exp(logits - logits.max(-1, keepdims=True))
+    p = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    prob = np.concatenate((p[..., 0], p[..., 1]), axis=-1)
+    pred = rs.normal(0, 0.2, size=(1, H, W, 36)).astype(np.float32)
+    info = np.array([[wl["im"][0], wl["im"][1], 1.0, 1]], np.float32)
+    gt = np.zeros((1, 20, 5), np.float32)
+    gt[0, 0] = [100, 80, 380, 300, 1]
+    gt[0, 1] = [500, 60, 900, 420, 0]
+    ng = np.array([2], np.int32)
+    feat = np.maximum(rs.normal(size=(1, H, W, C)), 0).astype(np.float32)
+    use_ref = ref_kernels.available()
+    if use_ref:                       # the reference's own Cython kernels (PyObject-compare NMS)
+        O_nms, O_iou, O_ui = O.nms, O.bbox_overlaps, O.bbox_overlaps_ui
+        O.nms = lambda d, t: [] if d.shape[0] == 0 else ref_kernels.cpu_nms(d, t)
+        O.bbox_overlaps = lambda b, q: ref_kernels.bbox_overlaps(
+            np.ascontiguousarray(b[:, :4], dtype=np.float64), np.ascontiguousarray(q[:, :4], dtype=np.float64))
+        O.bbox_overlaps_ui = lambda b, q: ref_kernels.bbox_overlaps_ui(
+            np.ascontiguousarray(b[:, :4], dtype=np.float64), np.ascontiguousarray(q[:, :4], dtype=np.float64))
+    cores = os.cpu_count() or 1
+    try:
+        def one_image(weak):
+            t0 = time.perf_counter()
+            if train and not weak:
+                O.anchor_target_layer(np.zeros((1, H, W, 18), np.float32), gt, ng, info, None, [16], [8, 16, 32],
+                                      "SNUBH", rng=np.random.RandomState(seed))
+            rois = O.proposal_layer(prob, pred, info, train, False, [16], [8, 16, 32])
+            if train and not weak:
+                rois = O.proposal_target_layer(rois, gt, ng, 3, True, False, rng=np.random.RandomState(seed))[0]
+            t1 = time.perf_counter()
+            top, arg = c_oracle.roi_pool_forward(feat, rois, 7, 7, 1.0 / 16, "cuda", threads=cores)
+            if train:
+                c_oracle.roi_pool_backward(top, arg, rois, feat.shape, 7, 7, 1.0 / 16)
+            t2 = time.perf_counter()
+            return t1 - t0, t2 - t1, rois.shape[0]
+        sup = one_image(False)
+        weak = one_image(True) if wl["n_ws"] else (0.0, 0.0, 0)
+    finally:
+        if use_ref:
+            O.nms, O.bbox_overlaps, O.bbox_overlaps_ui = O_nms, O_iou, O_ui
+    n_img = wl["n_sup"] + wl["n_ws"]
+    t_step = wl["n_sup"] * (sup[0] + sup[1]) + wl["n_ws"] * (weak[0] + weak[1])
+    return dict(
+        value=n_img / t_step, unit="images/s (hot path only: anchor targets + proposal layer + "
+                                   "proposal targets + RoI pool fwd/bwd; no backbone)",
+        cores=cores, kind="port",
+        sample="1 supervised image (%d RoIs: layers %.2fs, RoI pool %.2fs) + 1 weak image (%d RoIs: "
+               "layers %.2fs, RoI pool %.2fs) of this workload, extrapolated to %d+%d images; layers "
+               "single-threaded like the reference (GIL), RoI pool on %d threads like its Shard(); "
+               "NMS/IoU inner kernels = %s"
+               % (sup[2], sup[0], sup[1], weak[2], weak[0], weak[1], wl["n_sup"], wl["n_ws"], cores,
+                  "the reference's own Cython (oracle/_ref)" if use_ref else "C port (oracle/_ref absent)"),
+        cpu_hot_path_ms_per_step=t_step * 1e3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="resnet50_joint_b8", choices=sorted(WORKLOADS))
+    ap.add_argument("--sampling-rng", default="device", choices=["device", "reference"],
+                    help="anchor sub-sampling RNG: 'device' (no host round trip) or the reference's numpy stream")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from wssdl_bus_amd import _lib, synthetic
+    from wssdl_bus_amd.distributed import DistContext
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.fast_rcnn.train_bus import SolverWrapper
+    from wssdl_bus_amd.networks.factory_bus import get_network
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
+    _lib.lib()
+    ctx = DistContext()
+    if ctx.world_size != args.gpus:
+        if ctx.world_size == 1 and args.gpus > 1:
+            sys.exit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(ctx.local_rank)
+    wl = WORKLOADS[args.workload]
+    cfg.TRAIN.IMS_PER_BATCH = wl["n_sup"]
+    cfg.TRAIN.WS_IMS_PER_BATCH = wl["n_ws"]
+    cfg.SAMPLING_RNG = args.sampling_rng
+    seed = ctx.seed(cfg.RNG_SEED)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+    net = get_network(wl["net"], wl["depth"]).cuda().to(memory_format=torch.channels_last)
+    # identical initial weights on every rank (rank 0's), as a data-parallel job needs
+    if ctx.enabled:
+        for p in net.state_dict().values():
+            torch.distributed.broadcast(p, 0)
+    solver = SolverWrapper(net, dist_ctx=ctx)
+    im_h, im_w = wl["im"]
+    mode = wl["mode"]
+    if mode == "alter":
+        blobs_s = synthetic.make_batch(wl["n_sup"], 0, im_h, im_w, seed)
+        blobs_ws = synthetic.make_batch(0, wl["n_ws"], im_h, im_w, seed + 1000)
+    else:
+        blobs = synthetic.make_batch(wl["n_sup"], wl["n_ws"], im_h, im_w, seed)
+    images_per_step = wl["n_sup"] + wl["n_ws"]
+
+    def step():
+        if mode == "joint":
+            return solver.train_step_joint(blobs)
+        if mode == "alter":
+            return solver.train_step_alter(blobs_s, blobs_ws)
+        if mode == "sup":
+            layers = net(blobs["data"], blobs["im_info"], blobs["gt_boxes"], blobs["num_gt_boxes"],
+                         is_training=True, is_ws=False)
+            from wssdl_bus_amd.fast_rcnn.train_bus import supervised_loss
+            losses = supervised_loss(layers, net.weight_decay_params())
+            losses["loss"].backward()
+            solver._apply()
+            return losses
+        with torch.no_grad():                    # test: im_detect-style forward (test_bus.py:146-205)
+            net.eval()
+            return net(blobs["data"], blobs["im_info"], blobs["gt_boxes"], blobs["num_gt_boxes"],
+                       is_training=False, is_ws=False, test_net=True)
+
+    net.train()
+    for _ in range(args.warmup):
+        step()
+    _lib.timeline.reset(True)
+    ctx.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    ctx.barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.timeline.enabled = False
+    elapsed = ctx.max_over_ranks(elapsed)
+    loss_val = float(out["loss"]) if isinstance(out, dict) and "loss" in out and torch.is_tensor(out["loss"]) else None
+
+    if ctx.rank == 0:
+        tl = _lib.timeline.summary()
+        hot_ms = sum(d["total_ms"] for d in tl.values()) / max(args.steps, 1)
+        # dominant kernel = the hot-path launch with the largest total time in the timed region
+        dom = max((k for k in tl if alg_bytes(k, tl[k]["metas"][0]) > 0), key=lambda k: tl[k]["total_ms"],
+                  default=None)
+        roofline = None
+        if dom:
+            d = tl[dom]
+            byt = sum(alg_bytes(dom, m) for m in d["metas"]) / d["calls"]
+            ach = byt / (d["avg_ms"] * 1e-3) / 1e9
+            roofline = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                            frac=round(ach / HBM_PEAK_GBPS, 4), traffic=None,
+                            avg_launch_ms=round(d["avg_ms"], 4), alg_bytes_per_launch=int(byt),
+                            launches=d["calls"],
+                            per_kernel={k: dict(avg_ms=round(v["avg_ms"], 4), calls=v["calls"],
+                                                GBps=round(sum(alg_bytes(k, m) for m in v["metas"]) / v["calls"]
+                                                           / (v["avg_ms"] * 1e-3) / 1e9, 1))
+                                        for k, v in tl.items()})
+        result = {
+            "metric": "images/sec (train step, 600x1000)" if mode != "test" else "images/sec (test forward, 1000x1600)",
+            "value": round(images_per_step * ctx.world_size * args.steps / elapsed, 3),
+            "unit": "images/s",
+            "n_gpus": ctx.world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "baseline_config_index": wl["baseline_config"],
+                       "backbone": "%s-%d" % ("ResNet" if wl["net"].startswith("Resnet") else "VGG", wl["depth"]),
+                       "image": "%dx%d" % (im_h, im_w), "images_per_gpu": images_per_step,
+                       "supervised_per_gpu": wl["n_sup"], "weak_per_gpu": wl["n_ws"], "mode": mode,
+                       "parallelism": "image-parallel dp%d, RCCL grad all-reduce" % ctx.world_size,
+                       "sampling_rng": args.sampling_rng},
+            "roofline": roofline,
+            "hot_path": {"gpu_ms_per_step": round(hot_ms, 3),
+                         "gpu_images_per_s": round(images_per_step / (hot_ms * 1e-3), 1) if hot_ms > 0 else None},
+            "final_loss": loss_val,
+        }
+        if ctx.world_size == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(wl)
+            result["cpu_baseline"] = cb
+            if hot_ms > 0:
+                result["hot_path"]["speedup_vs_cpu_baseline"] = round(cb["cpu_hot_path_ms_per_step"] / hot_ms, 1)
+        print(json.dumps(result))
+    ctx.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -131,3 +131,52 @@ def generate_anchors_host(base_size, ratios, scales):
     if n < 0:
         check(-n, "wssdl_generate_anchors_host")
     return out
+
+
+# --------------------------------------------------------------------------
+# Optional HIP-event instrumentation of the C-ABI calls (used by bench.py's
+# `roofline` leg).  Events are recorded on the stream the kernels are launched
+# on (torch's current stream), so they bracket exactly the enqueued kernels.
+class _Timeline(object):
+    def __init__(self):
+        self.enabled = False
+        self.records = []           # (name, start_event, end_event, meta)
+
+    def reset(self, enabled):
+        self.enabled = enabled
+        self.records = []
+
+    def summary(self):
+        """name -> dict(calls, total_ms, avg_ms, metas).  Call after a synchronize."""
+        out = {}
+        for name, s, e, meta in self.records:
+            d = out.setdefault(name, dict(calls=0, total_ms=0.0, metas=[]))
+            d["calls"] += 1
+            d["total_ms"] += s.elapsed_time(e)
+            d["metas"].append(meta)
+        for d in out.values():
+            d["avg_ms"] = d["total_ms"] / max(d["calls"], 1)
+        return out
+
+
+timeline = _Timeline()
+
+
+class timed(object):
+    """with timed('roi_pool_forward', meta): <enqueue kernels>"""
+
+    def __init__(self, name, meta=None):
+        self.name, self.meta = name, meta
+
+    def __enter__(self):
+        if timeline.enabled:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if timeline.enabled:
+            self.e.record()
+            timeline.records.append((self.name, self.s, self.e, self.meta))
+        return False

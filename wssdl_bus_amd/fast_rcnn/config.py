@@ -24,6 +24,7 @@ __C = AttrDict()
 cfg = __C
 
 __C.TRAIN = AttrDict()
+__C.TRAIN.LEARNING_RATE = 0.0005                    # config.py:40
 __C.TRAIN.WEIGHT_DECAY = 0.0005                     # config.py:46
 __C.TRAIN.WS_IMS_PER_BATCH = 2                      # :49
 __C.TRAIN.WS_LOSS_USE_ADAPTIVE_SCALE_FACTOR = True  # :51

@@ -1,0 +1,150 @@
+"""Multi-task loss and train steps (combined and alternating) on PyTorch-ROCm.
+
+Reference: code/lib/fast_rcnn/train_bus.py:184-270 (alternating losses), :603-678 (combined
+losses), :286-301 / :694-705 (optimisers and the per-variable sum of the two gradient sets),
+:334-394 (one alternating iteration = a supervised step then a weak step).  Only what drives
+the hot path's backward is restated here; data loading, LR
+schedules, snapshots and logging are out of scope.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ..mil import core as mil_core
+from .config import cfg
+
+
+# ----------------------------------------------------------------- losses ---
+
+def rpn_cls_loss(rpn_cls_score_reshape, rpn_labels):
+    """train_bus.py:186-192 / :605-610: CE over anchors whose label != -1.
+    rpn_cls_score_reshape [N, A*H, W, 2]; rpn_labels [N, 1, A*H, W] int."""
+    score = rpn_cls_score_reshape.reshape(-1, 2)
+    label = rpn_labels.reshape(-1).to(torch.int64)
+    keep = label != -1
+    return F.cross_entropy(score[keep], label[keep])
+
+
+def rpn_box_loss(rpn_bbox_pred, rpn_data, n_images=None):
+    """train_bus.py:203-210 / :613-620.  The 'smooth L1' switches at |d| < 1 while using the
+    sigma = 3 pieces (0.5*(3*in_w*d)^2 and |d| - 0.5/9): the reference's formula, kept as is.
+    rpn_bbox_pred [N,H,W,4A]; rpn_data = (labels, targets, inside_w, outside_w) [N,4A,H,W]."""
+    tg, inw, outw = (t.permute(0, 2, 3, 1) for t in rpn_data[1:4])
+    pred = rpn_bbox_pred
+    if n_images is not None:                       # combined mode slices the supervised images
+        pred, tg, inw, outw = pred[:n_images], tg[:n_images], inw[:n_images], outw[:n_images]
+    d = pred - tg
+    sign = (d.abs() < 1).to(pred.dtype)
+    per = outw * (0.5 * (inw * d * 3) ** 2 * sign + (d.abs() - 0.5 / 9.0) * (sign - 1).abs())
+    return per.sum(dim=(1, 2)).mean() * 10
+
+
+def rcnn_cls_loss(cls_score, labels):
+    """train_bus.py:218 / :623-630: CE over the first len(labels) rows."""
+    label = labels.reshape(-1).to(torch.int64)
+    return F.cross_entropy(cls_score[:label.numel()], label)
+
+
+def rcnn_box_loss(bbox_pred, roi_data):
+    """train_bus.py:231-235 / :641-647: plain L1, mean over rows of the weighted row sums."""
+    tg, inw, outw = roi_data[2], roi_data[3], roi_data[4]
+    pred = bbox_pred[:tg.shape[0]]
+    return (outw * (inw * (pred - tg).abs())).sum(dim=1).mean()
+
+
+def mil_loss(cls_score_ws, batch_inds, mil_label, n_bags, global_step, funcs, counts_host=None):
+    """train_bus.py:239-260 / :650-671: bag logits -> CE weighted by the class prior
+    [0, WS_MAL_PCT, 1-WS_MAL_PCT] and by 1 - 0.99*0.9^floor(step/2000) (or a constant)."""
+    bag_logits, _ = mil_core.get_bag_logit(cls_score_ws, batch_inds, 3, mil_label, n_bags, funcs,
+                                           counts_host)
+    label = mil_label.reshape(-1).to(torch.int64)
+    w = torch.tensor([0.0, cfg.TRAIN.WS_MAL_PCT, 1 - cfg.TRAIN.WS_MAL_PCT],
+                     dtype=bag_logits.dtype, device=bag_logits.device)[label]
+    ce = F.cross_entropy(bag_logits, label, reduction='none')
+    if cfg.TRAIN.WS_LOSS_USE_ADAPTIVE_SCALE_FACTOR:
+        scale = 1.0 - 0.99 * (0.9 ** (int(global_step) // 2000))      # exponential_decay, staircase
+    else:
+        scale = cfg.TRAIN.WS_LOSS_SCALE_FACTOR
+    return (scale * (w * ce)).mean()
+
+
+def l2_weight_decay(params):
+    """train_bus.py:268-270: sum(l2_loss(w)) * WEIGHT_DECAY over '*weights' variables."""
+    if not params:
+        return 0.0
+    return torch.stack([(p * p).sum() for p in params]).sum() * (0.5 * cfg.TRAIN.WEIGHT_DECAY)
+
+
+def supervised_loss(layers, params, n_sup=None):
+    l = dict(
+        rpn_cross_entropy=rpn_cls_loss(layers['rpn_cls_score_reshape'], layers['rpn-data'][0]),
+        rpn_loss_box=rpn_box_loss(layers['rpn_bbox_pred'], layers['rpn-data'], n_sup),
+        cross_entropy=rcnn_cls_loss(layers['cls_score'], layers['roi-data'][1]),
+        loss_box=rcnn_box_loss(layers['bbox_pred'], layers['roi-data']),
+    )
+    l['weight_decay'] = l2_weight_decay(params)
+    l['loss'] = (l['cross_entropy'] + l['loss_box'] + l['rpn_cross_entropy'] + l['rpn_loss_box']
+                 + l['weight_decay'])
+    return l
+
+
+# ------------------------------------------------------------ train steps ---
+
+class SolverWrapper(object):
+    """The part of the reference's SolverWrapper (train_bus.py:97-131) that a step needs:
+    the network, Adam(eps=0.1) (:286-289,:694-695), the global step, and -- new in this
+    implementation -- gradient averaging across data-parallel ranks."""
+
+    def __init__(self, network, lr=None, dist_ctx=None):
+        self.net = network
+        self.lr = cfg.TRAIN.get('LEARNING_RATE', 0.0005) if lr is None else lr
+        self.params = [p for p in network.parameters() if p.requires_grad]
+        self.optimizer = torch.optim.Adam(self.params, lr=self.lr, eps=0.1)
+        self.global_step = 0
+        self.dist = dist_ctx
+
+    def _apply(self):
+        if self.dist is not None:
+            self.dist.allreduce_gradients(self.params)
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=True)
+        self.global_step += 1
+
+    def train_step_joint(self, blobs):
+        """One combined mini-batch (train_bus.py:732-764): supervised images first, weak images
+        after; the supervised and MIL gradients are summed per variable (:701-705), which is
+        the gradient of (loss + mil_cross_entropy)."""
+        n_s = int(cfg.TRAIN.IMS_PER_BATCH)
+        n_ws = int(cfg.TRAIN.WS_IMS_PER_BATCH)
+        layers = self.net(blobs['data'], blobs['im_info'], blobs['gt_boxes'], blobs['num_gt_boxes'],
+                          is_training=True, is_ws=False)
+        losses = supervised_loss(layers, self.net.weight_decay_params(), n_s)
+        n_valid = layers['roi-data'][1].numel()                       # len(label), :624-628
+        cls_ws = layers['cls_score'][n_valid:]
+        batch_inds = layers['roi-data'][0][n_valid:, 0] - n_s         # :653
+        mil_label = blobs['im_info'][n_s:, 3].to(torch.int32)         # image-level labels, :654
+        funcs = [mil_core.get_mal_max_logit, mil_core.get_mal_max_logit]     # :655
+        losses['mil_cross_entropy'] = mil_loss(cls_ws, batch_inds, mil_label, n_ws,
+                                               self.global_step, funcs)
+        (losses['loss'] + losses['mil_cross_entropy']).backward()
+        self._apply()
+        return losses
+
+    def train_step_alter(self, blobs_s, blobs_ws):
+        """One alternating iteration (train_bus.py:334-394): a supervised step on `loss`, then
+        a weak step on the MIL loss alone with is_ws=True."""
+        layers = self.net(blobs_s['data'], blobs_s['im_info'], blobs_s['gt_boxes'],
+                          blobs_s['num_gt_boxes'], is_training=True, is_ws=False)
+        losses = supervised_loss(layers, self.net.weight_decay_params())
+        losses['loss'].backward()
+        self._apply()
+        layers = self.net(blobs_ws['data'], blobs_ws['im_info'], blobs_ws['gt_boxes'],
+                          blobs_ws['num_gt_boxes'], is_training=True, is_ws=True)
+        batch_inds = layers['roi-data'][0][:, 0]                      # :239
+        mil_label = blobs_ws['im_info'][:, 3].to(torch.int32)         # :240
+        funcs = [mil_core.get_mass_max_logit, mil_core.get_mal_max_logit]    # :241
+        losses['mil_cross_entropy'] = mil_loss(layers['cls_score'], batch_inds, mil_label,
+                                               blobs_ws['data'].shape[0], self.global_step, funcs)
+        losses['mil_cross_entropy'].backward()
+        self._apply()
+        return losses

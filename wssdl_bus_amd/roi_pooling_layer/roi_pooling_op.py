@@ -39,7 +39,7 @@ def roi_pool(bottom_data, bottom_rois, pooled_height, pooled_width, spatial_scal
     mode = _ROUNDING[cfg.ROI_POOL_ROUNDING if rounding is None else rounding]
     top = torch.empty((R, pooled_height, pooled_width, C), dtype=torch.float32, device=data.device)
     arg = torch.empty((R, pooled_height, pooled_width, C), dtype=torch.int32, device=data.device)
-    with torch.cuda.device(data.device):
+    with torch.cuda.device(data.device), _lib.timed("roi_pool_forward", dict(N=N, H=H, W=W, C=C, R=R)):
         _lib.check(_lib.lib().wssdl_roi_pool_forward(
             _lib.ptr(data), N, H, W, C, _lib.ptr(rois), R, int(pooled_height), int(pooled_width),
             float(spatial_scale), mode, _lib.ptr(top), _lib.ptr(arg), _lib.stream()),
@@ -67,7 +67,7 @@ def roi_pool_grad(bottom_data, bottom_rois, argmax, grad, pooled_height, pooled_
         raise ValueError("out_backprop must be 4-dimensional")
     N, H, W, C = shape
     out = torch.empty(shape, dtype=torch.float32, device=g.device)
-    with torch.cuda.device(g.device):
+    with torch.cuda.device(g.device), _lib.timed("roi_pool_backward", dict(N=N, H=H, W=W, C=C, R=rois.shape[0])):
         _lib.check(_lib.lib().wssdl_roi_pool_backward(
             _lib.ptr(g), _lib.ptr(arg), _lib.ptr(rois), rois.shape[0], N, H, W, C,
             int(pooled_height), int(pooled_width), float(spatial_scale), _lib.ptr(out),

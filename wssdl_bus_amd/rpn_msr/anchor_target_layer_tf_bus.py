@@ -117,6 +117,16 @@ def _run(rpn_cls_score, gt_boxes, num_gt_boxes, im_info, n_images, n_out, _feat_
     as_np = _lib.wants_numpy(gt_boxes, im_info, rpn_cls_score if hasattr(rpn_cls_score, "dtype") else None)
     _, height, width = _shape_hw(rpn_cls_score)
     dev = _device_of(rpn_cls_score, gt_boxes, im_info)
+    with _lib.timed("anchor_target_layer", dict(n_images=n_images, n_out=n_out, H=height, W=width)):
+        outs = _run_device(gt_boxes, num_gt_boxes, im_info, n_images, n_out, height, width,
+                           _feat_stride, anchor_scales, dataset, rng, dev)
+    if as_np:
+        return tuple(o.cpu().numpy() for o in outs)
+    return outs
+
+
+def _run_device(gt_boxes, num_gt_boxes, im_info, n_images, n_out, height, width, _feat_stride,
+                anchor_scales, dataset, rng, dev):
     if n_images > 0:
         labels, argmax, counts, gt, anchors = anchor_labels(
             gt_boxes, num_gt_boxes, im_info, n_images, height, width, _feat_stride, anchor_scales,
@@ -133,11 +143,8 @@ def _run(rpn_cls_score, gt_boxes, num_gt_boxes, im_info, n_images, n_out, _feat_
     else:
         labels = argmax = gt = None
         anchors = generate_anchors(scales=np.array(anchor_scales))
-    outs = anchor_targets(labels, argmax, gt, anchors, n_images, n_out, height, width,
+    return anchor_targets(labels, argmax, gt, anchors, n_images, n_out, height, width,
                           _feat_stride, dev)
-    if as_np:
-        return tuple(o.cpu().numpy() for o in outs)
-    return outs
 
 
 def anchor_target_layer(rpn_cls_score, gt_boxes, num_gt_boxes, im_info, data,

@@ -55,7 +55,8 @@ def proposal_layer_padded(rpn_cls_prob_reshape, rpn_bbox_pred, im_info, is_train
             dec = torch.empty((N, M, 4), dtype=torch.float32, device=dev)
             sidx = torch.empty((N, topn), dtype=torch.int32, device=dev)
             scnt = torch.empty((N,), dtype=torch.int32, device=dev)
-        _lib.check(L.wssdl_proposal_layer(
+        with _lib.timed("proposal_layer", dict(N=N, H=H, W=W, A=A, pre=topn, post=pitch)):
+          _lib.check(L.wssdl_proposal_layer(
             _lib.ptr(prob), _lib.ptr(pred), _lib.ptr(info), info.shape[1], N, H, W,
             _lib.host_ptr(anchors), A, stride, int(pre), int(post), float(thresh),
             float(min_size), _lib.ptr(rois), _lib.ptr(counts), _lib.ptr(dec), _lib.ptr(sidx),

@@ -39,6 +39,11 @@ def _empty_outputs(dev, num_classes):
 
 def _supervised(rois, gt_dev, gt_host, ng_host, images, append_gt, num_classes, rng):
     """Sampled rows for the supervised `images` (in that order), all on the GPU."""
+    with _lib.timed("proposal_target_layer", dict(R=int(rois.shape[0]), images=len(images))):
+        return _supervised_impl(rois, gt_dev, gt_host, ng_host, images, append_gt, num_classes, rng)
+
+
+def _supervised_impl(rois, gt_dev, gt_host, ng_host, images, append_gt, num_classes, rng):
     dev = rois.device
     n_img = gt_dev.shape[0]
     num_pos = _num_pos(gt_host, ng_host, n_img)
