@@ -210,7 +210,7 @@ def main():
     elapsed = time.perf_counter() - t0
     _lib.timeline.enabled = False
     elapsed = ctx.max_over_ranks(elapsed)
-    loss_val = float(out["loss"]) if isinstance(out, dict) and "loss" in out and torch.is_tensor(out["loss"]) else None
+    loss_val = float(out["loss"].detach()) if isinstance(out, dict) and torch.is_tensor(out.get("loss")) else None
 
     if ctx.rank == 0:
         tl = _lib.timeline.summary()

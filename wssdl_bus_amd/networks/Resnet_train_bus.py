@@ -8,7 +8,8 @@ hot-path nodes are the ``Network`` layer methods backed by the HIP library.
 import torch
 import torch.nn as nn
 
-from .backbones import RESNET_DEFS, Conv, ResNetHead, ResNetTrunk
+from .backbones import RESNET_DEFS, Conv, ResNetTrunk
+from .roi_head import ConvNHWC, ResNetHeadNHWC
 from .network import Network
 
 n_classes = 3
@@ -35,7 +36,7 @@ class Resnet_train_bus(nn.Module, Network):
         self.rpn_conv = Conv(c, 256 * block.expansion, 3, 1, norm_type)          # 'rpn_conv/3x3'
         self.rpn_cls_score = Conv(256 * block.expansion, A * 2, 1, 1, None, relu=False, padding='VALID')
         self.rpn_bbox_pred = Conv(256 * block.expansion, A * 4, 1, 1, None, relu=False, padding='VALID')
-        self.head = ResNetHead(net_depth, norm_type)
+        self.head = ResNetHeadNHWC(net_depth, norm_type)
         self.cls_score = _fc(self.head.out_features, n_classes, 0.01)
         self.bbox_pred = _fc(self.head.out_features, n_classes * 4, 0.001)
 
@@ -78,8 +79,7 @@ class Resnet_train_bus(nn.Module, Network):
                  .proposal_target_layer_joint(n_classes, is_training, name='roi-data'))
         (self.feed('group2/relu', 'roi-data')
              .roi_pool(7, 7, 1.0 / 16, name='roi_pool'))
-        pooled = self.layers['roi_pool'].permute(0, 3, 1, 2)          # [R,C,7,7] channels_last
-        gap = self.head(pooled)
+        gap = self.head(self.layers['roi_pool'])                      # [R,7,7,C] NHWC, GEMM head
         self.layers['gap'] = gap
         self.layers['cls_score'] = self.cls_score(gap)
         self.layers['cls_prob'] = torch.softmax(self.layers['cls_score'], dim=-1)
@@ -88,5 +88,5 @@ class Resnet_train_bus(nn.Module, Network):
 
     def weight_decay_params(self):
         """Variables named '*weights' in the reference (conv / fc kernels), train_bus.py:268-270."""
-        return [m.weight for m in self.modules() if isinstance(m, (nn.Conv2d, nn.Linear))
+        return [m.weight for m in self.modules() if isinstance(m, (nn.Conv2d, nn.Linear, ConvNHWC))
                 and m.weight.requires_grad]

@@ -1,0 +1,125 @@
+"""Per-RoI ResNet head (group3 ... gap) as NHWC GEMMs.
+
+Reference wiring: code/lib/networks/Resnet_train_bus.py:91-97 (group3 -> norm -> relu -> gap),
+blocks network.py:457-491.  The number of RoIs changes from step to step (NMS keeps a
+data-dependent count), and MIOpen re-tunes / re-compiles convolution kernels for every new
+batch dimension (tens of seconds per new R on this stack), so the head does not use
+convolution kernels at all: RoI-pool output is already [R,7,7,C] NHWC, 1x1 convs are
+F.linear on [R*h*w, C] rows, 3x3 convs gather their TF-'SAME' patches and run one GEMM, and
+normalisation is batch-norm over rows.  GEMMs (rocBLAS/hipBLASLt) are shape-agnostic.
+Plumbing, not the product: stock PyTorch ops only.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .backbones import RESNET_DEFS, _same_pad
+
+
+class ConvNHWC(nn.Module):
+    """conv (TF 'SAME') + optional BN + optional ReLU on NHWC tensors via one GEMM.
+    weight [c_o, k*k*c_i] with the patch laid out (kh, kw, c_i)."""
+
+    def __init__(self, c_i, c_o, k, s, norm=None, relu=True):
+        super().__init__()
+        self.c_i, self.c_o, self.k, self.s, self.relu = c_i, c_o, k, s, relu
+        self.weight = nn.Parameter(torch.empty(c_o, k * k * c_i))
+        nn.init.trunc_normal_(self.weight, std=0.01, a=-0.02, b=0.02)
+        self.bias = nn.Parameter(torch.zeros(c_o)) if norm is None else None
+        self.bn = nn.BatchNorm1d(c_o, eps=1e-3, momentum=0.01) if norm == "BN" else None
+
+    def forward(self, x):
+        r, h, w, c = x.shape
+        k, s = self.k, self.s
+        if k == 1:
+            if s > 1:
+                x = x[:, ::s, ::s, :]
+            oh, ow = x.shape[1], x.shape[2]
+            rows = x.reshape(-1, c)
+        else:
+            pt, pb = _same_pad(h, k, s)
+            pl, pr = _same_pad(w, k, s)
+            xp = F.pad(x, (0, 0, pl, pr, pt, pb))
+            p = xp.unfold(1, k, s).unfold(2, k, s)            # [R, oh, ow, C, kh, kw]
+            oh, ow = p.shape[1], p.shape[2]
+            rows = p.permute(0, 1, 2, 4, 5, 3).reshape(-1, k * k * c)
+        y = F.linear(rows, self.weight, self.bias)
+        if self.bn is not None:
+            y = self.bn(y)
+        if self.relu:
+            y = F.relu(y)
+        return y.view(r, oh, ow, self.c_o)
+
+
+def _bn_rows(bn, x):
+    r, h, w, c = x.shape
+    return bn(x.reshape(-1, c)).view(r, h, w, c)
+
+
+class BottleneckNHWC(nn.Module):
+    expansion = 4
+
+    def __init__(self, c_i, c_o, s, preact, norm):
+        super().__init__()
+        self.preact = preact
+        self.pre_bn = nn.BatchNorm1d(c_i, eps=1e-3, momentum=0.01) \
+            if (preact != "no_preact" and norm == "BN") else None
+        self.conv1 = ConvNHWC(c_i, c_o, 1, 1, norm)
+        self.conv2 = ConvNHWC(c_o, c_o, 3, s, norm)
+        self.conv3 = ConvNHWC(c_o, c_o * 4, 1, 1, norm, relu=False)
+        self.short = ConvNHWC(c_i, c_o * 4, 1, s, norm, relu=False) if c_i != c_o * 4 else None
+
+    def forward(self, x):
+        ori = x
+        if self.preact != "no_preact":
+            y = F.relu(_bn_rows(self.pre_bn, x) if self.pre_bn is not None else x)
+            if self.preact == "both_preact":
+                ori = y
+            x = y
+        x = self.conv3(self.conv2(self.conv1(x)))
+        return x + (self.short(ori) if self.short is not None else ori)
+
+
+class BasicBlockNHWC(nn.Module):
+    expansion = 1
+
+    def __init__(self, c_i, c_o, s, preact, norm):
+        super().__init__()
+        self.preact = preact
+        self.pre_bn = nn.BatchNorm1d(c_i, eps=1e-3, momentum=0.01) \
+            if (preact != "no_preact" and norm == "BN") else None
+        self.conv1 = ConvNHWC(c_i, c_o, 3, s, norm)
+        self.conv2 = ConvNHWC(c_o, c_o, 3, 1, norm, relu=False)
+        self.short = ConvNHWC(c_i, c_o, 1, s, norm, relu=False) if c_i != c_o else None
+
+    def forward(self, x):
+        ori = x
+        if self.preact != "no_preact":
+            y = F.relu(_bn_rows(self.pre_bn, x) if self.pre_bn is not None else x)
+            if self.preact == "both_preact":
+                ori = y
+            x = y
+        x = self.conv2(self.conv1(x))
+        return x + (self.short(ori) if self.short is not None else ori)
+
+
+class ResNetHeadNHWC(nn.Module):
+    """[R,7,7,C] NHWC -> [R, 512*expansion]."""
+
+    def __init__(self, depth, norm="BN"):
+        super().__init__()
+        defs, block = RESNET_DEFS[depth]
+        blk = BottleneckNHWC if block.expansion == 4 else BasicBlockNHWC
+        e = blk.expansion
+        blocks = [blk(256 * e, 512, 2, "both_preact", norm)]
+        for _ in range(1, defs[3]):
+            blocks.append(blk(512 * e, 512, 1, "default", norm))
+        self.group3 = nn.Sequential(*blocks)
+        self.norm = nn.BatchNorm1d(512 * e, eps=1e-3, momentum=0.01) if norm == "BN" else None
+        self.out_features = 512 * e
+
+    def forward(self, x):
+        x = self.group3(x)
+        if self.norm is not None:
+            x = _bn_rows(self.norm, x)
+        return F.relu(x).mean(dim=(1, 2))
