@@ -150,47 +150,62 @@ __global__ __launch_bounds__(AT_BLOCK) void anchor_label_kernel(
         gmax[threadIdx.x] =
             __longlong_as_double((long long)gt_max[(size_t)img * WSSDL_MAX_GT + threadIdx.x]);
     __syncthreads();
+    __shared__ int blk_cnt[3];
+    if (threadIdx.x < 3) blk_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const int total = H * W * A;
     const int i = blockIdx.x * AT_BLOCK + threadIdx.x;
-    if (i >= total) return;
-    const int cell = i / A, a = i - cell * A;
-    const int h = cell / W, w = cell - h * W;
-    const AnchorBox b = make_anchor(base, a, h, w, stride, im_info[img * info_stride + 0],
-                                    im_info[img * info_stride + 1]);
     int label = -1, arg = -1;
-    if (b.inside) {
-        double best = 0.0;
-        bool hit = false;
-        arg = 0;
-        for (int k = 0; k < s.n_ov; ++k) {
-            double ov = iou_f64(b, s, k);
-            if (k == 0 || ov > best) { best = ov; arg = k; }   // numpy argmax: first maximum
-            hit = hit || (ov == gmax[k]);                       // np.where(overlaps == gt_max), :139
-        }
-        if (dataset == WSSDL_DATASET_SNUBH) {
-            if (s.n_ui > 0 && !clobber) {
-                const double barea = (b.x2 - b.x1 + 1) * (b.y2 - b.y1 + 1);
-                double mu = 0.0;
-                for (int k = 0; k < s.n_ui; ++k) {
-                    double u = ui_f64(b, barea, s, s.n_ov + k);
-                    if (k == 0 || u > mu) mu = u;
-                }
-                if (mu >= pos_thr) label = 0;                   // :149-151
+    bool inside = false;
+    if (i < total) {
+        const int cell = i / A, a = i - cell * A;
+        const int h = cell / W, w = cell - h * W;
+        const AnchorBox b = make_anchor(base, a, h, w, stride, im_info[img * info_stride + 0],
+                                        im_info[img * info_stride + 1]);
+        inside = b.inside;
+        if (b.inside) {
+            double best = 0.0;
+            bool hit = false;
+            arg = 0;
+            for (int k = 0; k < s.n_ov; ++k) {
+                double ov = iou_f64(b, s, k);
+                if (k == 0 || ov > best) { best = ov; arg = k; }   // numpy argmax: first maximum
+                hit = hit || (ov == gmax[k]);                       // np.where(overlaps == gt_max), :139
             }
-            if (hit) label = 1;                                 // :154
-            if (best >= pos_thr) label = 1;                     // :157
-        } else {
-            if (!clobber && best < neg_thr) label = 0;          // :185-187
-            if (hit) label = 1;
-            if (best >= pos_thr) label = 1;
-            if (clobber && best < neg_thr) label = 0;           // :195-197
+            if (dataset == WSSDL_DATASET_SNUBH) {
+                if (s.n_ui > 0 && !clobber) {
+                    const double barea = (b.x2 - b.x1 + 1) * (b.y2 - b.y1 + 1);
+                    double mu = 0.0;
+                    for (int k = 0; k < s.n_ui; ++k) {
+                        double u = ui_f64(b, barea, s, s.n_ov + k);
+                        if (k == 0 || u > mu) mu = u;
+                    }
+                    if (mu >= pos_thr) label = 0;                   // :149-151
+                }
+                if (hit) label = 1;                                 // :154
+                if (best >= pos_thr) label = 1;                     // :157
+            } else {
+                if (!clobber && best < neg_thr) label = 0;          // :185-187
+                if (hit) label = 1;
+                if (best >= pos_thr) label = 1;
+                if (clobber && best < neg_thr) label = 0;           // :195-197
+            }
         }
-        atomicAdd(&counts[img * 4 + 0], 1);
-        if (label == 1) atomicAdd(&counts[img * 4 + 1], 1);
-        if (label == 0) atomicAdd(&counts[img * 4 + 2], 1);
+        labels_pre[(size_t)img * total + i] = (signed char)label;
+        argmax_gt[(size_t)img * total + i] = arg;
     }
-    labels_pre[(size_t)img * total + i] = (signed char)label;
-    argmax_gt[(size_t)img * total + i] = arg;
+    // counts: wave ballot -> LDS -> one global atomic per workgroup
+    const unsigned long long m_in = __ballot(inside);
+    const unsigned long long m_fg = __ballot(inside && label == 1);
+    const unsigned long long m_bg = __ballot(inside && label == 0);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&blk_cnt[0], __popcll(m_in));
+        atomicAdd(&blk_cnt[1], __popcll(m_fg));
+        atomicAdd(&blk_cnt[2], __popcll(m_bg));
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && blk_cnt[threadIdx.x] != 0)
+        atomicAdd(&counts[img * 4 + threadIdx.x], blk_cnt[threadIdx.x]);
 }
 
 // ------------------------------------------------------- device sub-sampling ---

@@ -23,6 +23,7 @@
 #include "common.hip.h"
 
 #include <float.h>
+#include <stdlib.h>
 
 namespace wssdl {
 
@@ -128,102 +129,337 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(
     }
 }
 
+// Forward, XCD-sliced: workgroup b serves channel slice b % 8 (C/8 channels) -- under the
+// observed round-robin placement that is one XCD, whose 4 MiB L2 then only ever holds its
+// slice of the feature map (1.2 MB per 38x63x1024 image instead of 9.8 MB).  A lane owns 4
+// channels of one (roi, ph) bin row and walks its PW bins, so the RoI geometry is computed
+// once per PW outputs.  Requires C % 32 == 0.  Placement affects speed only.
+__global__ __launch_bounds__(256) void roi_pool_fwd_sliced_kernel(
+    const float *__restrict__ bottom, int N, int H, int W, int C, const float *__restrict__ rois,
+    int R, int PH, int PW, float scale, int rounding, float *__restrict__ top,
+    int *__restrict__ argmax, int lanes_per_row /* = C/32 */, int rows_per_block) {
+    const int slice = blockIdx.x & 7;
+    const long long rows = (long long)R * PH;
+    const long long row = (long long)(blockIdx.x >> 3) * rows_per_block + threadIdx.x / lanes_per_row;
+    if (row >= rows) return;
+    const int lane_in_row = threadIdx.x % lanes_per_row;
+    const int c0 = slice * (C >> 3) + lane_in_row * 4;
+    const int r = (int)(row / PH), ph = (int)(row - (long long)r * PH);
+    const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);
+    const bool bad = g.batch < 0 || g.batch >= N;
+    const float *img = bottom + (size_t)(bad ? 0 : g.batch) * H * W * C;
+    int hs, he;
+    if (rounding == WSSDL_ROI_ROUND_CPU) {
+        hs = (int)((float)ph * g.bin_h);
+        he = (int)((float)(ph + 1) * g.bin_h);
+    } else {
+        hs = (int)floorf((float)ph * g.bin_h);
+        he = (int)ceilf((float)(ph + 1) * g.bin_h);
+    }
+    hs = min(max(hs + g.sh, 0), H);
+    he = min(max(he + g.sh, 0), H);
+    size_t o = ((size_t)row * PW) * C + c0;
+    for (int pw = 0; pw < PW; ++pw, o += C) {
+        int ws, we;
+        if (rounding == WSSDL_ROI_ROUND_CPU) {
+            ws = (int)((float)pw * g.bin_w);
+            we = (int)((float)(pw + 1) * g.bin_w);
+        } else {
+            ws = (int)floorf((float)pw * g.bin_w);
+            we = (int)ceilf((float)(pw + 1) * g.bin_w);
+        }
+        ws = min(max(ws + g.sw, 0), W);
+        we = min(max(we + g.sw, 0), W);
+        const bool empty = (he <= hs) || (we <= ws) || bad;
+        float4v mv = empty ? (float4v)(0.0f) : (float4v)(-FLT_MAX);
+        int4v mi = (int4v)(-1);
+        if (!empty) {
+            for (int h = hs; h < he; ++h) {
+                int base = (h * W + ws) * C + c0;
+                for (int w = ws; w < we; ++w, base += C) {
+                    const float4v v = *reinterpret_cast<const float4v *>(img + base);
+                    if (v.x > mv.x) { mv.x = v.x; mi.x = base; }
+                    if (v.y > mv.y) { mv.y = v.y; mi.y = base + 1; }
+                    if (v.z > mv.z) { mv.z = v.z; mi.z = base + 2; }
+                    if (v.w > mv.w) { mv.w = v.w; mi.w = base + 3; }
+                }
+            }
+        }
+        __builtin_nontemporal_store(mv, reinterpret_cast<float4v *>(top + o));
+        __builtin_nontemporal_store(mi, reinterpret_cast<int4v *>(argmax + o));
+    }
+}
+
 // ----------------------------------------------------------------- backward ---
-template <int TH, int TW, int CG>
+struct FastDiv {          // n / d = (n * magic) >> shift with one full-rate v_mul_u32_u24
+    unsigned magic;       // < 2^24
+    int shift;
+};
+
+// candidate pooled-bin range of one bottom row / column, roi_pooling_op_gpu.cu.cc:169-177
+__device__ __forceinline__ void cand_range(int d, float bin, int P, int &s, int &e) {
+    s = (int)floorf((float)d / bin);
+    e = (int)ceilf((float)(d + 1) / bin);
+    s = min(max(s, 0), P);
+    e = min(max(e, 0), P);
+}
+
+// One (RoI, tile) intersection, produced by the filter phase (24 B in LDS).
+//   geo     = ph0 | pw0 << 8 | phn << 16 | pwn << 24: the candidate bins of the tile's cells are
+//             [ph0, ph0+phn) x [pw0, pw0+pwn)  (phstart/phend are monotone in h, so the union
+//             over the tile's rows is one interval; same for columns)
+//   rowmask : bit 8*k + j  <=>  tile row h0+j lies in the RoI (in_roi) and bin row ph0+k is one of
+//             its candidate rows; colmask likewise for columns.  phn or pwn > 8 (possible only
+//             for pooled sizes > 8): GENERIC, the masks are unused.
+struct TouchRec {
+    int r;
+    unsigned geo;
+    unsigned long long rowmask, colmask;
+};
+constexpr unsigned TOUCH_GENERIC = 0xffu;
+
+template <int TN>
+__device__ __forceinline__ void touch_axis(int t0, int t1, int rs, int re, float bin, int P, int &p0,
+                                           int &pn, unsigned long long &mask) {
+    // tile cells t0..t1 (inclusive, <= TN of them), RoI cells rs..re
+    const int lo = max(t0, rs), hi = min(t1, re);
+    int s[TN], e[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        s[j] = e[j] = 0;
+        if (t0 + j >= lo && t0 + j <= hi) cand_range(t0 + j - rs, bin, P, s[j], e[j]);
+    }
+    int a, z, t;
+    cand_range(lo - rs, bin, P, a, t);
+    cand_range(hi - rs, bin, P, t, z);
+    p0 = a;
+    pn = z - a;
+    mask = 0ull;
+    if (lo > hi) { pn = 0; return; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            if (a + k >= s[j] && a + k < e[j]) mask |= 1ull << (8 * k + j);
+}
+
+
+// FAST: C is a power of two (idx -> cell by shift) and cell / W fits a 24-bit multiply.
+template <int TH, int TW, int CG, int CHUNK, int RB, bool FAST>
 __global__ __launch_bounds__(CG) void roi_pool_bwd_kernel(
     const float *__restrict__ top_diff, const int *__restrict__ argmax,
     const float *__restrict__ rois, int R, int N, int H, int W, int C, int PH, int PW, float scale,
-    float *__restrict__ bottom_diff, int tiles_h, int tiles_w, int cgroups) {
-    constexpr int KPT = 4;                 // RoIs tested per thread per filter round
-    constexpr int CHUNK = KPT * CG;
+    float *__restrict__ bottom_diff, int tiles_h, int tiles_w, int cgroups, int cshift,
+    FastDiv divw) {
+    static_assert(TH <= 8 && TW <= 8, "one mask byte per candidate bin row / column");
+    static_assert(CHUNK % CG == 0, "whole filter rounds");
+    constexpr int KPT = CHUNK / CG;        // RoIs tested per thread per filter round
     constexpr int NW = CG / WSSDL_WAVE;
     __shared__ float acc[TH * TW * CG];
-    __shared__ int list[CHUNK];
+    __shared__ TouchRec list[CHUNK];
     __shared__ int wave_cnt[KPT][NW];
 
-    int b = blockIdx.x;
-    const int cg = b % cgroups;  b /= cgroups;
-    const int tx = b % tiles_w;  b /= tiles_w;
-    const int ty = b % tiles_h;
-    const int n = b / tiles_h;
+    // Workgroup -> (image, channel group, tile).  Workgroups are dealt round-robin over the 8
+    // XCDs (blockIdx % 8; observed, used for speed only): all tiles of one (image, channel
+    // group) pair are given the same blockIdx % 8, so the bins that straddle tile borders --
+    // read by 2-4 neighbouring tiles walking the same RoI list -- are served by one L2.
+    const int pairs = N * cgroups, tiles = tiles_h * tiles_w;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = xcd + 8 * (slot / tiles);
+    if (pair >= pairs) return;
+    const int tile = slot % tiles;
+    const int cg = pair % cgroups, n = pair / cgroups;
+    const int tx = tile % tiles_w, ty = tile / tiles_w;
     const int tc = threadIdx.x;
     const int c = cg * CG + tc;
     const bool c_ok = c < C;
     const int h0 = ty * TH, w0 = tx * TW;
     const int h1 = min(h0 + TH, H) - 1, w1 = min(w0 + TW, W) - 1;   // inclusive
     const int lane = tc & (WSSDL_WAVE - 1), wave = tc / WSSDL_WAVE;
+    const int cmask = (1 << cshift) - 1;
+    const int cl = c_ok ? c : C - 1;       // lanes past C read channel C-1 ...
+    const int cm = c_ok ? c : -1;          // ... and never match
+    // Loads go through buffer descriptors (one per RoI, rebuilt from scalars): the lane only
+    // contributes this byte offset, the bin offset travels in the scalar soffset operand, so
+    // visiting a bin costs no vector address arithmetic.
+    const int voff = cl * 4;
+    const int roi_bytes = PH * PW * C * 4;
 
 #pragma unroll
     for (int i = 0; i < TH * TW; ++i) acc[i * CG + tc] = 0.0f;
 
     for (int base = 0; base < R; base += CHUNK) {
-        // ---- filter: RoIs of image n whose rounded box touches the tile, in RoI order
+        // ---- filter: RoIs of image n whose rounded box touches the tile, in RoI order.
+        // The thread that tests a RoI also evaluates the reference's candidate-bin formulas
+        // for the tile's rows and columns once, so the walk below only tests bit masks.
         bool hit[KPT];
+        RoiGeom gk[KPT];
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
-            int r = base + k * CG + tc;
+            const int r = base + k * CG + tc;
             hit[k] = false;
             if (r < R) {
-                RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);
+                gk[k] = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);
+                const RoiGeom &g = gk[k];
                 hit[k] = (g.batch == n) && g.sw <= w1 && g.ew >= w0 && g.sh <= h1 && g.eh >= h0;
             }
-            unsigned long long m = __ballot(hit[k]);
+            const unsigned long long m = __ballot(hit[k]);
             if (lane == 0) wave_cnt[k][wave] = __popcll(m);
         }
         __syncthreads();
         int cnt = 0;
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
-            unsigned long long m = __ballot(hit[k]);
+            const unsigned long long m = __ballot(hit[k]);
             int before = 0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                int wc = wave_cnt[k][w];
+                const int wc = wave_cnt[k][w];
                 before += (w < wave) ? wc : 0;
             }
             if (hit[k]) {
-                int pos = cnt + before + __popcll(m & ((1ull << lane) - 1ull));
-                list[pos] = base + k * CG + tc;
+                // stage the geometry in the record's fields; finished below
+                TouchRec &q = list[cnt + before + __popcll(m & ((1ull << lane) - 1ull))];
+                q.r = base + k * CG + tc;
+                q.geo = 0;
+                q.rowmask = ((unsigned long long)(unsigned)gk[k].sh << 32) | (unsigned)gk[k].eh;
+                q.colmask = ((unsigned long long)(unsigned)gk[k].sw << 32) | (unsigned)gk[k].ew;
             }
 #pragma unroll
             for (int w = 0; w < NW; ++w) cnt += wave_cnt[k][w];
         }
         __syncthreads();
+        // finish the records with the hits packed into the first threads (no divergence
+        // between hit and non-hit lanes): candidate ranges of the tile's rows / columns
+        for (int t = tc; t < cnt; t += CG) {
+            TouchRec q = list[t];
+            const int sh = (int)(unsigned)(q.rowmask >> 32), eh = (int)(unsigned)q.rowmask;
+            const int sw = (int)(unsigned)(q.colmask >> 32), ew = (int)(unsigned)q.colmask;
+            const float bin_h = (float)max(eh - sh + 1, 1) / (float)PH;     // as roi_geometry
+            const float bin_w = (float)max(ew - sw + 1, 1) / (float)PW;
+            int ph0, phn, pw0, pwn;
+            touch_axis<TH>(h0, h1, sh, eh, bin_h, PH, ph0, phn, q.rowmask);
+            touch_axis<TW>(w0, w1, sw, ew, bin_w, PW, pw0, pwn, q.colmask);
+            if (phn <= 0 || pwn <= 0) phn = pwn = 0;                          // nothing to visit
+            else if (phn > 8 || pwn > 8) phn = pwn = (int)TOUCH_GENERIC;
+            q.geo = (unsigned)ph0 | ((unsigned)pw0 << 8) | ((unsigned)phn << 16) | ((unsigned)pwn << 24);
+            list[t] = q;
+        }
+        __syncthreads();
 
-        // ---- walk the touching RoIs in order; every lane = one channel
+        // ---- walk the touching RoIs in order; every lane = one channel, so per element the
+        // f32 additions happen in the reference's order (roi^, ph^, pw^).  The record is
+        // wave-uniform (scalar registers); bins are visited BB at a time: 2*BB loads from a
+        // scalar base + lane offset are issued back to back, then accumulated in order.
         for (int i = 0; i < cnt; ++i) {
-            const int r = list[i];
-            RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);
-            const int hlo = max(h0, g.sh), hhi = min(h1, g.eh);
-            const int wlo = max(w0, g.sw), whi = min(w1, g.ew);
-            // candidate bins of the tile's cells: phstart/phend are monotone in h
-            // (roi_pooling_op_gpu.cu.cc:169-177), so the union over the tile rows
-            // is [phstart(hlo), phend(hhi)).
-            int ph0 = (int)floorf((float)(hlo - g.sh) / g.bin_h);
-            int ph1 = (int)ceilf((float)(hhi - g.sh + 1) / g.bin_h);
-            int pw0 = (int)floorf((float)(wlo - g.sw) / g.bin_w);
-            int pw1 = (int)ceilf((float)(whi - g.sw + 1) / g.bin_w);
-            ph0 = min(max(ph0, 0), PH);  ph1 = min(max(ph1, 0), PH);
-            pw0 = min(max(pw0, 0), PW);  pw1 = min(max(pw1, 0), PW);
-            for (int ph = ph0; ph < ph1; ++ph) {
-                for (int pw = pw0; pw < pw1; ++pw) {
-                    if (!c_ok) continue;
-                    size_t o = (((size_t)r * PH + ph) * PW + pw) * C + c;
-                    int idx = argmax[o];
-                    if (idx < 0) continue;
-                    int cell = idx / C;
-                    if (idx - cell * C != c) continue;
-                    int h = cell / W, w = cell - h * W;
-                    if (h < hlo || h > hhi || w < wlo || w > whi) continue;   // tile & in_roi
-                    int phs = (int)floorf((float)(h - g.sh) / g.bin_h);
-                    int phe = (int)ceilf((float)(h - g.sh + 1) / g.bin_h);
-                    int pws = (int)floorf((float)(w - g.sw) / g.bin_w);
-                    int pwe = (int)ceilf((float)(w - g.sw + 1) / g.bin_w);
-                    phs = min(max(phs, 0), PH);  phe = min(max(phe, 0), PH);
-                    pws = min(max(pws, 0), PW);  pwe = min(max(pwe, 0), PW);
-                    if (ph >= phs && ph < phe && pw >= pws && pw < pwe) {
-                        float *a = &acc[((h - h0) * TW + (w - w0)) * CG + tc];
-                        *a = *a + top_diff[o];
+            const int r = __builtin_amdgcn_readfirstlane(list[i].r);
+            const unsigned geo = (unsigned)__builtin_amdgcn_readfirstlane((int)list[i].geo);
+            const int ph0 = geo & 0xff, pw0 = (geo >> 8) & 0xff;
+            const int phn = (geo >> 16) & 0xff, pwn = geo >> 24;
+            const size_t rbin0 = (size_t)r * PH * PW;
+            if (phn == 0) continue;
+            if (phn != (int)TOUCH_GENERIC) {
+                const unsigned long long rowmask =
+                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(list[i].rowmask >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)list[i].rowmask);
+                const unsigned long long colmask =
+                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(list[i].colmask >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)list[i].colmask);
+                // column masks of the <= 8 candidate bin columns (compile-time shifts)
+                unsigned cmk[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cmk[j] = (unsigned)(colmask >> (8 * j)) & 0xffu;
+                const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<int *>(argmax + rbin0 * C), 0, roi_bytes, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(top_diff + rbin0 * C), 0, roi_bytes, 0x00020000);
+                const int bin_bytes = C * 4;
+                int so_row = (ph0 * PW + pw0) * bin_bytes;       // scalar byte offset of the bin row
+                for (int rb = 0; rb < phn; rb += RB) {
+                    // issue the loads of up to RB bin rows back to back
+                    int idx[RB][8];
+                    float td[RB][8];
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            idx[q][j] = -1;
+                            td[q][j] = 0.0f;
+                            if (rb + q < phn && j < pwn) {       // wave-uniform
+                                const int so = so_row + j * bin_bytes;
+                                idx[q][j] = (int)__builtin_amdgcn_raw_buffer_load_b32(ra, voff, so, 0);
+                                td[q][j] = __builtin_bit_cast(
+                                    float, __builtin_amdgcn_raw_buffer_load_b32(rt, voff, so, 0));
+                            }
+                        }
+                        so_row += PW * bin_bytes;
+                    }
+                    // keep every loaded value live here: otherwise the compiler sinks the
+                    // top_diff loads into the (rare) hit branch and serialises them
+#pragma unroll
+                    for (int q = 0; q < RB; ++q)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(idx[q][j]), "+v"(td[q][j]));
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) {
+                        if (rb + q < phn) {                      // wave-uniform
+                            const unsigned rm = (unsigned)(rowmask >> (8 * (rb + q))) & 0xffu;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                if (j < pwn) {                   // wave-uniform
+                                    const int id = idx[q][j];
+                                    int cell, cc, h, w;
+                                    if (FAST) {
+                                        cell = id >> cshift;
+                                        cc = id & cmask;
+                                        h = (int)(__umul24((unsigned)cell, divw.magic) >> divw.shift);
+                                        w = cell - (int)__umul24((unsigned)h, (unsigned)W);
+                                    } else {
+                                        cell = id / C;
+                                        cc = id - cell * C;
+                                        h = cell / W;
+                                        w = cell - h * W;
+                                    }
+                                    const unsigned dh = (unsigned)(h - h0), dw = (unsigned)(w - w0);
+                                    // tile, in_roi and candidate-bin tests: two mask look-ups
+                                    const unsigned bits = (rm >> (dh & 7u)) & (cmk[j] >> (dw & 7u)) & 1u;
+                                    const bool ok = (bits != 0u) & ((dh | dw) < 8u) & (id >= 0) & (cc == cm);
+                                    if (ok) {
+                                        float *a = &acc[(dh * TW + dw) * CG + tc];
+                                        *a = *a + td[q][j];
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            } else {
+                // pooled sizes with more than 8 candidate bin rows / columns per tile: one bin
+                // at a time, the reference's tests evaluated per lane
+                const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);
+                const int hlo = max(h0, g.sh), hhi = min(h1, g.eh);
+                const int wlo = max(w0, g.sw), whi = min(w1, g.ew);
+                int pa, pz, qa, qz, t;
+                cand_range(hlo - g.sh, g.bin_h, PH, pa, t);
+                cand_range(hhi - g.sh, g.bin_h, PH, t, pz);
+                cand_range(wlo - g.sw, g.bin_w, PW, qa, t);
+                cand_range(whi - g.sw, g.bin_w, PW, t, qz);
+                for (int ph = pa; ph < pz; ++ph) {
+                    for (int pw = qa; pw < qz; ++pw) {
+                        const size_t bo = (rbin0 + (size_t)(ph * PW + pw)) * C;
+                        const int id = (argmax + bo)[cl];
+                        const float tv = (top_diff + bo)[cl];
+                        if (id < 0) continue;
+                        const int cell = id / C, cc = id - cell * C;
+                        const int h = cell / W, w = cell - h * W;
+                        if (cc != cm || h < hlo || h > hhi || w < wlo || w > whi) continue;
+                        int rs, re, cs, ce;
+                        cand_range(h - g.sh, g.bin_h, PH, rs, re);
+                        cand_range(w - g.sw, g.bin_w, PW, cs, ce);
+                        if (ph >= rs && ph < re && pw >= cs && pw < ce) {
+                            float *a = &acc[((h - h0) * TW + (w - w0)) * CG + tc];
+                            *a = *a + tv;
+                        }
                     }
                 }
             }
@@ -233,24 +469,52 @@ __global__ __launch_bounds__(CG) void roi_pool_bwd_kernel(
 
     if (c_ok) {
         float *img = bottom_diff + (size_t)n * H * W * C;
+#pragma unroll
         for (int i = 0; i < TH * TW; ++i) {
-            int h = h0 + i / TW, w = w0 + i % TW;
+            const int h = h0 + i / TW, w = w0 + i % TW;
             if (h < H && w < W) img[((size_t)h * W + w) * C + c] = acc[i * CG + tc];
         }
     }
 }
 
-template <int CG>
+template <int TH, int TW, int CG, int CHUNK, int RB>
 static int launch_bwd(const float *top_diff, const int *argmax, const float *rois, int R, int N,
                       int H, int W, int C, int PH, int PW, float scale, float *bottom_diff,
                       hipStream_t st) {
-    constexpr int TH = 8, TW = 8;
     int tiles_h = cdiv(H, TH), tiles_w = cdiv(W, TW), cgroups = cdiv(C, CG);
-    long long blocks = (long long)N * tiles_h * tiles_w * cgroups;
+    // 8 interleaved queues (one per blockIdx % 8) of ceil(pairs / 8) * tiles workgroups each
+    long long blocks = 8LL * cdiv((long long)N * cgroups, 8) * tiles_h * tiles_w;
     if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL((roi_pool_bwd_kernel<TH, TW, CG>), dim3((unsigned)blocks), dim3(CG), 0, st,
-                       top_diff, argmax, rois, R, N, H, W, C, PH, PW, scale, bottom_diff, tiles_h,
-                       tiles_w, cgroups);
+    int cshift = 0;
+    while ((1 << cshift) < C) ++cshift;
+    const bool cpow2 = (1 << cshift) == C;
+    // cell / W for every cell < H*W by one 24-bit multiply: (cell * magic) >> shift with
+    // cell, magic < 2^24 and cell * magic < 2^32; verified exhaustively (H*W is small)
+    FastDiv dw;
+    dw.magic = 0;
+    dw.shift = 0;
+    bool fast = cpow2 && (long long)H * W < (1 << 16);
+    if (fast) {
+        const unsigned cells = (unsigned)H * (unsigned)W;
+        bool found = false;
+        for (int sft = 8; sft <= 24 && !found; ++sft) {
+            unsigned long long mg = ((1ULL << sft) + (unsigned)W - 1) / (unsigned)W;
+            if (mg >= (1ULL << 24) || mg * (cells ? cells - 1 : 0) >= (1ULL << 32)) continue;
+            bool exact = true;
+            for (unsigned n = 0; n < cells && exact; ++n)
+                exact = (unsigned)((n * mg) >> sft) == n / (unsigned)W;
+            if (exact) { dw.magic = (unsigned)mg; dw.shift = sft; found = true; }
+        }
+        fast = found;
+    }
+    if (fast)
+        hipLaunchKernelGGL((roi_pool_bwd_kernel<TH, TW, CG, CHUNK, RB, true>), dim3((unsigned)blocks),
+                           dim3(CG), 0, st, top_diff, argmax, rois, R, N, H, W, C, PH, PW, scale,
+                           bottom_diff, tiles_h, tiles_w, cgroups, cshift, dw);
+    else
+        hipLaunchKernelGGL((roi_pool_bwd_kernel<TH, TW, CG, CHUNK, RB, false>), dim3((unsigned)blocks),
+                           dim3(CG), 0, st, top_diff, argmax, rois, R, N, H, W, C, PH, PW, scale,
+                           bottom_diff, tiles_h, tiles_w, cgroups, cshift, dw);
     return check_launch();
 }
 
@@ -273,6 +537,17 @@ extern "C" int wssdl_roi_pool_forward(const float *bottom, int N, int H, int W, 
     const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(bottom) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(top) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(argmax) & 15) == 0);
+    if (vec && C % 32 == 0 && C / 32 <= 256 && !getenv("WSSDL_FWD_FLAT")) {
+        const int lanes_per_row = C / 32;
+        const int rows_per_block = 256 / lanes_per_row;
+        const long long row_blocks = ((long long)R * pooled_h + rows_per_block - 1) / rows_per_block;
+        if (row_blocks * 8 <= 0x7fffffffLL) {
+            hipLaunchKernelGGL(roi_pool_fwd_sliced_kernel, dim3((unsigned)(row_blocks * 8)), dim3(256), 0,
+                               st, bottom, N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale,
+                               rounding, top, argmax, lanes_per_row, rows_per_block);
+            return check_launch();
+        }
+    }
     long long total = (long long)R * pooled_h * pooled_w * (vec ? C / 4 : C);
     long long blocks = (total + 255) / 256;
     if (blocks > (1LL << 22)) blocks = 1LL << 22;     // grid-stride beyond 4M workgroups
@@ -293,17 +568,27 @@ extern "C" int wssdl_roi_pool_backward(const float *top_diff, const int32_t *arg
                                        float *bottom_diff, wssdl_stream_t stream) {
     if (N < 0 || H < 1 || W < 1 || C < 1 || R < 0 || pooled_h < 1 || pooled_w < 1)
         return WSSDL_ERR_INVALID_ARGUMENT;
+    if (pooled_h > 255 || pooled_w > 255) return WSSDL_ERR_INVALID_ARGUMENT;   // 8-bit bin tables
     if ((long long)H * W * C > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
     if (N == 0) return WSSDL_OK;
     if (!bottom_diff || (R > 0 && (!top_diff || !argmax || !rois)))
         return WSSDL_ERR_INVALID_ARGUMENT;
     hipStream_t st = as_stream(stream);
-    if (C > 128)
-        return launch_bwd<256>(top_diff, argmax, rois, R, N, H, W, C, pooled_h, pooled_w,
-                               spatial_scale, bottom_diff, st);
-    if (C > 64)
-        return launch_bwd<128>(top_diff, argmax, rois, R, N, H, W, C, pooled_h, pooled_w,
-                               spatial_scale, bottom_diff, st);
-    return launch_bwd<64>(top_diff, argmax, rois, R, N, H, W, C, pooled_h, pooled_w,
-                          spatial_scale, bottom_diff, st);
+#define WSSDL_BWD(TH, TW, CG, CHUNK, RB)                                                          \
+    return launch_bwd<TH, TW, CG, CHUNK, RB>(top_diff, argmax, rois, R, N, H, W, C, pooled_h, pooled_w, \
+                                             spatial_scale, bottom_diff, st)
+    if (const char *v = getenv("WSSDL_BWD_VARIANT")) {      // tuning experiments only
+        const int k = atoi(v);
+        if (k == 1) WSSDL_BWD(8, 8, 256, 512, 4);
+        if (k == 2) WSSDL_BWD(4, 8, 256, 256, 4);
+        if (k == 3) WSSDL_BWD(4, 8, 256, 256, 2);
+        if (k == 4) WSSDL_BWD(8, 8, 256, 512, 8);
+        if (k == 5) WSSDL_BWD(4, 8, 128, 256, 4);
+        if (k == 6) WSSDL_BWD(8, 4, 256, 256, 4);
+        if (k == 7) WSSDL_BWD(4, 8, 256, 256, 8);
+    }
+    if (C > 128) WSSDL_BWD(4, 8, 256, 256, 2);
+    if (C > 64) WSSDL_BWD(4, 8, 128, 256, 2);
+    WSSDL_BWD(4, 8, 64, 128, 2);
+#undef WSSDL_BWD
 }
