@@ -71,54 +71,62 @@ __device__ __forceinline__ float box_area_ref(float x1, float y1, float x2, floa
     return w * h;
 }
 
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ boxes,
-                                                      int box_stride_img,
-                                                      const int *__restrict__ n_dev, int n_max,
-                                                      double thresh,
-                                                      unsigned long long *__restrict__ mask,
-                                                      int ncb) {
-    const int cb = blockIdx.x, rb = blockIdx.y, img = blockIdx.z;
-    if (cb < rb) return;
+constexpr int MASK_WAVES = 4;
+
+constexpr int MASK_SEG = 16;     // column blocks per workgroup
+
+// One workgroup per (64-row block, segment of 16 column blocks); its 4 waves stride over the
+// segment's column blocks cb >= rb (upper triangle only).  A lane keeps its row box in
+// registers; the 64 column boxes of the wave's current block sit in that wave's LDS slice and
+// are read as broadcasts.
+__global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
+    const float *__restrict__ boxes, int box_stride_img, const int *__restrict__ n_dev, int n_max,
+    double thresh, unsigned long long *__restrict__ mask, int ncb) {
+    const int rb = blockIdx.x, seg = blockIdx.y, img = blockIdx.z;
     const int n = min(n_dev[img], n_max);
-    if (rb * 64 >= n || cb * 64 >= n) return;
-    __shared__ float cx1[64], cy1[64], cx2[64], cy2[64], carea[64];
+    if (rb * 64 >= n || (seg + 1) * MASK_SEG <= rb || seg * MASK_SEG * 64 >= n) return;
+    __shared__ float cbox[MASK_WAVES][5][64];
     const float *b = boxes + (size_t)img * box_stride_img;
-    const int t = threadIdx.x;
-    const int col = cb * 64 + t;
-    if (col < n) {
-        float x1 = b[col * 4 + 0], y1 = b[col * 4 + 1], x2 = b[col * 4 + 2], y2 = b[col * 4 + 3];
-        cx1[t] = x1; cy1[t] = y1; cx2[t] = x2; cy2[t] = y2;
-        carea[t] = box_area_ref(x1, y1, x2, y2);
-    }
-    __syncthreads();
-    const int i = rb * 64 + t;
-    if (i >= n) return;
-    const float ix1 = b[i * 4 + 0], iy1 = b[i * 4 + 1], ix2 = b[i * 4 + 2], iy2 = b[i * 4 + 3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = rb * 64 + lane;
+    const bool row_ok = i < n;
+    float ix1 = 0.f, iy1 = 0.f, ix2 = 0.f, iy2 = 0.f;
+    if (row_ok) { ix1 = b[i * 4 + 0]; iy1 = b[i * 4 + 1]; ix2 = b[i * 4 + 2]; iy2 = b[i * 4 + 3]; }
     const float iarea = box_area_ref(ix1, iy1, ix2, iy2);
-    const int jn = min(64, n - cb * 64);
-    unsigned long long bits = 0ull;
-    for (int j = 0; j < jn; ++j) {
-        if (cb * 64 + j <= i) continue;
-        float xx1 = fmax_ref(ix1, cx1[j]);
-        float yy1 = fmax_ref(iy1, cy1[j]);
-        float xx2 = fmin_ref(ix2, cx2[j]);
-        float yy2 = fmin_ref(iy2, cy2[j]);
-        float w = xx2 - xx1;  w = fmax_ref(0.0f, w + 1.0f);
-        float h = yy2 - yy1;  h = fmax_ref(0.0f, h + 1.0f);
-        float inter = w * h;
-        float den = iarea + carea[j];
-        den = den - inter;
-        float ovr = inter / den;
-        if ((double)ovr >= thresh) bits |= 1ull << j;
+    const int cb_end = min((n + 63) / 64, (seg + 1) * MASK_SEG);
+    for (int cb = max(rb, seg * MASK_SEG) + wave; cb < cb_end; cb += MASK_WAVES) {
+        const int col = cb * 64 + lane;
+        float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
+        if (col < n) { x1 = b[col * 4 + 0]; y1 = b[col * 4 + 1]; x2 = b[col * 4 + 2]; y2 = b[col * 4 + 3]; }
+        // the wave's own slice: wave-synchronous, no workgroup barrier needed
+        cbox[wave][0][lane] = x1; cbox[wave][1][lane] = y1; cbox[wave][2][lane] = x2;
+        cbox[wave][3][lane] = y2; cbox[wave][4][lane] = box_area_ref(x1, y1, x2, y2);
+        __builtin_amdgcn_wave_barrier();
+        const int jn = min(64, n - cb * 64);
+        unsigned long long bits = 0ull;
+        for (int j = 0; j < jn; ++j) {
+            float xx1 = fmax_ref(ix1, cbox[wave][0][j]);
+            float yy1 = fmax_ref(iy1, cbox[wave][1][j]);
+            float xx2 = fmin_ref(ix2, cbox[wave][2][j]);
+            float yy2 = fmin_ref(iy2, cbox[wave][3][j]);
+            float w = xx2 - xx1;  w = fmax_ref(0.0f, w + 1.0f);
+            float h = yy2 - yy1;  h = fmax_ref(0.0f, h + 1.0f);
+            float inter = w * h;
+            float den = iarea + cbox[wave][4][j];
+            den = den - inter;
+            float ovr = inter / den;
+            if ((double)ovr >= thresh && cb * 64 + j > i) bits |= 1ull << j;
+        }
+        if (row_ok) mask[((size_t)img * n_max + i) * ncb + cb] = bits;
+        __builtin_amdgcn_wave_barrier();
     }
-    mask[((size_t)img * n_max + i) * ncb + cb] = bits;
 }
 
 int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, int n_max,
                     int n_images, double thresh, unsigned long long *mask, hipStream_t st) {
     int ncb = cdiv(n_max, 64);
     if (ncb == 0 || n_images == 0) return WSSDL_OK;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(ncb, ncb, n_images), dim3(64), 0, st, boxes,
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(ncb, cdiv(ncb, MASK_SEG), n_images), dim3(64 * MASK_WAVES), 0, st, boxes,
                        box_stride_img, n_dev, n_max, thresh, mask, ncb);
     return check_launch();
 }
@@ -139,6 +147,7 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_kernel(
     const float *__restrict__ boxes, int box_stride_img, float *__restrict__ rois_padded) {
     extern __shared__ unsigned long long removed[];   // [ncb]
     __shared__ unsigned long long s_kept;
+    __shared__ int s_rows[64];
     const int img = blockIdx.x;
     const int n = min(n_dev[img], n_max);
     const unsigned long long *m = mask + (size_t)img * n_max * ncb;
@@ -147,26 +156,32 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_kernel(
     __syncthreads();
     int count = 0;
     const int nchunks = (n + 63) / 64;
+    // wave 0 keeps the diagonal word of the next chunk in flight during the push phase
+    unsigned long long diag = 0ull;
+    if (wave == 0 && nchunks > 0) diag = (lane < n) ? m[(size_t)lane * ncb] : 0ull;
     for (int c = 0; c < nchunks; ++c) {
         if (wave == 0) {
             const int row = c * 64 + lane;
-            unsigned long long diag = (row < n) ? m[(size_t)row * ncb + c] : 0ull;
-            unsigned long long cur = removed[c];
-            cur = readlane_u64(cur, 0);
             const int nv = n - c * 64;
             const unsigned long long valid = (nv >= 64) ? ~0ull : ((1ull << nv) - 1ull);
+            unsigned long long cur = readlane_u64(removed[c], 0) | ~valid;
+            // greedy resolve inside the chunk, entirely in scalar registers: visit only the
+            // boxes that survive (about kept-per-chunk iterations, not 64)
             unsigned long long kept = 0ull;
-#pragma unroll
-            for (int b = 0; b < 64; ++b) {
-                unsigned long long d = readlane_u64(diag, b);
-                if (!((cur >> b) & 1ull) && ((valid >> b) & 1ull)) {
-                    kept |= 1ull << b;
-                    cur |= d;
-                }
+            unsigned long long cand = ~cur;
+            while (cand != 0ull) {
+                const int bsel = __builtin_amdgcn_readfirstlane(__ffsll((long long)cand) - 1);
+                kept |= 1ull << bsel;
+                unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)diag, bsel);
+                unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(diag >> 32), bsel);
+                cur |= (((unsigned long long)hi << 32) | lo) | (1ull << bsel);
+                cand = ~cur & ((bsel == 63) ? 0ull : (~0ull << (bsel + 1)));
             }
             if (lane == 0) s_kept = kept;
             if ((kept >> lane) & 1ull) {
-                int pos = count + __popcll(kept & ((1ull << lane) - 1ull));
+                const int ord = __popcll(kept & ((1ull << lane) - 1ull));
+                s_rows[ord] = row;
+                const int pos = count + ord;
                 if (pos < max_keep) {
                     if (keep)
                         keep[(size_t)img * max_keep + pos] =
@@ -178,20 +193,31 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_kernel(
                     }
                 }
             }
+            // prefetch the next chunk's diagonal word
+            const int nrow = (c + 1) * 64 + lane;
+            diag = (c + 1 < nchunks && nrow < n) ? m[(size_t)nrow * ncb + c + 1] : 0ull;
         }
         __syncthreads();
         const unsigned long long kept = s_kept;
-        count += __popcll(kept);
+        const int nk = __popcll(kept);
+        count += nk;
         if (count >= max_keep) break;
-        for (int w = c + 1 + tid; w < ncb; w += SWEEP_BLOCK) {
-            unsigned long long acc = removed[w];
-            unsigned long long k = kept;
-            while (k) {
-                int b = __ffsll((long long)k) - 1;
-                k &= k - 1ull;
-                acc |= m[(size_t)(c * 64 + b) * ncb + w];
+        // push: OR the kept rows' mask words into the LDS bitmap.  8 groups of 32 lanes take
+        // the kept rows round-robin; a group reads 32 consecutive words (256 B) per step; all
+        // loads are independent, the OR is an LDS atomic.
+        const int grp = tid >> 5, wl = tid & 31;
+        for (int kr = grp; kr < nk; kr += SWEEP_BLOCK / 32) {
+            const unsigned long long *rowp = m + (size_t)s_rows[kr] * ncb;
+            for (int w = c + 1 + wl; w < ncb; w += 128) {
+                unsigned long long v0 = rowp[w];
+                unsigned long long v1 = (w + 32 < ncb) ? rowp[w + 32] : 0ull;
+                unsigned long long v2 = (w + 64 < ncb) ? rowp[w + 64] : 0ull;
+                unsigned long long v3 = (w + 96 < ncb) ? rowp[w + 96] : 0ull;
+                if (v0) atomicOr(&removed[w], v0);
+                if (v1) atomicOr(&removed[w + 32], v1);
+                if (v2) atomicOr(&removed[w + 64], v2);
+                if (v3) atomicOr(&removed[w + 96], v3);
             }
-            removed[w] = acc;
         }
         __syncthreads();
     }

@@ -16,6 +16,61 @@ import torch.nn.functional as F
 from .backbones import RESNET_DEFS, _same_pad
 
 
+class _RowBatchNormFn(torch.autograd.Function):
+    """Training-mode batch norm over the rows of [M, C] built from column reductions
+    (`var_mean`, `sum`) and fused elementwise ops.  PyTorch's native channels-last batch-norm
+    kernels take 12 ms forward+backward on a [136k, 2048] f32 tensor on MI355X; this form
+    takes about 2.5 ms.  Same maths (biased variance for normalisation)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        var, mean = torch.var_mean(x, dim=0, unbiased=False)
+        rstd = torch.rsqrt(var + eps)
+        scale = rstd * weight
+        y = torch.addcmul(bias - mean * scale, x, scale)
+        ctx.save_for_backward(x, mean, rstd, weight)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dmean, _dvar):
+        x, mean, rstd, weight = ctx.saved_tensors
+        m = x.shape[0]
+        sum_dy = dy.sum(0)
+        sum_dy_x = (dy * x).sum(0)
+        sum_dy_xhat = (sum_dy_x - mean * sum_dy) * rstd
+        # dx = w*rstd * (dy - mean(dy) - xhat * mean(dy*xhat)),  xhat = (x - mean) * rstd
+        a = weight * rstd
+        k1 = a * rstd * sum_dy_xhat / m                  # multiplies (x - mean)
+        k0 = a * sum_dy / m - k1 * mean                  # constant per column: a*mean(dy) - k1*mean
+        dx = torch.addcmul(-k0, dy, a)
+        dx.addcmul_(x, -k1)
+        return dx, sum_dy_xhat, sum_dy, None
+
+
+class RowBatchNorm(nn.Module):
+    """BatchNorm over rows ([M, C] input) with the usual running statistics."""
+
+    def __init__(self, num_features, eps=1e-3, momentum=0.01):
+        super().__init__()
+        self.eps, self.momentum = eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+
+    def forward(self, x):
+        if not self.training:
+            scale = self.weight * torch.rsqrt(self.running_var + self.eps)
+            return torch.addcmul(self.bias - self.running_mean * scale, x, scale)
+        y, mean, var = _RowBatchNormFn.apply(x, self.weight, self.bias, self.eps)
+        with torch.no_grad():
+            m = x.shape[0]
+            self.running_mean.lerp_(mean, self.momentum)
+            self.running_var.lerp_(var * (m / max(m - 1, 1)), self.momentum)
+        return y
+
+
 class ConvNHWC(nn.Module):
     """conv (TF 'SAME') + optional BN + optional ReLU on NHWC tensors via one GEMM.
     weight [c_o, k*k*c_i] with the patch laid out (kh, kw, c_i)."""
@@ -26,7 +81,7 @@ class ConvNHWC(nn.Module):
         self.weight = nn.Parameter(torch.empty(c_o, k * k * c_i))
         nn.init.trunc_normal_(self.weight, std=0.01, a=-0.02, b=0.02)
         self.bias = nn.Parameter(torch.zeros(c_o)) if norm is None else None
-        self.bn = nn.BatchNorm1d(c_o, eps=1e-3, momentum=0.01) if norm == "BN" else None
+        self.bn = RowBatchNorm(c_o) if norm == "BN" else None
 
     def forward(self, x):
         r, h, w, c = x.shape
@@ -62,8 +117,7 @@ class BottleneckNHWC(nn.Module):
     def __init__(self, c_i, c_o, s, preact, norm):
         super().__init__()
         self.preact = preact
-        self.pre_bn = nn.BatchNorm1d(c_i, eps=1e-3, momentum=0.01) \
-            if (preact != "no_preact" and norm == "BN") else None
+        self.pre_bn = RowBatchNorm(c_i) if (preact != "no_preact" and norm == "BN") else None
         self.conv1 = ConvNHWC(c_i, c_o, 1, 1, norm)
         self.conv2 = ConvNHWC(c_o, c_o, 3, s, norm)
         self.conv3 = ConvNHWC(c_o, c_o * 4, 1, 1, norm, relu=False)
@@ -86,8 +140,7 @@ class BasicBlockNHWC(nn.Module):
     def __init__(self, c_i, c_o, s, preact, norm):
         super().__init__()
         self.preact = preact
-        self.pre_bn = nn.BatchNorm1d(c_i, eps=1e-3, momentum=0.01) \
-            if (preact != "no_preact" and norm == "BN") else None
+        self.pre_bn = RowBatchNorm(c_i) if (preact != "no_preact" and norm == "BN") else None
         self.conv1 = ConvNHWC(c_i, c_o, 3, s, norm)
         self.conv2 = ConvNHWC(c_o, c_o, 3, 1, norm, relu=False)
         self.short = ConvNHWC(c_i, c_o, 1, s, norm, relu=False) if c_i != c_o else None
@@ -115,7 +168,7 @@ class ResNetHeadNHWC(nn.Module):
         for _ in range(1, defs[3]):
             blocks.append(blk(512 * e, 512, 1, "default", norm))
         self.group3 = nn.Sequential(*blocks)
-        self.norm = nn.BatchNorm1d(512 * e, eps=1e-3, momentum=0.01) if norm == "BN" else None
+        self.norm = RowBatchNorm(512 * e) if norm == "BN" else None
         self.out_features = 512 * e
 
     def forward(self, x):
