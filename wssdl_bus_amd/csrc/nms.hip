@@ -25,39 +25,122 @@
 namespace wssdl {
 
 // ---------------------------------------------------------------- rank/top-k ---
+// Descending order of the topn largest 64-bit keys of each image, in three steps:
+//   topk_threshold : the topn-th largest key by MSB-first radix select (one workgroup per
+//                    image, 8 histogram passes over the keys; keys are unique);
+//   topk_compact   : keys >= threshold -> dense candidate array (any order);
+//   rank_topk      : position of every candidate = number of greater candidates, counted over
+//                    LDS-staged tiles -- O(topn^2) instead of O(M^2) compares.
+// 64-bit keys = (order-preserving score bits << 32 | index) make the order total (ties:
+// higher index first) and the result deterministic.
+constexpr int SEL_BLOCK = 1024;
+
+__global__ __launch_bounds__(SEL_BLOCK) void topk_threshold_kernel(
+    const unsigned long long *__restrict__ keys, int M, int topn,
+    unsigned long long *__restrict__ thresh, int *__restrict__ n_sorted) {
+    __shared__ int hist[256];
+    __shared__ int s_sel[2];
+    __shared__ int s_valid;
+    const int img = blockIdx.x, t = threadIdx.x;
+    const unsigned long long *k = keys + (size_t)img * M;
+    if (t == 0) s_valid = 0;
+    __syncthreads();
+    int c = 0;
+    for (int i = t; i < M; i += SEL_BLOCK) c += (k[i] != 0ull) ? 1 : 0;
+    atomicAdd(&s_valid, c);
+    __syncthreads();
+    const int valid = s_valid;
+    __syncthreads();
+    if (t == 0) n_sorted[img] = min(valid, topn);
+    if (valid <= topn) {                       // every valid key is a candidate
+        if (t == 0) thresh[img] = 1ull;
+        return;
+    }
+    unsigned long long prefix = 0ull, pmask = 0ull;
+    int want = topn;                           // rank (1-based, from the top) inside the prefix bucket
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        if (t < 256) hist[t] = 0;
+        __syncthreads();
+        for (int i = t; i < M; i += SEL_BLOCK) {
+            const unsigned long long v = k[i];
+            if (v != 0ull && (v & pmask) == prefix) atomicAdd(&hist[(int)((v >> shift) & 0xff)], 1);
+        }
+        __syncthreads();
+        if (t == 0) {
+            int acc = 0, b = 255;
+            for (; b > 0; --b) {
+                if (acc + hist[b] >= want) break;
+                acc += hist[b];
+            }
+            s_sel[0] = b;
+            s_sel[1] = want - acc;
+        }
+        __syncthreads();
+        prefix |= (unsigned long long)s_sel[0] << shift;
+        pmask |= 0xffull << shift;
+        want = s_sel[1];
+        __syncthreads();
+    }
+    if (t == 0) thresh[img] = prefix;          // the topn-th largest key
+}
+
+__global__ __launch_bounds__(256) void topk_compact_kernel(
+    const unsigned long long *__restrict__ keys, int M, int topn,
+    const unsigned long long *__restrict__ thresh, unsigned long long *__restrict__ cand,
+    int *__restrict__ cand_fill) {
+    const int img = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const unsigned long long v = keys[(size_t)img * M + i];
+    if (v != 0ull && v >= thresh[img]) {
+        const int pos = atomicAdd(&cand_fill[img], 1);
+        if (pos < topn) cand[(size_t)img * topn + pos] = v;
+    }
+}
+
 constexpr int RANK_BLOCK = 256;
 constexpr int RANK_TILE = 1024;
 
 __global__ __launch_bounds__(RANK_BLOCK) void rank_topk_kernel(
-    const unsigned long long *__restrict__ keys, int M, int topn, int *__restrict__ rank_out,
-    int *__restrict__ sorted_index, int *__restrict__ n_sorted) {
+    const unsigned long long *__restrict__ cand, const int *__restrict__ n_cand, int topn,
+    int *__restrict__ sorted_index) {
     __shared__ unsigned long long tile[RANK_TILE];
     const int img = blockIdx.y;
-    const unsigned long long *k = keys + (size_t)img * M;
+    const int n = min(n_cand[img], topn);
+    if (blockIdx.x * RANK_BLOCK >= n) return;
+    const unsigned long long *k = cand + (size_t)img * topn;
     const int i = blockIdx.x * RANK_BLOCK + threadIdx.x;
-    const unsigned long long mine = (i < M) ? k[i] : 0ull;
+    const unsigned long long mine = (i < n) ? k[i] : ~0ull;
     int cnt = 0;
-    for (int j0 = 0; j0 < M; j0 += RANK_TILE) {
+    for (int j0 = 0; j0 < n; j0 += RANK_TILE) {
         __syncthreads();
         for (int t = threadIdx.x; t < RANK_TILE; t += RANK_BLOCK)
-            tile[t] = (j0 + t < M) ? k[j0 + t] : 0ull;
+            tile[t] = (j0 + t < n) ? k[j0 + t] : 0ull;
         __syncthreads();
-#pragma unroll 8
-        for (int t = 0; t < RANK_TILE; ++t) cnt += (tile[t] > mine) ? 1 : 0;
+        const int tn = min(RANK_TILE, n - j0);
+        int t = 0;
+        for (; t + 8 <= tn; t += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cnt += (tile[t + u] > mine) ? 1 : 0;
+        }
+        for (; t < tn; ++t) cnt += (tile[t] > mine) ? 1 : 0;
     }
-    if (i < M) {
-        if (rank_out) rank_out[(size_t)img * M + i] = (mine != 0ull) ? cnt : -1;
-        if (mine != 0ull && cnt < topn) sorted_index[(size_t)img * topn + cnt] = i;
-        // the element with the smallest valid key knows the number of valid keys
-        if (mine != 0ull) atomicMax(&n_sorted[img], min(cnt + 1, topn));
-    }
+    if (i < n) sorted_index[(size_t)img * topn + cnt] = (int)(unsigned)(mine & 0xffffffffull);
 }
 
-int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int topn, int *rank_out,
+int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int topn,
+                     unsigned long long *cand, unsigned long long *thresh, int *cand_fill,
                      int *sorted_index, int *n_sorted, hipStream_t st) {
-    // sorted_index must be pre-filled with -1 and n_sorted with 0 by the caller
-    hipLaunchKernelGGL(rank_topk_kernel, dim3(cdiv(M, RANK_BLOCK), n_images), dim3(RANK_BLOCK), 0,
-                       st, keys, M, topn, rank_out, sorted_index, n_sorted);
+    // sorted_index must be pre-filled with -1 and cand_fill with 0 by the caller
+    hipLaunchKernelGGL(topk_threshold_kernel, dim3(n_images), dim3(SEL_BLOCK), 0, st, keys, M, topn,
+                       thresh, n_sorted);
+    int rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(topk_compact_kernel, dim3(cdiv(M, 256), n_images), dim3(256), 0, st, keys, M,
+                       topn, thresh, cand, cand_fill);
+    if ((rc = check_launch())) return rc;
+    hipLaunchKernelGGL(rank_topk_kernel, dim3(cdiv(topn, RANK_BLOCK), n_images), dim3(RANK_BLOCK), 0,
+                       st, cand, n_sorted, topn, sorted_index);
     return check_launch();
 }
 
@@ -255,8 +338,8 @@ __global__ void nms_gather_kernel(const float *__restrict__ dets, const int *__r
 }
 
 struct NmsWs {
-    unsigned long long *keys, *mask;
-    int *order, *n_sorted;
+    unsigned long long *keys, *cand, *thresh, *mask;
+    int *order, *n_sorted, *cand_fill;
     float *boxes;
 };
 
@@ -265,8 +348,11 @@ static size_t carve_nms(void *ws, int n, NmsWs *out) {
     int ncb = cdiv(n, 64);
     NmsWs w;
     w.keys = c.take<unsigned long long>(n);
+    w.cand = c.take<unsigned long long>(n);
+    w.thresh = c.take<unsigned long long>(32);
     w.order = c.take<int>(n);
     w.n_sorted = c.take<int>(64);
+    w.cand_fill = c.take<int>(64);
     w.boxes = c.take<float>((size_t)n * 4);
     w.mask = c.take<unsigned long long>((size_t)n * ncb);
     if (out) *out = w;
@@ -296,12 +382,13 @@ extern "C" int wssdl_nms(const float *dets, int n, double thresh, int max_keep, 
     NmsWs w;
     carve_nms(workspace, n, &w);
     if (hipMemsetAsync(w.order, 0xff, sizeof(int) * (size_t)n, st) != hipSuccess ||
-        hipMemsetAsync(w.n_sorted, 0, sizeof(int), st) != hipSuccess)
+        hipMemsetAsync(w.n_sorted, 0, sizeof(int), st) != hipSuccess ||
+        hipMemsetAsync(w.cand_fill, 0, sizeof(int), st) != hipSuccess)
         return WSSDL_ERR_LAUNCH;
     hipLaunchKernelGGL(nms_prepare_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dets, n, w.keys);
     int rc = check_launch();
     if (rc) return rc;
-    rc = launch_rank_topk(w.keys, n, 1, n, nullptr, w.order, w.n_sorted, st);
+    rc = launch_rank_topk(w.keys, n, 1, n, w.cand, w.thresh, w.cand_fill, w.order, w.n_sorted, st);
     if (rc) return rc;
     hipLaunchKernelGGL(nms_gather_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dets, w.order,
                        w.n_sorted, n, w.boxes);

@@ -13,10 +13,12 @@ __host__ __device__ __forceinline__ unsigned long long score_key(float score, un
     return ((unsigned long long)u << 32) | (unsigned long long)idx;
 }
 
-// keys [n_images, M]; sorted_index [n_images, topn] (pre-filled with -1) receives
-// the index of the element at each descending-score position < topn; n_sorted
-// [n_images] (pre-zeroed) receives min(#valid, topn); rank_out optional [n_images, M].
-int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int topn, int *rank_out,
+// keys [n_images, M] (0 = not a candidate); sorted_index [n_images, topn] (pre-filled with -1)
+// receives the index (low key word) of the element at each descending-score position < topn;
+// n_sorted [n_images] receives min(#valid, topn).  Scratch: cand [n_images, topn] u64,
+// thresh [n_images] u64, cand_fill [n_images] i32 (pre-zeroed).
+int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int topn,
+                     unsigned long long *cand, unsigned long long *thresh, int *cand_fill,
                      int *sorted_index, int *n_sorted, hipStream_t st);
 
 // boxes: per image [n_max, 4] f32 in score order (image stride box_stride_img floats);

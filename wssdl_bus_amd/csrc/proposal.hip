@@ -97,9 +97,9 @@ __global__ __launch_bounds__(256) void proposal_compact_kernel(
 }
 
 struct ProposalWs {
-    unsigned long long *keys, *mask;
+    unsigned long long *keys, *cand, *thresh, *mask;
     float *boxes, *sorted_boxes;
-    int *sorted_index, *n_sorted;
+    int *sorted_index, *n_sorted, *cand_fill;
 };
 
 static size_t carve_proposal(void *ws, int N, int M, int topn, ProposalWs *out) {
@@ -110,6 +110,9 @@ static size_t carve_proposal(void *ws, int N, int M, int topn, ProposalWs *out) 
     w.boxes = c.take<float>((size_t)N * M * 4);
     w.sorted_index = c.take<int>((size_t)N * topn);
     w.n_sorted = c.take<int>((size_t)N + 64);
+    w.cand_fill = c.take<int>((size_t)N + 64);
+    w.thresh = c.take<unsigned long long>((size_t)N + 32);
+    w.cand = c.take<unsigned long long>((size_t)N * topn);
     w.sorted_boxes = c.take<float>((size_t)N * topn * 4);
     w.mask = c.take<unsigned long long>((size_t)N * topn * ncb);
     if (out) *out = w;
@@ -163,6 +166,7 @@ extern "C" int wssdl_proposal_layer(const float *rpn_cls_prob, const float *rpn_
 
     if (hipMemsetAsync(sidx, 0xff, sizeof(int) * (size_t)N * topn, st) != hipSuccess ||
         hipMemsetAsync(nsorted, 0, sizeof(int) * (size_t)N, st) != hipSuccess ||
+        hipMemsetAsync(w.cand_fill, 0, sizeof(int) * (size_t)N, st) != hipSuccess ||
         hipMemsetAsync(rois_padded, 0, sizeof(float) * (size_t)N * pitch * 5, st) != hipSuccess)
         return WSSDL_ERR_LAUNCH;
 
@@ -173,7 +177,8 @@ extern "C" int wssdl_proposal_layer(const float *rpn_cls_prob, const float *rpn_
                        rpn_bbox_pred, im_info, im_info_stride, N, H, W, base, A, feat_stride,
                        min_size, boxes, w.keys);
     if ((rc = check_launch())) return rc;
-    if ((rc = launch_rank_topk(w.keys, M, N, topn, nullptr, sidx, nsorted, st))) return rc;
+    if ((rc = launch_rank_topk(w.keys, M, N, topn, w.cand, w.thresh, w.cand_fill, sidx, nsorted, st)))
+        return rc;
     hipLaunchKernelGGL(proposal_gather_kernel, dim3(cdiv(topn, 256), N), dim3(256), 0, st, boxes,
                        sidx, nsorted, M, topn, w.sorted_boxes);
     if ((rc = check_launch())) return rc;
