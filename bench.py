@@ -154,7 +154,7 @@ def main():
     if ctx.world_size != args.gpus:
         if ctx.world_size == 1 and args.gpus > 1:
             sys.exit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(ctx.local_rank)
+    torch.cuda.set_device(ctx.local_rank % torch.cuda.device_count())
     wl = WORKLOADS[args.workload]
     cfg.TRAIN.IMS_PER_BATCH = wl["n_sup"]
     cfg.TRAIN.WS_IMS_PER_BATCH = wl["n_ws"]

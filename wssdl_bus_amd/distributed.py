@@ -24,10 +24,13 @@ class DistContext(object):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
+                # "nccl" IS RCCL on ROCm.  WSSDL_DIST_BACKEND=gloo lets the multi-rank code path
+                # be exercised with several ranks on one GPU (RCCL refuses duplicate devices).
+                backend = os.environ.get("WSSDL_DIST_BACKEND") or (
+                    "nccl" if torch.cuda.is_available() else "gloo")
             self.backend = backend
-            if backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
+            if torch.cuda.is_available():
+                torch.cuda.set_device(self.local_rank % torch.cuda.device_count())
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
 
     # ---- sharding: whole images per rank, no data-path collective ----
