@@ -1,0 +1,175 @@
+"""Edge cases and size-independent properties of the HIP path on a real MI355X (-m gpu):
+empty / degenerate inputs, duplicate boxes, batch independence, determinism, and one
+end-to-end train step of the mirrored network."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import c_oracle, np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+STRIDE = [16, ]
+SCALES = [8, 16, 32]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    from wssdl_bus_amd import _lib
+    _lib.lib()
+    return torch
+
+
+def test_roi_pool_empty_and_degenerate(torch_cuda):
+    from wssdl_bus_amd.roi_pooling_layer.roi_pooling_op import roi_pool, roi_pool_grad
+    rs = np.random.RandomState(0)
+    f = rs.normal(size=(2, 10, 12, 64)).astype(np.float32)
+    top, arg = roi_pool(f, np.zeros((0, 5), np.float32), 7, 7, 1.0 / 16)
+    assert top.shape == (0, 7, 7, 64) and arg.shape == (0, 7, 7, 64)
+    g = roi_pool_grad(f, np.zeros((0, 5), np.float32), arg, top, 7, 7, 1.0 / 16)
+    assert g.shape == f.shape and not g.any()                       # fully written, all zero
+    rois = np.array([[0, 500, 500, 600, 600],                       # entirely outside the 12x10 map
+                     [1, 0, 0, 0, 0],                               # single cell
+                     [0, 100, 60, 40, 20],                          # malformed: end < start
+                     [1, 0, 0, 191, 159]], np.float32)              # whole map
+    for mode in ("cuda", "cpu"):
+        et, ea = c_oracle.roi_pool_forward(f, rois, 7, 7, 1.0 / 16, mode)
+        top, arg = roi_pool(f, rois, 7, 7, 1.0 / 16, rounding=mode)
+        assert np.array_equal(top, et) and np.array_equal(arg, ea)
+        assert (arg[0] == -1).all() and (top[0] == 0).all()
+        d = rs.normal(size=top.shape).astype(np.float32)
+        want = c_oracle.roi_pool_backward(d, ea, rois, f.shape, 7, 7, 1.0 / 16, literal=True)
+        assert np.array_equal(roi_pool_grad(f, rois, arg, d, 7, 7, 1.0 / 16), want)
+    with pytest.raises(ValueError):
+        roi_pool(f[0], rois, 7, 7, 1.0 / 16)                        # "data must be 4-dimensional"
+    with pytest.raises(ValueError):
+        roi_pool(f, rois[:, :4], 7, 7, 1.0 / 16)
+
+
+def test_roi_pool_other_pooled_sizes(torch_cuda):
+    from wssdl_bus_amd.roi_pooling_layer.roi_pooling_op import roi_pool, roi_pool_grad
+    rs = np.random.RandomState(2)
+    f = np.maximum(rs.normal(size=(1, 20, 24, 32)), 0).astype(np.float32)
+    x1 = rs.uniform(0, 300, 40)
+    y1 = rs.uniform(0, 250, 40)
+    rois = np.stack([np.zeros(40), x1, y1, x1 + rs.uniform(8, 80, 40), y1 + rs.uniform(8, 70, 40)], 1).astype(np.float32)
+    for ph, pw, scale in ((6, 6, 1.0 / 3), (1, 1, 1.0 / 16), (14, 14, 1.0 / 16), (3, 11, 1.0 / 8)):
+        et, ea = c_oracle.roi_pool_forward(f, rois, ph, pw, scale, "cuda")
+        top, arg = roi_pool(f, rois, ph, pw, scale)
+        assert np.array_equal(top, et) and np.array_equal(arg, ea), (ph, pw)
+        d = rs.normal(size=top.shape).astype(np.float32)
+        want = c_oracle.roi_pool_backward(d, ea, rois, f.shape, ph, pw, scale)
+        assert np.array_equal(roi_pool_grad(f, rois, arg, d, ph, pw, scale), want), (ph, pw)   # incl. >8 bins per tile
+
+
+def test_nms_duplicates_and_idempotence(torch_cuda):
+    from wssdl_bus_amd.nms.hip_nms import hip_nms
+    d = np.tile(np.array([[10, 10, 50, 60]], np.float32), (200, 1))
+    dets = np.hstack((d, (np.arange(200)[:, None] / 200.0).astype(np.float32)))
+    assert hip_nms(dets, 0.7) == [199]                              # identical boxes: only the best survives
+    assert hip_nms(dets, 1.5) == list(range(199, -1, -1))           # threshold above 1: nothing suppressed
+    g = load_golden("nms")
+    dets = g["n6000/dets"]
+    keep = hip_nms(dets, 0.7)
+    assert keep == g["n6000/keep_07"].tolist()
+    kept = dets[keep]
+    assert hip_nms(kept, 0.7) == list(range(len(keep)))             # NMS of its own output keeps everything
+    ties = dets[:300].copy()
+    ties[:, 4] = 0.5                                                # documented tie rule: higher index first
+    k = hip_nms(ties, 0.7)
+    order = np.arange(299, -1, -1)
+    assert k == [int(order[i]) for i in c_oracle_keep(ties[order], 0.7)]
+
+
+def c_oracle_keep(dets_sorted, th):
+    # oracle NMS visiting the rows in the given order (scores made strictly decreasing)
+    d = dets_sorted.copy()
+    d[:, 4] = np.linspace(1.0, 0.5, len(d), dtype=np.float32)
+    return O.nms(d, th)
+
+
+def test_proposal_layer_batch_independence_and_properties(torch_cuda):
+    torch = torch_cuda
+    from wssdl_bus_amd.rpn_msr.proposal_layer_tf_bus import proposal_layer, proposal_layer_padded
+    g = load_golden("proposal_layer")
+    prob, pred, info = g["res_38x63_train/prob"], g["res_38x63_train/pred"], g["res_38x63_train/im_info"]
+    both = proposal_layer(prob, pred, info, True, False, STRIDE, SCALES)
+    for i in range(2):
+        single = proposal_layer(prob[i:i + 1], pred[i:i + 1], info[i:i + 1], True, False, STRIDE, SCALES)
+        sel = both[both[:, 0] == i]
+        assert np.array_equal(sel[:, 1:], single[:, 1:])           # an image's rois do not depend on its batch
+    # BASELINE config 3 size: 8 images in one call; invariants of the result
+    gen = torch.Generator("cuda").manual_seed(5)
+    N, H, W, A = 8, 38, 63, 9
+    p = torch.softmax(torch.randn((N, H, W, A, 2), device="cuda", generator=gen), -1)
+    prob8 = torch.cat((p[..., 0], p[..., 1]), -1).contiguous()
+    pred8 = 0.2 * torch.randn((N, H, W, 4 * A), device="cuda", generator=gen)
+    info8 = torch.tensor([[600, 1000, 1.0, 1]] * N, device="cuda")
+    rois, counts, dec, sidx, scnt = proposal_layer_padded(prob8, pred8, info8, True, STRIDE, SCALES, debug=True)
+    rois2, counts2 = proposal_layer_padded(prob8, pred8, info8, True, STRIDE, SCALES)
+    assert torch.equal(rois, rois2) and torch.equal(counts, counts2)      # deterministic
+    c = counts.cpu().numpy()
+    assert (c <= 2000).all() and (c > 0).all()
+    fg = prob8[..., A:].reshape(N, -1)
+    for i in range(N):
+        r = rois[i, :c[i]].cpu().numpy()
+        assert (r[:, 0] == i).all()
+        assert (r[:, 1] >= 0).all() and (r[:, 3] <= 999).all() and (r[:, 2] >= 0).all() and (r[:, 4] <= 599).all()
+        assert ((r[:, 3] - r[:, 1] + 1) >= 16).all() and ((r[:, 4] - r[:, 2] + 1) >= 16).all()
+        n = int(scnt[i])
+        s = fg[i][sidx[i, :n].long()].cpu().numpy()
+        assert (np.diff(s) <= 0).all()                               # candidates in descending score order
+        assert not rois[i, c[i]:].any()
+
+
+def test_anchor_target_no_positive_gt_is_all_ignore(torch_cuda):
+    # the reference raises here (argmax over an empty axis); this implementation returns
+    # all-ignore labels and zero targets instead of launching with an invalid index
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.rpn_msr.anchor_target_layer_tf_bus import anchor_target_layer
+    gt = np.zeros((1, 20, 5), np.float32)
+    gt[0, 0] = [100, 100, 300, 300, 0]                                # background box only
+    cfg.SAMPLING_RNG = "reference"
+    lab, tg, inw, outw = anchor_target_layer(np.zeros((1, 38, 63, 18), np.float32), gt, np.array([1], np.int32),
+                                             np.array([[600, 1000, 1, 1]], np.float32), None, STRIDE, SCALES,
+                                             "SNUBH", rng=np.random.RandomState(0))
+    assert (lab != 1).all() and not tg.any() and not inw.any()
+
+
+def test_network_train_step_end_to_end(torch_cuda):
+    torch = torch_cuda
+    from wssdl_bus_amd import synthetic
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.fast_rcnn.train_bus import SolverWrapper
+    from wssdl_bus_amd.networks.factory_bus import get_network
+    cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.WS_IMS_PER_BATCH = 1, 1
+    cfg.SAMPLING_RNG = "reference"
+    np.random.seed(3)
+    torch.manual_seed(3)
+    try:
+        net = get_network("Resnet_train", 18).cuda().to(memory_format=torch.channels_last)
+        blobs = synthetic.make_batch(1, 1, 320, 480, seed=3)
+        solver = SolverWrapper(net)
+        losses = solver.train_step_joint(blobs)
+        L = net.layers
+        assert L["rpn-data"][0].dtype == torch.int32 and L["rpn-data"][0].shape == (2, 1, 9 * 20, 30)
+        assert L["roi-data"][1].dtype == torch.int32
+        n_sup = L["roi-data"][1].shape[0]
+        assert L["roi-data"][0].shape[0] == L["cls_score"].shape[0] >= n_sup
+        assert (L["roi-data"][0][n_sup:, 0] == 1).all()             # weak image's rois follow the sampled rows
+        for k in ("loss", "mil_cross_entropy", "rpn_cross_entropy", "rpn_loss_box", "cross_entropy", "loss_box"):
+            assert torch.isfinite(losses[k]).all(), k
+        before = float(losses["loss"])
+        for _ in range(3):
+            losses = solver.train_step_joint(blobs)
+        assert torch.isfinite(losses["loss"]) and solver.global_step == 4
+        # alternating network: supervised + weak step
+        net2 = get_network("Resnet_train_alter", 18).cuda().to(memory_format=torch.channels_last)
+        s2 = SolverWrapper(net2)
+        out = s2.train_step_alter(synthetic.make_batch(1, 0, 320, 480, seed=4), synthetic.make_batch(0, 2, 320, 480, seed=5))
+        assert torch.isfinite(out["loss"]) and torch.isfinite(out["mil_cross_entropy"]) and s2.global_step == 2
+        assert before > 0
+    finally:
+        cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.WS_IMS_PER_BATCH = 1, 2

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(AT_BLOCK) void anchor_label_kernel(
         if (b.inside) {
             double best = 0.0;
             bool hit = false;
-            arg = 0;
+            arg = (s.n_ov > 0) ? 0 : -1;      // no positive gt: the reference raises; we emit no target
             for (int k = 0; k < s.n_ov; ++k) {
                 double ov = iou_f64(b, s, k);
                 if (k == 0 || ov > best) { best = ov; arg = k; }   // numpy argmax: first maximum
