@@ -212,6 +212,21 @@ def main():
     elapsed = ctx.max_over_ranks(elapsed)
     loss_val = float(out["loss"].detach()) if isinstance(out, dict) and torch.is_tensor(out.get("loss")) else None
 
+    def measured_copy_gbps():
+        # device-to-device copy of 1 GiB (read + write counted), the practical HBM ceiling
+        # to read `roofline.frac` against
+        a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(5):
+            b.copy_(a)
+        e.record()
+        torch.cuda.synchronize()
+        return 5 * 2 * a.numel() * 4 / (s.elapsed_time(e) * 1e-3) / 1e9
+
     if ctx.rank == 0:
         tl = _lib.timeline.summary()
         hot_ms = sum(d["total_ms"] for d in tl.values()) / max(args.steps, 1)
@@ -228,8 +243,19 @@ def main():
             d = tl[dom]
             byt = sum(alg_bytes(dom, m) for m in d["metas"]) / d["calls"]
             ach = byt / (d["avg_ms"] * 1e-3) / 1e9
+            # PMC traffic cannot be collected inside this process; tools/profile_round.sh runs the
+            # FETCH_SIZE / WRITE_SIZE passes of this same command and commits the per-launch means
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "hotpath_traffic.json")
+            kname = {"roi_pool_forward": "roi_pool_fwd", "roi_pool_backward": "roi_pool_bwd"}.get(dom)
+            if kname and os.path.exists(tpath) and args.workload == "resnet50_joint_b8":
+                tj = json.load(open(tpath))
+                for k, v in tj.get("kernels", {}).items():
+                    if kname in k:
+                        traffic, traffic_src = int(v["hbm_bytes_per_launch"]), "profiles/hotpath_traffic.json"
             roofline = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBPS, 4), traffic=None,
+                            frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_src,
+                            measured_d2d_copy=round(measured_copy_gbps(), 1),
                             avg_launch_ms=round(d["avg_ms"], 4), alg_bytes_per_launch=int(byt),
                             launches=d["calls"],
                             per_kernel={k: dict(avg_ms=round(v["avg_ms"], 4), calls=v["calls"],

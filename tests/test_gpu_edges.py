@@ -173,3 +173,59 @@ def test_network_train_step_end_to_end(torch_cuda):
         assert before > 0
     finally:
         cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.WS_IMS_PER_BATCH = 1, 2
+
+
+def test_post_detection_nms_matches_oracle(torch_cuda):
+    """f3: per-class NMS + max_per_image cap (test_bus.py:360-401) against the NumPy formulas."""
+    torch = torch_cuda
+    from wssdl_bus_amd.fast_rcnn.bbox_transform import bbox_transform_inv
+    from wssdl_bus_amd.fast_rcnn.test_bus import _clip_boxes, postprocess_detections
+    rs = np.random.RandomState(7)
+    R, K = 300, 3
+    ctr = rs.uniform(50, 700, size=(R, 2)) * [1.0, 0.6]
+    wh = rs.uniform(30, 200, size=(R, 2))
+    boxes = np.hstack((ctr - wh / 2, ctr + wh / 2)).astype(np.float32)
+    deltas = rs.normal(0, 0.1, size=(R, 4 * K)).astype(np.float32)
+    logits = rs.normal(0, 2, size=(R, K)).astype(np.float32)
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    scores = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    pred = _clip_boxes(bbox_transform_inv(torch.from_numpy(boxes).cuda(), torch.from_numpy(deltas).cuda()), (480, 760))
+    # oracle decode (K classes): same formulas per class
+    want_pred = np.zeros_like(deltas)
+    for j in range(K):
+        want_pred[:, 4 * j:4 * j + 4] = O.bbox_transform_inv(boxes.astype(np.float64), deltas[:, 4 * j:4 * j + 4])
+    want_pred[:, 0::4] = np.maximum(want_pred[:, 0::4], 0)
+    want_pred[:, 1::4] = np.maximum(want_pred[:, 1::4], 0)
+    want_pred[:, 2::4] = np.minimum(want_pred[:, 2::4], 759)
+    want_pred[:, 3::4] = np.minimum(want_pred[:, 3::4], 479)
+    assert np.allclose(pred.cpu().numpy(), want_pred, rtol=1e-5, atol=1e-3)
+    got = postprocess_detections(torch.from_numpy(scores).cuda(), pred, K, thresh=0.05, max_per_image=40)
+    p = pred.cpu().numpy()
+    want = {}
+    for j in range(1, K):
+        inds = np.where(scores[:, j] > 0.05)[0]
+        d = np.hstack((p[inds, 4 * j:4 * j + 4], scores[inds, j:j + 1])).astype(np.float32)
+        want[j] = d[O.nms(d, 0.3)]
+    alls = np.hstack([want[j][:, 4] for j in range(1, K)])
+    if len(alls) > 40:
+        th = np.sort(alls)[-40]
+        for j in range(1, K):
+            want[j] = want[j][want[j][:, 4] >= th]
+    for j in range(1, K):
+        assert np.array_equal(got[j].cpu().numpy(), want[j]), j
+    assert sum(len(want[j]) for j in want) <= 40 + 2
+
+
+def test_im_detect_runs(torch_cuda):
+    torch = torch_cuda
+    from wssdl_bus_amd import synthetic
+    from wssdl_bus_amd.fast_rcnn.test_bus import im_detect, postprocess_detections
+    from wssdl_bus_amd.networks.factory_bus import get_network
+    torch.manual_seed(1)
+    net = get_network("Resnet_train", 18).cuda().to(memory_format=torch.channels_last)
+    blobs = synthetic.make_batch(1, 0, 320, 480, seed=9)
+    scores, boxes = im_detect(net, blobs["data"], blobs["im_info"])
+    assert scores.shape[0] == boxes.shape[0] <= 300 and scores.shape[1] == 3 and boxes.shape[1] == 12
+    assert torch.allclose(scores.sum(1), torch.ones_like(scores[:, 0]), atol=1e-5)
+    dets = postprocess_detections(scores, boxes, 3, thresh=0.0, max_per_image=50)
+    assert sum(d.shape[0] for d in dets.values()) <= 52

@@ -13,4 +13,5 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_su
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$name -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/pmc_$name.log 2>&1
 done
 tail -3 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log; tail -1 $OUT/bench.log | cut -c1-600
-python3 tools/pmc_summary.py $OUT roi_pool | sort
+python3 tools/pmc_summary.py $OUT wssdl | sort > $OUT/pmc_hotpath.txt
+python3 tools/traffic_json.py $OUT $OUT/hotpath_traffic.json

@@ -54,6 +54,9 @@ __C.TRAIN.RPN_BBOX_INSIDE_WEIGHTS = (1.0, 1.0, 1.0, 1.0)   # :214
 __C.TRAIN.RPN_POSITIVE_WEIGHT = -1.0                # :218
 
 __C.TEST = AttrDict()
+__C.TEST.NMS = 0.3                                  # :238
+__C.TEST.CLS_AGNOSTIC_NMS = False                   # :241
+__C.TEST.BBOX_REG = True                            # :248
 __C.TEST.RPN_NMS_THRESH = 0.7                       # :257
 __C.TEST.RPN_PRE_NMS_TOP_N = 6000                   # :259
 __C.TEST.RPN_POST_NMS_TOP_N = 300                   # :262
