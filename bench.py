@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--sampling-rng", default="device", choices=["device", "reference"],
                     help="anchor sub-sampling RNG: 'device' (no host round trip) or the reference's numpy stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused-rpn-softmax", action="store_true",
+                    help="f2: fuse reshape->softmax->reshape into the proposal decode kernel")
     args = ap.parse_args()
 
     import numpy as np
@@ -159,6 +161,7 @@ def main():
     cfg.TRAIN.IMS_PER_BATCH = wl["n_sup"]
     cfg.TRAIN.WS_IMS_PER_BATCH = wl["n_ws"]
     cfg.SAMPLING_RNG = args.sampling_rng
+    cfg.FUSED_RPN_SOFTMAX = bool(args.fused_rpn_softmax)
     seed = ctx.seed(cfg.RNG_SEED)
     np.random.seed(seed)
     torch.manual_seed(seed)

@@ -119,6 +119,17 @@ WSSDL_API int wssdl_proposal_layer(const float *rpn_cls_prob, const float *rpn_b
                          float *rois_padded, int32_t *roi_counts,
                          float *decoded, int32_t *sorted_index, int32_t *sorted_count,
                          void *workspace, size_t workspace_bytes, wssdl_stream_t stream);
+/* f2: the same layer fed with the raw RPN class scores rpn_cls_score [N,H,W,2A] (logits):
+ * the reshape -> softmax -> reshape chain in front of the layer (networks/network.py:283-291,
+ * 398-404, Resnet_train_bus.py:76-81) is fused into the decode kernel: the fg probability of
+ * anchor a is softmax(score[a], score[A+a])[1]. */
+WSSDL_API int wssdl_proposal_layer_from_logits(const float *rpn_cls_score, const float *rpn_bbox_pred,
+                         const float *im_info, int im_info_stride, int N, int H, int W,
+                         const double *base_anchors_host, int A, int feat_stride,
+                         int pre_nms_topN, int post_nms_topN, double nms_thresh, float min_size,
+                         float *rois_padded, int32_t *roi_counts,
+                         float *decoded, int32_t *sorted_index, int32_t *sorted_count,
+                         void *workspace, size_t workspace_bytes, wssdl_stream_t stream);
 /* gathers the per-image lists into the reference's contiguous blob [sum counts, 5]
  * (proposal_layer_tf_bus.py:144-146).  total_host must equal sum(roi_counts). */
 WSSDL_API int wssdl_proposal_compact(const float *rois_padded, const int32_t *roi_counts, int N,
@@ -196,6 +207,21 @@ WSSDL_API int wssdl_roi_pool_forward(const float *bottom, int N, int H, int W, i
 WSSDL_API int wssdl_roi_pool_backward(const float *top_diff, const int32_t *argmax, const float *rois,
                             int R, int N, int H, int W, int C, int pooled_h, int pooled_w,
                             float spatial_scale, float *bottom_diff, wssdl_stream_t stream);
+
+/* ---------------------------------------------------------------------- f1 ---
+ * MIL bag-instance selection: mil/core.py:11-46 (get_bag_logit) with the selectors
+ * get_mal_max_logit :60-69, get_ben_max_logit :49-57, get_mass_max_logit :88-96.
+ * instance_logits [R,num_classes] f32; the bag of row r is (int)(bag_of_row[r*bag_stride] -
+ * bag_offset) (e.g. the batch-index column of the rois blob minus IMS_PER_BATCH,
+ * fast_rcnn/train_bus.py:653); bag_labels [n_bags] i32.  Bags labelled 1 use selector_label1,
+ * the others selector_other (train_bus.py:241,655).  row_out [n_bags] i32 receives the row to
+ * gather (first extremum; -1 for an empty bag), count_out (optional) the instances per bag. */
+enum wssdl_mil_selector { WSSDL_MIL_MAL_MAX = 0, WSSDL_MIL_BEN_MAX = 1, WSSDL_MIL_MASS_MAX = 2 };
+WSSDL_API int wssdl_mil_select(const float *instance_logits, int R, int num_classes,
+                     const float *bag_of_row, int bag_stride, float bag_offset,
+                     const int32_t *bag_labels, int n_bags, int selector_label1,
+                     int selector_other, int32_t *row_out, int32_t *count_out,
+                     wssdl_stream_t stream);
 
 #ifdef __cplusplus
 }

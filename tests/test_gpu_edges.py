@@ -229,3 +229,46 @@ def test_im_detect_runs(torch_cuda):
     assert torch.allclose(scores.sum(1), torch.ones_like(scores[:, 0]), atol=1e-5)
     dets = postprocess_detections(scores, boxes, 3, thresh=0.0, max_per_image=50)
     assert sum(d.shape[0] for d in dets.values()) <= 52
+
+
+def test_mil_select_device_matches_host_restatement(torch_cuda):
+    """f1: the HIP bag-selection op against the host restatement of mil/core.py:11-96."""
+    torch = torch_cuda
+    from wssdl_bus_amd.mil import core as M
+    g = torch.Generator("cuda").manual_seed(3)
+    counts = [2000, 1, 1737, 300]
+    R = sum(counts)
+    logits = torch.randn((R, 3), device="cuda", generator=g).requires_grad_(True)
+    logits.data[5] = logits.data[2]                       # duplicated rows: the first extremum must win
+    logits.data[2050] = logits.data[2040]
+    rois = torch.zeros((R, 5), device="cuda")
+    rois[:, 0] = torch.repeat_interleave(torch.arange(4, device="cuda"), torch.tensor(counts, device="cuda")) + 3.0
+    labels = torch.tensor([1, 2, 1, 2], dtype=torch.int32, device="cuda")
+    for funcs in ([M.get_mal_max_logit, M.get_mal_max_logit], [M.get_mass_max_logit, M.get_mal_max_logit],
+                  [M.get_ben_max_logit, M.get_mass_max_logit]):
+        want, wscale = M.get_bag_logit(logits, rois[:, 0] - 3, 3, labels, 4, funcs)
+        got, gscale = M.get_bag_logit_device(logits, rois[:, 0], 3.0, labels, 4, funcs)   # strided column
+        assert torch.equal(got, want) and torch.allclose(gscale, wscale)
+    got.sum().backward()                                  # differentiable gather
+    assert logits.grad is not None and int((logits.grad != 0).any(dim=1).sum()) == 4
+
+
+def test_proposal_layer_from_logits_matches_softmax_path(torch_cuda):
+    """f2: the fused reshape->softmax->reshape + proposal layer against the unfused chain."""
+    torch = torch_cuda
+    from wssdl_bus_amd.networks.network import Network
+    from wssdl_bus_amd.rpn_msr.proposal_layer_tf_bus import proposal_layer, proposal_layer_from_score
+    gen = torch.Generator("cuda").manual_seed(11)
+    N, H, W, A = 2, 38, 63, 9
+    score = torch.randn((N, H, W, 2 * A), device="cuda", generator=gen)
+    pred = 0.2 * torch.randn((N, H, W, 4 * A), device="cuda", generator=gen)
+    info = torch.tensor([[600, 1000, 1.0, 1], [584, 1000, 2.0, 2]], device="cuda")
+    net = Network({'rpn_cls_score': score})
+    (net.feed('rpn_cls_score').reshape_layer(2, name='rpn_cls_score_reshape').softmax(name='rpn_cls_prob')
+        .reshape_layer(2 * A, name='rpn_cls_prob_reshape'))
+    ref = proposal_layer(net.get_output('rpn_cls_prob_reshape').contiguous(), pred, info, True, False)
+    got = proposal_layer_from_score(score, pred, info, True, False)
+    assert abs(ref.shape[0] - got.shape[0]) <= 4
+    m = min(ref.shape[0], got.shape[0])
+    same = (ref[:m] - got[:m]).abs().amax(dim=1) <= 1e-3
+    assert same.float().mean().item() >= 0.99          # softmax differs by an ulp between the two paths

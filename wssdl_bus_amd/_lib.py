@@ -33,6 +33,8 @@ SYMBOLS = {
     "wssdl_proposal_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "wssdl_proposal_layer": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _d, _f,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "wssdl_proposal_layer_from_logits": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _d, _f,
+                                              _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "wssdl_proposal_compact": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp]),
     "wssdl_anchor_workspace_bytes": (_sz, [_i]),
     "wssdl_anchor_labels": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _d, _d, _i,
@@ -45,6 +47,7 @@ SYMBOLS = {
                                _vp]),
     "wssdl_roi_pool_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "wssdl_roi_pool_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "wssdl_mil_select": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -22,7 +22,7 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void proposal_decode_kernel(
     const float *__restrict__ prob, const float *__restrict__ pred,
     const float *__restrict__ im_info, int info_stride, int N, int H, int W, BaseAnchors base,
-    int A, int stride, float min_size, float *__restrict__ boxes,
+    int A, int stride, float min_size, int from_logits, float *__restrict__ boxes,
     unsigned long long *__restrict__ keys) {
     const int M = H * W * A;
     const long long total = (long long)N * M;
@@ -37,7 +37,15 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(
         const float im_scale = im_info[n * info_stride + 2];
         const size_t cbase = (size_t)n * H * W + cell;
         // fg probability: channels A..2A-1 (proposal_layer_tf_bus.py:86)
-        const float score = prob[cbase * (2 * A) + A + a];
+        float score = prob[cbase * (2 * A) + A + a];
+        if (from_logits) {
+            // fused reshape -> softmax -> reshape (network.py:283-291,398-404): the pair of anchor
+            // a is (score[a], score[A+a]); softmax as exp(x - max) / sum like TF's kernel
+            const float bg = prob[cbase * (2 * A) + a];
+            const float mx = fmaxf(bg, score);
+            const float e0 = (float)exp((double)(bg - mx)), e1 = (float)exp((double)(score - mx));
+            score = e1 / (e0 + e1);
+        }
         const float4v d = *reinterpret_cast<const float4v *>(pred + (cbase * A + a) * 4);
         // anchors are integer-valued doubles cast to f32 (bbox_transform.py:34)
         const float ax1 = (float)(base.v[a][0] + (double)(stride * w));
@@ -134,7 +142,7 @@ extern "C" size_t wssdl_proposal_workspace_bytes(int N, int H, int W, int A, int
     return carve_proposal(nullptr, N, M, effective_topn(pre_nms_topN, M), nullptr);
 }
 
-extern "C" int wssdl_proposal_layer(const float *rpn_cls_prob, const float *rpn_bbox_pred,
+static int proposal_layer_impl(int from_logits, const float *rpn_cls_prob, const float *rpn_bbox_pred,
                                     const float *im_info, int im_info_stride, int N, int H, int W,
                                     const double *base_anchors_host, int A, int feat_stride,
                                     int pre_nms_topN, int post_nms_topN, double nms_thresh,
@@ -175,7 +183,7 @@ extern "C" int wssdl_proposal_layer(const float *rpn_cls_prob, const float *rpn_
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(proposal_decode_kernel, dim3(blocks), dim3(256), 0, st, rpn_cls_prob,
                        rpn_bbox_pred, im_info, im_info_stride, N, H, W, base, A, feat_stride,
-                       min_size, boxes, w.keys);
+                       min_size, from_logits, boxes, w.keys);
     if ((rc = check_launch())) return rc;
     if ((rc = launch_rank_topk(w.keys, M, N, topn, w.cand, w.thresh, w.cand_fill, sidx, nsorted, st)))
         return rc;
@@ -198,6 +206,32 @@ extern "C" int wssdl_proposal_layer(const float *rpn_cls_prob, const float *rpn_
                        st) != hipSuccess)
         return WSSDL_ERR_LAUNCH;
     return WSSDL_OK;
+}
+
+extern "C" int wssdl_proposal_layer(const float *rpn_cls_prob, const float *rpn_bbox_pred,
+                                    const float *im_info, int im_info_stride, int N, int H, int W,
+                                    const double *base_anchors_host, int A, int feat_stride,
+                                    int pre_nms_topN, int post_nms_topN, double nms_thresh,
+                                    float min_size, float *rois_padded, int32_t *roi_counts,
+                                    float *decoded, int32_t *sorted_index, int32_t *sorted_count,
+                                    void *workspace, size_t workspace_bytes,
+                                    wssdl_stream_t stream) {
+    return proposal_layer_impl(0, rpn_cls_prob, rpn_bbox_pred, im_info, im_info_stride, N, H, W,
+                               base_anchors_host, A, feat_stride, pre_nms_topN, post_nms_topN,
+                               nms_thresh, min_size, rois_padded, roi_counts, decoded, sorted_index,
+                               sorted_count, workspace, workspace_bytes, stream);
+}
+
+extern "C" int wssdl_proposal_layer_from_logits(
+    const float *rpn_cls_score, const float *rpn_bbox_pred, const float *im_info,
+    int im_info_stride, int N, int H, int W, const double *base_anchors_host, int A,
+    int feat_stride, int pre_nms_topN, int post_nms_topN, double nms_thresh, float min_size,
+    float *rois_padded, int32_t *roi_counts, float *decoded, int32_t *sorted_index,
+    int32_t *sorted_count, void *workspace, size_t workspace_bytes, wssdl_stream_t stream) {
+    return proposal_layer_impl(1, rpn_cls_score, rpn_bbox_pred, im_info, im_info_stride, N, H, W,
+                               base_anchors_host, A, feat_stride, pre_nms_topN, post_nms_topN,
+                               nms_thresh, min_size, rois_padded, roi_counts, decoded, sorted_index,
+                               sorted_count, workspace, workspace_bytes, stream);
 }
 
 extern "C" int wssdl_proposal_compact(const float *rois_padded, const int32_t *roi_counts, int N,

@@ -73,6 +73,9 @@ __C.USE_GPU_NMS = False                             # :321 (kept for API parity;
 # 'device'   : counter-based hash sampling on the GPU (no host sync; same distribution).
 __C.SAMPLING_RNG = "reference"
 __C.DEVICE_RNG_SEED = 3
+# f2: feed the proposal layer with the raw rpn_cls_score and fuse reshape -> softmax -> reshape
+# into its decode kernel (the 'rpn_cls_prob*' layers are then not materialised)
+__C.FUSED_RPN_SOFTMAX = False
 # RoI-pool bin rounding: 'cuda' (canonical, roi_pooling_op_gpu.cu.cc:51-58) or
 # 'cpu' (roi_pooling_op.cc:167-170)
 __C.ROI_POOL_ROUNDING = "cuda"

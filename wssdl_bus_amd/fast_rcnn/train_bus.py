@@ -54,9 +54,15 @@ def rcnn_box_loss(bbox_pred, roi_data):
 
 def mil_loss(cls_score_ws, batch_inds, mil_label, n_bags, global_step, funcs, counts_host=None):
     """train_bus.py:239-260 / :650-671: bag logits -> CE weighted by the class prior
-    [0, WS_MAL_PCT, 1-WS_MAL_PCT] and by 1 - 0.99*0.9^floor(step/2000) (or a constant)."""
-    bag_logits, _ = mil_core.get_bag_logit(cls_score_ws, batch_inds, 3, mil_label, n_bags, funcs,
-                                           counts_host)
+    [0, WS_MAL_PCT, 1-WS_MAL_PCT] and by 1 - 0.99*0.9^floor(step/2000) (or a constant).
+    On the GPU the bag selection is the HIP op (no host round trip); on CPU tensors (tests) the
+    host-side restatement of mil/core.py runs."""
+    if cls_score_ws.is_cuda:
+        bag_logits, _ = mil_core.get_bag_logit_device(cls_score_ws, batch_inds, 0.0, mil_label,
+                                                      n_bags, funcs)
+    else:
+        bag_logits, _ = mil_core.get_bag_logit(cls_score_ws, batch_inds, 3, mil_label, n_bags,
+                                               funcs, counts_host)
     label = mil_label.reshape(-1).to(torch.int64)
     w = torch.tensor([0.0, cfg.TRAIN.WS_MAL_PCT, 1 - cfg.TRAIN.WS_MAL_PCT],
                      dtype=bag_logits.dtype, device=bag_logits.device)[label]

@@ -50,3 +50,33 @@ def get_bag_logit(instance_logits, batch_inds, num_classes, bag_labels, batch_si
         rows.append(row)
         scales.append(torch.softmax(row, dim=1)[0, int(labels_host[i])])
     return torch.cat(rows, dim=0), torch.stack(scales)
+
+
+# ------------------------------------------------------------------ device op (f1) ---
+_SELECTORS = {get_mal_max_logit: 0, get_ben_max_logit: 1, get_mass_max_logit: 2}
+
+
+def get_bag_logit_device(instance_logits, bag_column, bag_offset, bag_labels, batch_size, funcs):
+    """get_bag_logit as ONE kernel launch + one gather, with no host round trip: the HIP op
+    ``wssdl_mil_select`` picks each bag's instance row, ``index_select`` (differentiable) gathers
+    the logit rows.  `bag_column` is the column holding each instance's bag index plus
+    `bag_offset` (a strided view such as ``rois[n_valid:, 0]`` is fine).  Returns
+    (bag_logits [batch_size, K], scale_factors [batch_size]) like get_bag_logit."""
+    from .. import _lib
+    logits = instance_logits.contiguous()
+    R, K = logits.shape
+    col = bag_column if bag_column.dtype == torch.float32 else bag_column.to(torch.float32)
+    stride = col.stride(0) if col.dim() == 1 and R > 1 else 1
+    if col.dim() != 1 or (R > 1 and stride < 1):
+        col = col.reshape(-1).contiguous()
+        stride = 1
+    labels = bag_labels.reshape(-1).to(torch.int32).contiguous()
+    rows = torch.empty((batch_size,), dtype=torch.int32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        _lib.check(_lib.lib().wssdl_mil_select(
+            _lib.ptr(logits), R, K, _lib.ptr(col), int(stride), float(bag_offset), _lib.ptr(labels),
+            int(batch_size), _SELECTORS[funcs[0]], _SELECTORS[funcs[1]], _lib.ptr(rows), None,
+            _lib.stream()), "wssdl_mil_select")
+    bag_logits = instance_logits.index_select(0, rows.to(torch.int64))
+    scale = torch.softmax(bag_logits, dim=1).gather(1, labels.to(torch.int64).unsqueeze(1)).squeeze(1)
+    return bag_logits, scale

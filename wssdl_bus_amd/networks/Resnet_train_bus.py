@@ -8,6 +8,8 @@ hot-path nodes are the ``Network`` layer methods backed by the HIP library.
 import torch
 import torch.nn as nn
 
+from ..fast_rcnn.config import cfg
+
 from .backbones import RESNET_DEFS, Conv, ResNetTrunk
 from .roi_head import ConvNHWC, ResNetHeadNHWC
 from .network import Network
@@ -62,12 +64,17 @@ class Resnet_train_bus(nn.Module, Network):
                      .anchor_target_layer_joint(_feat_stride, anchor_scales, self.dataset, is_training,
                                                 name='rpn-data'))
         (self.feed('rpn_cls_score')
-             .reshape_layer(2, name='rpn_cls_score_reshape')
-             .softmax(name='rpn_cls_prob'))
-        (self.feed('rpn_cls_prob')
-             .reshape_layer(len(anchor_scales) * 3 * 2, name='rpn_cls_prob_reshape'))
-        (self.feed('rpn_cls_prob_reshape', 'rpn_bbox_pred', 'im_info')
-             .proposal_layer(_feat_stride, anchor_scales, is_training, is_ws, name='rpn_rois'))
+             .reshape_layer(2, name='rpn_cls_score_reshape'))
+        if cfg.FUSED_RPN_SOFTMAX:
+            (self.feed('rpn_cls_score', 'rpn_bbox_pred', 'im_info')
+                 .proposal_layer_from_score(_feat_stride, anchor_scales, is_training, is_ws, name='rpn_rois'))
+        else:
+            (self.feed('rpn_cls_score_reshape')
+                 .softmax(name='rpn_cls_prob'))
+            (self.feed('rpn_cls_prob')
+                 .reshape_layer(len(anchor_scales) * 3 * 2, name='rpn_cls_prob_reshape'))
+            (self.feed('rpn_cls_prob_reshape', 'rpn_bbox_pred', 'im_info')
+                 .proposal_layer(_feat_stride, anchor_scales, is_training, is_ws, name='rpn_rois'))
         if test_net:
             # Resnet_test_bus.py:60-64 wiring of the test network: proposals feed RoI pooling directly
             self.layers['roi-data'] = self.layers['rpn_rois']

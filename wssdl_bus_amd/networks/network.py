@@ -12,7 +12,8 @@ from ..roi_pooling_layer import roi_pooling_op as roi_pool_op
 from ..rpn_msr.anchor_target_layer_tf_bus import (anchor_target_layer as anchor_target_layer_py,
                                                   anchor_target_layer_joint as anchor_target_layer_joint_py,
                                                   anchor_target_layer_ws as anchor_target_layer_ws_py)
-from ..rpn_msr.proposal_layer_tf_bus import proposal_layer as proposal_layer_py
+from ..rpn_msr.proposal_layer_tf_bus import (proposal_layer as proposal_layer_py,
+                                             proposal_layer_from_score as proposal_layer_from_score_py)
 from ..rpn_msr.proposal_target_layer_tf_bus import (proposal_target_layer as proposal_target_layer_py,
                                                     proposal_target_layer_joint as proposal_target_layer_joint_py)
 
@@ -81,6 +82,14 @@ class Network(object):
         with torch.no_grad():
             out = proposal_layer_py(_first(input[0]).detach(), input[1].detach(), input[2],
                                     is_training, is_ws, _feat_stride, anchor_scales)
+        return out.reshape(-1, 5)
+
+    @layer
+    def proposal_layer_from_score(self, input, _feat_stride, anchor_scales, is_training, is_ws, name):
+        """f2 variant of proposal_layer: input[0] is the raw rpn_cls_score."""
+        with torch.no_grad():
+            out = proposal_layer_from_score_py(_first(input[0]).detach(), input[1].detach(), input[2],
+                                               is_training, is_ws, _feat_stride, anchor_scales)
         return out.reshape(-1, 5)
 
     @layer

@@ -22,7 +22,8 @@ def _rpn_params(is_training):
 
 
 def proposal_layer_padded(rpn_cls_prob_reshape, rpn_bbox_pred, im_info, is_training,
-                          _feat_stride=[16, ], anchor_scales=[8, 16, 32], debug=False):
+                          _feat_stride=[16, ], anchor_scales=[8, 16, 32], debug=False,
+                          from_logits=False):
     """Device-resident form: returns (rois_padded [N, post_nms_topN, 5], counts [N] i32)
     without any host synchronisation (+ decoded / sorted_index / sorted_count when
     `debug`)."""
@@ -56,7 +57,8 @@ def proposal_layer_padded(rpn_cls_prob_reshape, rpn_bbox_pred, im_info, is_train
             sidx = torch.empty((N, topn), dtype=torch.int32, device=dev)
             scnt = torch.empty((N,), dtype=torch.int32, device=dev)
         with _lib.timed("proposal_layer", dict(N=N, H=H, W=W, A=A, pre=topn, post=pitch)):
-          _lib.check(L.wssdl_proposal_layer(
+          fn = L.wssdl_proposal_layer_from_logits if from_logits else L.wssdl_proposal_layer
+          _lib.check(fn(
             _lib.ptr(prob), _lib.ptr(pred), _lib.ptr(info), info.shape[1], N, H, W,
             _lib.host_ptr(anchors), A, stride, int(pre), int(post), float(thresh),
             float(min_size), _lib.ptr(rois), _lib.ptr(counts), _lib.ptr(dec), _lib.ptr(sidx),
@@ -88,5 +90,17 @@ def proposal_layer(rpn_cls_prob_reshape, rpn_bbox_pred, im_info, is_training, is
     as_np = _lib.wants_numpy(rpn_cls_prob_reshape, rpn_bbox_pred, im_info)
     rois, counts = proposal_layer_padded(rpn_cls_prob_reshape, rpn_bbox_pred, im_info,
                                          is_training, _feat_stride, anchor_scales)
+    blob = compact_rois(rois, counts)
+    return blob.cpu().numpy() if as_np else blob
+
+
+def proposal_layer_from_score(rpn_cls_score, rpn_bbox_pred, im_info, is_training, is_ws=False,
+                              _feat_stride=[16, ], anchor_scales=[8, 16, 32]):
+    """f2: proposal_layer fed with the raw ``rpn_cls_score`` [N,H,W,2A]: the reference's
+    reshape_layer(2) -> softmax -> reshape_layer(2A) chain (Resnet_train_bus.py:76-81) is fused
+    into the decode kernel.  Same output contract as proposal_layer."""
+    as_np = _lib.wants_numpy(rpn_cls_score, rpn_bbox_pred, im_info)
+    rois, counts = proposal_layer_padded(rpn_cls_score, rpn_bbox_pred, im_info, is_training,
+                                         _feat_stride, anchor_scales, from_logits=True)
     blob = compact_rois(rois, counts)
     return blob.cpu().numpy() if as_np else blob
