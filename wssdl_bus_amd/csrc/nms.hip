@@ -176,6 +176,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
     float ix1 = 0.f, iy1 = 0.f, ix2 = 0.f, iy2 = 0.f;
     if (row_ok) { ix1 = b[i * 4 + 0]; iy1 = b[i * 4 + 1]; ix2 = b[i * 4 + 2]; iy2 = b[i * 4 + 3]; }
     const float iarea = box_area_ref(ix1, iy1, ix2, iy2);
+    const float t_lo = (float)(thresh * (1.0 - 1e-4)), t_hi = (float)(thresh * (1.0 + 1e-4));
     const int cb_end = min((n + 63) / 64, (seg + 1) * MASK_SEG);
     for (int cb = max(rb, seg * MASK_SEG) + wave; cb < cb_end; cb += MASK_WAVES) {
         const int col = cb * 64 + lane;
@@ -197,8 +198,14 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
             float inter = w * h;
             float den = iarea + cbox[wave][4][j];
             den = den - inter;
-            float ovr = inter / den;
-            if ((double)ovr >= thresh && cb * 64 + j > i) bits |= 1ull << j;
+            // (double)(inter / den) >= thresh, deciding without the IEEE division whenever the
+            // quotient is at least 1e-4 (relative) away from the threshold -- the f32 rounding
+            // of the quotient (2^-24) cannot cross that margin; otherwise the exact test
+            bool sup;
+            if (den > 0.0f && inter < den * t_lo) sup = false;
+            else if (den > 0.0f && inter > den * t_hi) sup = true;
+            else sup = (double)(inter / den) >= thresh;
+            if (sup && cb * 64 + j > i) bits |= 1ull << j;
         }
         if (row_ok) mask[((size_t)img * n_max + i) * ncb + cb] = bits;
         __builtin_amdgcn_wave_barrier();
