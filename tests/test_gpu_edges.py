@@ -272,3 +272,14 @@ def test_proposal_layer_from_logits_matches_softmax_path(torch_cuda):
     m = min(ref.shape[0], got.shape[0])
     same = (ref[:m] - got[:m]).abs().amax(dim=1) <= 1e-3
     assert same.float().mean().item() >= 0.99          # softmax differs by an ulp between the two paths
+
+
+def test_nms_large_n_uses_global_kept_list(torch_cuda):
+    """n > ~15k with max_keep = n: the sweep's kept list lives in global scratch, not LDS."""
+    from wssdl_bus_amd.nms.hip_nms import hip_nms
+    rs = np.random.RandomState(12)
+    n = 20000
+    c = rs.uniform(0, 3000, size=(n, 2))
+    wh = rs.uniform(10, 80, size=(n, 2))
+    d = np.hstack((c, c + wh, rs.permutation(n)[:, None] / float(n))).astype(np.float32)
+    assert hip_nms(d, 0.5) == O.nms(d, 0.5)

@@ -223,6 +223,7 @@ int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, in
 
 // ----------------------------------------------------------------- nms sweep ---
 constexpr int SWEEP_BLOCK = 256;
+constexpr size_t SWEEP_LDS_LIMIT = 60 * 1024;     // kept list in LDS up to ~15k entries
 
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int lane) {
     unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, lane);
@@ -230,33 +231,62 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
     return ((unsigned long long)hi << 32) | lo;
 }
 
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned lo = __shfl_xor((unsigned)v, off, 64);
+        unsigned hi = __shfl_xor((unsigned)(v >> 32), off, 64);
+        v |= ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+
+// Greedy sweep over the suppression matrix, one workgroup per image, pull formulation: the
+// word that chunk c needs is  removed_c = OR over every box kept in chunks < c of mask[box][c].
+// Per chunk, wave 0 (critical path)
+//   resolves the 64-row chunk against its diagonal word in scalar registers, visiting only
+//   the surviving boxes, appends them to the kept list, then fetches word c+1 of the boxes it
+//   just kept (one load per lane, wave OR-reduce);
+// while waves 1..3, overlapped with that,
+//   OR word c+1 of every box kept in EARLIER chunks (list in LDS, loads all independent).
+// One barrier per chunk joins the two halves.  Stops as soon as max_keep boxes are kept (the
+// reference's caller truncates keep[:post_nms_topN]).
 __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_kernel(
     const unsigned long long *__restrict__ mask, const int *__restrict__ n_dev, int n_max, int ncb,
     int max_keep, const int *__restrict__ order, int order_stride_img,
     int *__restrict__ keep, int *__restrict__ num_keep,
-    const float *__restrict__ boxes, int box_stride_img, float *__restrict__ rois_padded) {
-    extern __shared__ unsigned long long removed[];   // [ncb]
-    __shared__ unsigned long long s_kept;
-    __shared__ int s_rows[64];
+    const float *__restrict__ boxes, int box_stride_img, float *__restrict__ rois_padded,
+    int *__restrict__ kept_scratch) {
+    extern __shared__ int kept_lds[];                // [max_keep + 64] rows kept so far, in order
+    // (global scratch instead when the list does not fit in LDS: same-CU visibility after the
+    // workgroup barrier is all that is needed)
+    int *kept_rows = kept_scratch ? kept_scratch + (size_t)blockIdx.x * (max_keep + 64) : kept_lds;
+    __shared__ unsigned long long s_part[2][SWEEP_BLOCK / 64];   // helpers' partial ORs, by parity
+    __shared__ unsigned long long s_own[2];          // wave 0's contribution for the next chunk
+    __shared__ int s_count;
     const int img = blockIdx.x;
     const int n = min(n_dev[img], n_max);
     const unsigned long long *m = mask + (size_t)img * n_max * ncb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int w = tid; w < ncb; w += SWEEP_BLOCK) removed[w] = 0ull;
+    constexpr int NHELP = SWEEP_BLOCK - 64;
+    if (tid == 0) { s_count = 0; s_own[0] = s_own[1] = 0ull; }
+    if (tid < 2 * (SWEEP_BLOCK / 64)) s_part[tid / (SWEEP_BLOCK / 64)][tid % (SWEEP_BLOCK / 64)] = 0ull;
     __syncthreads();
-    int count = 0;
+    int count = 0;                                    // boxes kept in chunks < c (all threads agree)
     const int nchunks = (n + 63) / 64;
-    // wave 0 keeps the diagonal word of the next chunk in flight during the push phase
     unsigned long long diag = 0ull;
     if (wave == 0 && nchunks > 0) diag = (lane < n) ? m[(size_t)lane * ncb] : 0ull;
     for (int c = 0; c < nchunks; ++c) {
+        const int par = c & 1;
         if (wave == 0) {
+            unsigned long long rem = s_own[par];
+#pragma unroll
+            for (int w = 1; w < SWEEP_BLOCK / 64; ++w) rem |= s_part[par][w];
+            rem = readlane_u64(rem, 0);
             const int row = c * 64 + lane;
             const int nv = n - c * 64;
             const unsigned long long valid = (nv >= 64) ? ~0ull : ((1ull << nv) - 1ull);
-            unsigned long long cur = readlane_u64(removed[c], 0) | ~valid;
-            // greedy resolve inside the chunk, entirely in scalar registers: visit only the
-            // boxes that survive (about kept-per-chunk iterations, not 64)
+            unsigned long long cur = rem | ~valid;
             unsigned long long kept = 0ull;
             unsigned long long cand = ~cur;
             while (cand != 0ull) {
@@ -267,12 +297,11 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_kernel(
                 cur |= (((unsigned long long)hi << 32) | lo) | (1ull << bsel);
                 cand = ~cur & ((bsel == 63) ? 0ull : (~0ull << (bsel + 1)));
             }
-            if (lane == 0) s_kept = kept;
-            if ((kept >> lane) & 1ull) {
-                const int ord = __popcll(kept & ((1ull << lane) - 1ull));
-                s_rows[ord] = row;
-                const int pos = count + ord;
+            const bool mine = (kept >> lane) & 1ull;
+            if (mine) {
+                const int pos = count + __popcll(kept & ((1ull << lane) - 1ull));
                 if (pos < max_keep) {
+                    kept_rows[pos] = row;
                     if (keep)
                         keep[(size_t)img * max_keep + pos] =
                             order ? order[(size_t)img * order_stride_img + row] : row;
@@ -283,33 +312,29 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_kernel(
                     }
                 }
             }
-            // prefetch the next chunk's diagonal word
-            const int nrow = (c + 1) * 64 + lane;
-            diag = (c + 1 < nchunks && nrow < n) ? m[(size_t)nrow * ncb + c + 1] : 0ull;
-        }
-        __syncthreads();
-        const unsigned long long kept = s_kept;
-        const int nk = __popcll(kept);
-        count += nk;
-        if (count >= max_keep) break;
-        // push: OR the kept rows' mask words into the LDS bitmap.  8 groups of 32 lanes take
-        // the kept rows round-robin; a group reads 32 consecutive words (256 B) per step; all
-        // loads are independent, the OR is an LDS atomic.
-        const int grp = tid >> 5, wl = tid & 31;
-        for (int kr = grp; kr < nk; kr += SWEEP_BLOCK / 32) {
-            const unsigned long long *rowp = m + (size_t)s_rows[kr] * ncb;
-            for (int w = c + 1 + wl; w < ncb; w += 128) {
-                unsigned long long v0 = rowp[w];
-                unsigned long long v1 = (w + 32 < ncb) ? rowp[w + 32] : 0ull;
-                unsigned long long v2 = (w + 64 < ncb) ? rowp[w + 64] : 0ull;
-                unsigned long long v3 = (w + 96 < ncb) ? rowp[w + 96] : 0ull;
-                if (v0) atomicOr(&removed[w], v0);
-                if (v1) atomicOr(&removed[w + 32], v1);
-                if (v2) atomicOr(&removed[w + 64], v2);
-                if (v3) atomicOr(&removed[w + 96], v3);
+            // word c+1 of the boxes kept in this chunk, and the next diagonal word
+            unsigned long long nxt = 0ull;
+            if (c + 1 < nchunks) {
+                if (mine) nxt = m[(size_t)row * ncb + c + 1];
+                const int nrow = (c + 1) * 64 + lane;
+                diag = (nrow < n) ? m[(size_t)nrow * ncb + c + 1] : 0ull;
             }
+            nxt = wave_or_u64(nxt);
+            if (lane == 0) {
+                s_own[par ^ 1] = nxt;
+                s_count = count + __popcll(kept);
+            }
+        } else if (c + 1 < nchunks) {
+            // helpers: word c+1 of every box kept before this chunk
+            unsigned long long acc = 0ull;
+            const int lim = min(count, max_keep);
+            for (int i = tid - 64; i < lim; i += NHELP) acc |= m[(size_t)kept_rows[i] * ncb + c + 1];
+            acc = wave_or_u64(acc);
+            if (lane == 0) s_part[par ^ 1][wave] = acc;
         }
         __syncthreads();
+        count = s_count;
+        if (count >= max_keep) break;
     }
     if (tid == 0) num_keep[img] = min(count, max_keep);
 }
@@ -317,13 +342,19 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_kernel(
 int launch_nms_sweep(const unsigned long long *mask, const int *n_dev, int n_max, int n_images,
                      int max_keep, const int *order, int order_stride_img, int *keep,
                      int *num_keep, const float *boxes, int box_stride_img, float *rois_padded,
-                     hipStream_t st) {
+                     int *kept_scratch, hipStream_t st) {
     int ncb = cdiv(n_max, 64);
     if (n_images == 0) return WSSDL_OK;
-    size_t lds = (size_t)(ncb > 0 ? ncb : 1) * sizeof(unsigned long long);
+    size_t lds = ((size_t)max_keep + 64) * sizeof(int);
+    if (lds > SWEEP_LDS_LIMIT) {
+        if (!kept_scratch) return WSSDL_ERR_WORKSPACE;
+        lds = 0;
+    } else {
+        kept_scratch = nullptr;
+    }
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(n_images), dim3(SWEEP_BLOCK), lds, st, mask, n_dev,
                        n_max, ncb, max_keep, order, order_stride_img, keep, num_keep, boxes,
-                       box_stride_img, rois_padded);
+                       box_stride_img, rois_padded, kept_scratch);
     return check_launch();
 }
 
@@ -346,7 +377,7 @@ __global__ void nms_gather_kernel(const float *__restrict__ dets, const int *__r
 
 struct NmsWs {
     unsigned long long *keys, *cand, *thresh, *mask;
-    int *order, *n_sorted, *cand_fill;
+    int *order, *n_sorted, *cand_fill, *kept;
     float *boxes;
 };
 
@@ -360,6 +391,7 @@ static size_t carve_nms(void *ws, int n, NmsWs *out) {
     w.order = c.take<int>(n);
     w.n_sorted = c.take<int>(64);
     w.cand_fill = c.take<int>(64);
+    w.kept = c.take<int>((size_t)n + 64);
     w.boxes = c.take<float>((size_t)n * 4);
     w.mask = c.take<unsigned long long>((size_t)n * ncb);
     if (out) *out = w;
@@ -404,5 +436,5 @@ extern "C" int wssdl_nms(const float *dets, int n, double thresh, int max_keep, 
     rc = launch_nms_mask(w.boxes, n * 4, w.n_sorted, n, 1, thresh, w.mask, st);
     if (rc) return rc;
     return launch_nms_sweep(w.mask, w.n_sorted, n, 1, max_keep, w.order, n, keep, num_keep,
-                            nullptr, 0, nullptr, st);
+                            nullptr, 0, nullptr, w.kept, st);
 }

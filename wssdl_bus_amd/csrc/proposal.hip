@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void proposal_compact_kernel(
 struct ProposalWs {
     unsigned long long *keys, *cand, *thresh, *mask;
     float *boxes, *sorted_boxes;
-    int *sorted_index, *n_sorted, *cand_fill;
+    int *sorted_index, *n_sorted, *cand_fill, *kept;
 };
 
 static size_t carve_proposal(void *ws, int N, int M, int topn, ProposalWs *out) {
@@ -121,6 +121,7 @@ static size_t carve_proposal(void *ws, int N, int M, int topn, ProposalWs *out) 
     w.cand_fill = c.take<int>((size_t)N + 64);
     w.thresh = c.take<unsigned long long>((size_t)N + 32);
     w.cand = c.take<unsigned long long>((size_t)N * topn);
+    w.kept = c.take<int>((size_t)N * ((size_t)topn + 64));
     w.sorted_boxes = c.take<float>((size_t)N * topn * 4);
     w.mask = c.take<unsigned long long>((size_t)N * topn * ncb);
     if (out) *out = w;
@@ -195,7 +196,8 @@ static int proposal_layer_impl(int from_logits, const float *rpn_cls_prob, const
     // the sweep writes (batch_idx, box) rows straight into rois_padded and stops
     // after `pitch` kept boxes
     if ((rc = launch_nms_sweep(w.mask, nsorted, topn, N, pitch, nullptr, 0, nullptr, roi_counts,
-                               w.sorted_boxes, topn * 4, rois_padded, st)))
+                               w.sorted_boxes, topn * 4, rois_padded,
+                               pitch <= topn ? w.kept : nullptr, st)))
         return rc;
     if (sorted_index &&
         hipMemcpyAsync(sorted_index, sidx, sizeof(int) * (size_t)N * topn, hipMemcpyDeviceToDevice,
