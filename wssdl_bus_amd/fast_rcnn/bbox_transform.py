@@ -1,50 +1,46 @@
-"""Box transforms as device tensor ops (reference: code/lib/fast_rcnn/bbox_transform.py:10-77).
+"""Box <-> delta transforms as device tensor ops.
 
-On the RPN hot path these formulas run *inside* the HIP kernels (proposal decode, anchor /
-RoI targets).  The stand-alone functions here serve the post-detection step of the test
-path (fast_rcnn/test_bus.py), where the head's class-wise deltas are decoded; f32 PyTorch
-ops in the reference's operation order."""
+Same maths as the reference's ``fast_rcnn/bbox_transform.py`` (:10-28 encode, :30-61 decode,
+:63-77 clip), written over a (width, height, centre) helper.  On the RPN hot path these
+formulas run *inside* the HIP kernels (proposal decode, anchor / RoI targets); the stand-alone
+functions serve the post-detection step of the test path (fast_rcnn/test_bus.py), where the
+head's class-wise deltas are decoded.  f32 PyTorch ops, +1 pixel convention.
+"""
 import torch
 
 
+def _whc(b):
+    """(w, h, cx, cy) of [R,4] corner boxes; centre = corner + half extent, as the reference."""
+    wh = b[:, 2:4] - b[:, 0:2] + 1.0
+    ctr = b[:, 0:2] + 0.5 * wh
+    return wh[:, 0], wh[:, 1], ctr[:, 0], ctr[:, 1]
+
+
 def bbox_transform(ex_rois, gt_rois):
-    ew = ex_rois[:, 2] - ex_rois[:, 0] + 1.0
-    eh = ex_rois[:, 3] - ex_rois[:, 1] + 1.0
-    ecx = ex_rois[:, 0] + 0.5 * ew
-    ecy = ex_rois[:, 1] + 0.5 * eh
-    gw = gt_rois[:, 2] - gt_rois[:, 0] + 1.0
-    gh = gt_rois[:, 3] - gt_rois[:, 1] + 1.0
-    gcx = gt_rois[:, 0] + 0.5 * gw
-    gcy = gt_rois[:, 1] + 0.5 * gh
-    return torch.stack(((gcx - ecx) / ew, (gcy - ecy) / eh, torch.log(gw / ew), torch.log(gh / eh)), dim=1)
+    """Regression targets (dx, dy, dw, dh) that map ex_rois onto gt_rois."""
+    ew, eh, ex, ey = _whc(ex_rois)
+    gw, gh, gx, gy = _whc(gt_rois)
+    return torch.stack(((gx - ex) / ew, (gy - ey) / eh, (gw / ew).log(), (gh / eh).log()), dim=1)
 
 
 def bbox_transform_inv(boxes, deltas):
-    """boxes [R,4], deltas [R,4K] -> [R,4K] (bbox_transform.py:30-61)."""
+    """Decode class-wise deltas [R,4K] on boxes [R,4] -> corner boxes [R,4K]."""
     if boxes.shape[0] == 0:
-        return torch.zeros((0, deltas.shape[1]), dtype=deltas.dtype, device=deltas.device)
-    boxes = boxes.to(deltas.dtype)
-    w = boxes[:, 2] - boxes[:, 0] + 1.0
-    h = boxes[:, 3] - boxes[:, 1] + 1.0
-    cx = boxes[:, 0] + 0.5 * w
-    cy = boxes[:, 1] + 0.5 * h
-    dx, dy, dw, dh = deltas[:, 0::4], deltas[:, 1::4], deltas[:, 2::4], deltas[:, 3::4]
-    pcx = dx * w[:, None] + cx[:, None]
-    pcy = dy * h[:, None] + cy[:, None]
-    pw = torch.exp(dw) * w[:, None]
-    ph = torch.exp(dh) * h[:, None]
-    out = torch.zeros_like(deltas)
-    out[:, 0::4] = pcx - 0.5 * pw
-    out[:, 1::4] = pcy - 0.5 * ph
-    out[:, 2::4] = pcx + 0.5 * pw
-    out[:, 3::4] = pcy + 0.5 * ph
-    return out
+        return deltas.new_zeros((0, deltas.shape[1]))
+    w, h, cx, cy = (t.unsqueeze(1) for t in _whc(boxes.to(deltas.dtype)))
+    d = deltas.reshape(deltas.shape[0], -1, 4)                 # [R,K,(dx,dy,dw,dh)]
+    pcx = d[..., 0] * w + cx
+    pcy = d[..., 1] * h + cy
+    half_w = 0.5 * (d[..., 2].exp() * w)
+    half_h = 0.5 * (d[..., 3].exp() * h)
+    out = torch.stack((pcx - half_w, pcy - half_h, pcx + half_w, pcy + half_h), dim=-1)
+    return out.reshape(deltas.shape)
 
 
 def clip_boxes(boxes, im_shape):
-    """bbox_transform.py:63-77: every coordinate into [0, im-1]; im_shape = (h, w)."""
-    boxes[:, 0::4] = torch.clamp(boxes[:, 0::4], max=float(im_shape[1]) - 1).clamp_min(0)
-    boxes[:, 1::4] = torch.clamp(boxes[:, 1::4], max=float(im_shape[0]) - 1).clamp_min(0)
-    boxes[:, 2::4] = torch.clamp(boxes[:, 2::4], max=float(im_shape[1]) - 1).clamp_min(0)
-    boxes[:, 3::4] = torch.clamp(boxes[:, 3::4], max=float(im_shape[0]) - 1).clamp_min(0)
+    """Every coordinate into [0, im-1]; im_shape = (height, width).  In place, like the reference."""
+    v = boxes.view(boxes.shape[0], -1, 4)
+    xmax, ymax = float(im_shape[1]) - 1.0, float(im_shape[0]) - 1.0
+    v[..., 0::2].clamp_(min=0.0, max=xmax)
+    v[..., 1::2].clamp_(min=0.0, max=ymax)
     return boxes
