@@ -21,8 +21,9 @@ def rpn_cls_loss(rpn_cls_score_reshape, rpn_labels):
     rpn_cls_score_reshape [N, A*H, W, 2]; rpn_labels [N, 1, A*H, W] int."""
     score = rpn_cls_score_reshape.reshape(-1, 2)
     label = rpn_labels.reshape(-1).to(torch.int64)
-    keep = label != -1
-    return F.cross_entropy(score[keep], label[keep])
+    # mean CE over the anchors whose label != -1 (tf.gather of the kept rows in the reference);
+    # ignore_index does the same without materialising the kept rows (no host sync)
+    return F.cross_entropy(score, label, ignore_index=-1)
 
 
 def rpn_box_loss(rpn_bbox_pred, rpn_data, n_images=None):
