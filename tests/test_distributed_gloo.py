@@ -42,9 +42,32 @@ def _worker(rank, world, port, q):
     ctx.allreduce_gradients(params)
     out["local"] = local
     out["reduced"] = [p.grad.clone() for p in params]
+    # the same gradients through the overlapped (hook-driven) path: two steps, the second one a
+    # backward that leaves the first layers without gradients
+    torch.manual_seed(0)
+    net2 = torch.nn.Sequential(torch.nn.Linear(40, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8),
+                               torch.nn.Linear(8, 3))
+    p2 = list(net2.parameters())
+    ctx.bucket_bytes = 256
+    ov = ctx.overlap(p2)
+    assert len(ov.buckets) >= 2, [len(b) for b in ov.buckets]
+    net2[:3](x).sum().backward()
+    if rank == 0:
+        (net2[3](torch.ones(2, 8)).sum()).backward()
+    ov.finish()
+    out["overlap"] = [p.grad.clone() for p in p2]
+    for p in p2:
+        p.grad = None
+    (net2[3](torch.full((2, 8), float(rank + 1))).sum()).backward()      # only the last layer
+    ov.finish()
+    out["overlap2"] = [p.grad.clone() for p in p2]
+    ov.remove()
     out["tmax"] = ctx.max_over_ranks(1.0 + rank)
     out["tsum"] = ctx.sum_over_ranks(1.0 + rank)
     ctx.barrier()
+    # plain numpy through the queue (torch tensors are shared by fd and the worker may exit first)
+    for k in ("local", "reduced", "overlap", "overlap2"):
+        out[k] = [None if t is None else t.detach().numpy().copy() for t in out[k]]
     q.put((rank, out))
     ctx.shutdown()
 
@@ -59,6 +82,9 @@ def test_data_parallel_gloo_world2():
     for p in procs:
         p.start()
     res = dict(q.get(timeout=150) for _ in range(world))
+    for r in res:
+        for k in ("local", "reduced", "overlap", "overlap2"):
+            res[r][k] = [None if a is None else torch.from_numpy(a) for a in res[r][k]]
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
@@ -72,6 +98,14 @@ def test_data_parallel_gloo_world2():
         want = (g[0] + g[1]) / world
         for r in range(world):
             assert torch.allclose(res[r]["reduced"][k], want, rtol=1e-6, atol=1e-7)
+    for k in range(len(res[0]["reduced"])):
+        for r in range(world):
+            assert torch.allclose(res[r]["overlap"][k], res[r]["reduced"][k], rtol=1e-6, atol=1e-7)
+    # second step: first three parameter tensors get zeros, the last layer the mean over ranks
+    for r in range(world):
+        assert all(float(g.abs().sum()) == 0.0 for g in res[r]["overlap2"][:4])
+        assert torch.allclose(res[r]["overlap2"][4], torch.full((3, 8), 2 * 1.5))      # mean of 2*1 and 2*2
+        assert torch.allclose(res[r]["overlap2"][5], torch.full((3,), 2.0))
     assert res[0]["tmax"] == res[1]["tmax"] == 2.0
     assert res[0]["tsum"] == res[1]["tsum"] == 3.0
 

@@ -78,6 +78,10 @@ class DistContext(object):
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
         return flat, work, list(ps)
 
+    def overlap(self, params):
+        """Bucketed all-reduce overlapped with backward: see GradOverlap."""
+        return GradOverlap(self, params)
+
     def barrier(self):
         if self.enabled:
             dist.barrier()
@@ -101,3 +105,82 @@ class DistContext(object):
     def shutdown(self):
         if self.enabled and dist.is_initialized():
             dist.destroy_process_group()
+
+
+class GradOverlap(object):
+    """Gradient all-reduce overlapped with the backward pass.
+
+    Parameters are packed (in reverse registration order, i.e. roughly the order in which
+    backward produces their gradients) into buckets of ``ctx.bucket_bytes``.  A post-accumulate
+    hook on every parameter counts its bucket down; when the last gradient of a bucket has
+    been accumulated the bucket is flattened and its all-reduce is launched asynchronously on
+    RCCL's stream while backward keeps running.  ``finish()`` (called before the optimiser step)
+    launches whatever is left -- buckets holding parameters that received no gradient in this
+    backward, e.g. the RPN weights in a MIL-only step, are completed with zeros so that every
+    rank issues the same collectives in the same order -- waits, and writes the means back."""
+
+    def __init__(self, ctx, params):
+        self.ctx = ctx
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []
+        cur, size = [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            size += p.numel() * p.element_size()
+            if size >= ctx.bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.bucket_of = {}
+        for b, ps in enumerate(self.buckets):
+            for p in ps:
+                self.bucket_of[id(p)] = b
+        self.handles = []
+        if ctx.enabled:
+            self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+        self._reset()
+
+    def _reset(self):
+        self.pending = [len(ps) for ps in self.buckets]
+        self.launched = [None] * len(self.buckets)
+        self.next_to_launch = 0
+
+    def _hook(self, p):
+        b = self.bucket_of[id(p)]
+        self.pending[b] -= 1
+        # launch strictly in bucket order so that all ranks issue identical collectives
+        while (self.next_to_launch < len(self.buckets) and self.pending[self.next_to_launch] == 0):
+            self._launch(self.next_to_launch)
+            self.next_to_launch += 1
+
+    def _launch(self, b):
+        ps = self.buckets[b]
+        for p in ps:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        self.launched[b] = (flat, work)
+
+    def finish(self):
+        """Call after backward, before optimizer.step()."""
+        if not self.ctx.enabled:
+            return
+        for b in range(self.next_to_launch, len(self.buckets)):
+            self._launch(b)
+        for b, ps in enumerate(self.buckets):
+            flat, work = self.launched[b]
+            work.wait()
+            flat.div_(self.ctx.world_size)
+            off = 0
+            for p in ps:
+                n = p.grad.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        self._reset()
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []

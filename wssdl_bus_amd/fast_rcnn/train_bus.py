@@ -109,9 +109,13 @@ class SolverWrapper(object):
         self.optimizer = torch.optim.Adam(self.params, lr=self.lr, eps=0.1)
         self.global_step = 0
         self.dist = dist_ctx
+        # data parallel: bucketed gradient all-reduce overlapped with backward
+        self.overlap = dist_ctx.overlap(self.params) if (dist_ctx is not None and dist_ctx.enabled) else None
 
     def _apply(self):
-        if self.dist is not None:
+        if self.overlap is not None:
+            self.overlap.finish()
+        elif self.dist is not None:
             self.dist.allreduce_gradients(self.params)
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
