@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwssdl_bus_hip.so")
+LIB_PATH = os.environ.get("WSSDL_BUS_HIP_LIB") or os.path.join(_HERE, "libwssdl_bus_hip.so")
 
 OK, ERR_INVALID_ARGUMENT, ERR_WORKSPACE, ERR_LAUNCH = 0, 1, 2, 3
 ROUND_CUDA, ROUND_CPU = 0, 1

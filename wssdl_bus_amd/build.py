@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libwssdl_bus_hip.so")
+OUT = os.environ.get("WSSDL_BUS_HIP_LIB") or os.path.join(HERE, "libwssdl_bus_hip.so")
 SOURCES = ["api_common.hip", "bbox_overlaps.hip", "nms.hip", "proposal.hip", "anchor_target.hip",
            "roi_targets.hip", "roi_pool.hip", "mil.hip"]
 HEADERS = ["common.hip.h", "nms.hip.h", os.path.join("..", "..", "include", "wssdl_bus_hip.h")]
@@ -39,7 +39,8 @@ def is_stale():
 def build(force=False, verbose=True):
     if not force and not is_stale():
         return OUT
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp"]
+    extra = os.environ.get("WSSDL_HIPCC_EXTRA", "").split()     # e.g. -DWSSDL_SWEEP_BLOCK=512 (tuning)
+    cmd = [hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp"]
     if verbose:
         print("[wssdl_bus_amd] " + " ".join(cmd))
     subprocess.check_call(cmd)

@@ -222,7 +222,10 @@ int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, in
 }
 
 // ----------------------------------------------------------------- nms sweep ---
-constexpr int SWEEP_BLOCK = 256;
+#ifndef WSSDL_SWEEP_BLOCK
+#define WSSDL_SWEEP_BLOCK 1024
+#endif
+constexpr int SWEEP_BLOCK = WSSDL_SWEEP_BLOCK;
 constexpr size_t SWEEP_LDS_LIMIT = 60 * 1024;     // kept list in LDS up to ~15k entries
 
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int lane) {
@@ -231,14 +234,27 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// OR over the 64 lanes of a wave with DPP moves (VALU latency; a ds_bpermute butterfly costs six
+// dependent LDS round trips, which sat on the per-chunk critical path of the sweep).  Shifts
+// within each row of 16 bring the row's OR to its lane 15, the two row broadcasts carry it to
+// lane 63; OR is idempotent so the overlapping shifts need no masking.  Uniform result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_or(unsigned v) {
+    return v | (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+    v = dpp_or<0x111, 0xf>(v);      // row_shr:1
+    v = dpp_or<0x112, 0xf>(v);      // row_shr:2
+    v = dpp_or<0x114, 0xf>(v);      // row_shr:4
+    v = dpp_or<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of each row holds the row's OR
+    v = dpp_or<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_or<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds all
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        unsigned lo = __shfl_xor((unsigned)v, off, 64);
-        unsigned hi = __shfl_xor((unsigned)(v >> 32), off, 64);
-        v |= ((unsigned long long)hi << 32) | lo;
-    }
-    return v;
+    unsigned lo = wave_or_u32((unsigned)v);
+    unsigned hi = wave_or_u32((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 // Greedy sweep over the suppression matrix, one workgroup per image, pull formulation: the
@@ -247,7 +263,7 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
 //   resolves the 64-row chunk against its diagonal word in scalar registers, visiting only
 //   the surviving boxes, appends them to the kept list, then fetches word c+1 of the boxes it
 //   just kept (one load per lane, wave OR-reduce);
-// while waves 1..3, overlapped with that,
+// while the other waves, overlapped with that,
 //   OR word c+1 of every box kept in EARLIER chunks (list in LDS, loads all independent).
 // One barrier per chunk joins the two halves.  Stops as soon as max_keep boxes are kept (the
 // reference's caller truncates keep[:post_nms_topN]).
@@ -274,15 +290,21 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_kernel(
     __syncthreads();
     int count = 0;                                    // boxes kept in chunks < c (all threads agree)
     const int nchunks = (n + 63) / 64;
-    unsigned long long diag = 0ull;
-    if (wave == 0 && nchunks > 0) diag = (lane < n) ? m[(size_t)lane * ncb] : 0ull;
+    // wave 0 keeps two words per lane in flight one chunk ahead: the diagonal word of its row and
+    // the word right of it (needed only if the row survives: loaded speculatively so that no
+    // memory latency sits between resolving a chunk and handing its result on)
+    unsigned long long diag = 0ull, right = 0ull;
+    if (wave == 0 && nchunks > 0 && lane < n) {
+        diag = m[(size_t)lane * ncb];
+        if (nchunks > 1) right = m[(size_t)lane * ncb + 1];
+    }
     for (int c = 0; c < nchunks; ++c) {
         const int par = c & 1;
         if (wave == 0) {
-            unsigned long long rem = s_own[par];
-#pragma unroll
-            for (int w = 1; w < SWEEP_BLOCK / 64; ++w) rem |= s_part[par][w];
-            rem = readlane_u64(rem, 0);
+            // s_part[par][0] is unused by the helpers (wave 0 is not one): lane 0 reads s_own there
+            unsigned long long rem = (lane == 0) ? s_own[par]
+                                   : (lane < SWEEP_BLOCK / 64) ? s_part[par][lane] : 0ull;
+            rem = wave_or_u64(rem);
             const int row = c * 64 + lane;
             const int nv = n - c * 64;
             const unsigned long long valid = (nv >= 64) ? ~0ull : ((1ull << nv) - 1ull);
@@ -312,14 +334,16 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_kernel(
                     }
                 }
             }
-            // word c+1 of the boxes kept in this chunk, and the next diagonal word
-            unsigned long long nxt = 0ull;
-            if (c + 1 < nchunks) {
-                if (mine) nxt = m[(size_t)row * ncb + c + 1];
-                const int nrow = (c + 1) * 64 + lane;
-                diag = (nrow < n) ? m[(size_t)nrow * ncb + c + 1] : 0ull;
+            // word c+1 of the boxes kept in this chunk (already in registers), then prefetch the
+            // two words of the next chunk's rows
+            unsigned long long nxt = wave_or_u64(mine ? right : 0ull);
+            diag = 0ull;
+            right = 0ull;
+            const int nrow = (c + 1) * 64 + lane;
+            if (c + 1 < nchunks && nrow < n) {
+                diag = m[(size_t)nrow * ncb + c + 1];
+                if (c + 2 < nchunks) right = m[(size_t)nrow * ncb + c + 2];
             }
-            nxt = wave_or_u64(nxt);
             if (lane == 0) {
                 s_own[par ^ 1] = nxt;
                 s_count = count + __popcll(kept);
@@ -339,6 +363,163 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_kernel(
     if (tid == 0) num_keep[img] = min(count, max_keep);
 }
 
+
+// ------------------------------------------------- nms sweep, latency-pipelined ---
+// Same greedy sweep, restructured so that no global-memory latency sits on the per-chunk
+// critical path (the version above spends ~1.6 us per 64-box chunk, most of it waiting for one
+// dependent load; 188 chunks at 12000 boxes).  Contributions to removed[w] are split by age:
+//   * boxes kept in chunks w-3..w-1: wave 0 holds words c+1..c+3 of every row of chunk c in
+//     registers (loaded two chunks ahead, together with the diagonal word) and ORs the
+//     survivors' words into the ring slots of words c+1..c+3 right after resolving chunk c;
+//   * boxes kept in chunks < w-3: the helper waves issue word c+3 of every box kept before
+//     chunk c during iteration c and consume it two iterations later, so each of their loads
+//     has two full iterations to complete.
+// removed[] lives in a 4-slot LDS ring (slot = word & 3) updated with ds_or_b64.  The barrier
+// waits for LDS traffic only, so the loads stay in flight across it.  Needs the kept list in
+// LDS and max_keep <= LH * (SWEEP_BLOCK - 64); the kernel above is the general fallback.
+constexpr int SWEEP_LH = 3;
+
+__device__ __forceinline__ void lds_only_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+struct SweepRows {                  // wave 0: one row per lane, words c..c+3 of chunk c
+    unsigned long long w[4];
+};
+struct SweepPend {                  // helpers: loads in flight for one future word
+    unsigned long long v[SWEEP_LH];
+};
+
+struct SweepCtx {
+    const unsigned long long *m;
+    int n, ncb, nchunks, max_keep, img;
+    const int *order; int order_stride_img;
+    int *keep; const float *boxes; int box_stride_img; float *rois_padded;
+    int *kept_rows; unsigned long long *ring; int *s_count;
+    int tid, lane, wave;
+};
+
+__device__ __forceinline__ void sweep_load_rows(const SweepCtx &k, int chunk, SweepRows &r) {
+    const int row = chunk * 64 + k.lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r.w[j] = 0ull;
+        if (row < k.n && chunk + j < k.nchunks) r.w[j] = k.m[(size_t)row * k.ncb + chunk + j];
+    }
+}
+
+// one chunk; `rows` holds chunk c (refilled with chunk c+2), `pend` holds the helpers' word c+1
+// loads issued at iteration c-2 (refilled with word c+3).  Returns the kept count after c.
+__device__ __forceinline__ int sweep_step(const SweepCtx &k, int c, int count, SweepRows &rows,
+                                          SweepPend &pend) {
+    constexpr int NHELP = SWEEP_BLOCK - 64;
+    if (k.wave == 0) {
+        unsigned long long rem = 0ull;
+        if (k.lane == 0) { rem = k.ring[c & 3]; k.ring[c & 3] = 0ull; }   // slot reused by word c+4
+        rem = readlane_u64(rem, 0);
+        const int row = c * 64 + k.lane;
+        const int nv = k.n - c * 64;
+        const unsigned long long valid = (nv >= 64) ? ~0ull : ((1ull << nv) - 1ull);
+        unsigned long long cur = rem | ~valid;
+        unsigned long long kept = 0ull;
+        unsigned long long cand = ~cur;
+        const unsigned long long diag = rows.w[0];
+        while (cand != 0ull) {
+            const int bsel = __builtin_amdgcn_readfirstlane(__ffsll((long long)cand) - 1);
+            kept |= 1ull << bsel;
+            unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)diag, bsel);
+            unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(diag >> 32), bsel);
+            cur |= (((unsigned long long)hi << 32) | lo) | (1ull << bsel);
+            cand = ~cur & ((bsel == 63) ? 0ull : (~0ull << (bsel + 1)));
+        }
+        const bool mine = (kept >> k.lane) & 1ull;
+        // hand the survivors' next three words on first: this is what the next chunk waits for
+        const unsigned long long n1 = wave_or_u64(mine ? rows.w[1] : 0ull);
+        const unsigned long long n2 = wave_or_u64(mine ? rows.w[2] : 0ull);
+        const unsigned long long n3 = wave_or_u64(mine ? rows.w[3] : 0ull);
+        if (k.lane == 0) {
+            atomicOr(&k.ring[(c + 1) & 3], n1);
+            atomicOr(&k.ring[(c + 2) & 3], n2);
+            atomicOr(&k.ring[(c + 3) & 3], n3);
+            *k.s_count = count + __popcll(kept);
+        }
+        if (mine) {
+            const int pos = count + __popcll(kept & ((1ull << k.lane) - 1ull));
+            if (pos < k.max_keep) {
+                k.kept_rows[pos] = row;
+                if (k.keep)
+                    k.keep[(size_t)k.img * k.max_keep + pos] =
+                        k.order ? k.order[(size_t)k.img * k.order_stride_img + row] : row;
+                if (k.rois_padded) {
+                    const float *bx = k.boxes + (size_t)k.img * k.box_stride_img + (size_t)row * 4;
+                    float *o = k.rois_padded + ((size_t)k.img * k.max_keep + pos) * 5;
+                    o[0] = (float)k.img; o[1] = bx[0]; o[2] = bx[1]; o[3] = bx[2]; o[4] = bx[3];
+                }
+            }
+        }
+        sweep_load_rows(k, c + 2, rows);
+    } else {
+        // consume word c+1 (issued at iteration c-2: boxes kept before chunk c-2)
+        unsigned long long acc = 0ull;
+#pragma unroll
+        for (int j = 0; j < SWEEP_LH; ++j) acc |= pend.v[j];
+        acc = wave_or_u64(acc);
+        if (k.lane == 0 && acc != 0ull) atomicOr(&k.ring[(c + 1) & 3], acc);
+        // issue word c+3 of every box kept before chunk c
+        const int lim = min(count, k.max_keep);
+#pragma unroll
+        for (int j = 0; j < SWEEP_LH; ++j) {
+            const int i = k.tid - 64 + j * NHELP;
+            pend.v[j] = 0ull;
+            if (i < lim && c + 3 < k.nchunks) pend.v[j] = k.m[(size_t)k.kept_rows[i] * k.ncb + c + 3];
+        }
+    }
+    lds_only_barrier();
+    return *k.s_count;
+}
+
+__global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(
+    const unsigned long long *__restrict__ mask, const int *__restrict__ n_dev, int n_max, int ncb,
+    int max_keep, const int *__restrict__ order, int order_stride_img,
+    int *__restrict__ keep, int *__restrict__ num_keep,
+    const float *__restrict__ boxes, int box_stride_img, float *__restrict__ rois_padded) {
+    extern __shared__ int kept_lds[];                // [max_keep + 64]
+    __shared__ unsigned long long s_ring[4];
+    __shared__ int s_count;
+    SweepCtx k;
+    k.img = blockIdx.x;
+    k.n = min(n_dev[k.img], n_max);
+    k.ncb = ncb;
+    k.nchunks = (k.n + 63) / 64;
+    k.max_keep = max_keep;
+    k.m = mask + (size_t)k.img * n_max * ncb;
+    k.order = order; k.order_stride_img = order_stride_img;
+    k.keep = keep; k.boxes = boxes; k.box_stride_img = box_stride_img; k.rois_padded = rois_padded;
+    k.kept_rows = kept_lds; k.ring = s_ring; k.s_count = &s_count;
+    k.tid = threadIdx.x; k.lane = k.tid & 63; k.wave = k.tid >> 6;
+    if (k.tid < 4) s_ring[k.tid] = 0ull;
+    if (k.tid == 0) s_count = 0;
+    __syncthreads();
+    SweepRows rows0, rows1;
+    SweepPend pend0, pend1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rows0.w[j] = rows1.w[j] = 0ull;
+#pragma unroll
+    for (int j = 0; j < SWEEP_LH; ++j) pend0.v[j] = pend1.v[j] = 0ull;
+    if (k.wave == 0) {
+        sweep_load_rows(k, 0, rows0);
+        sweep_load_rows(k, 1, rows1);
+    }
+    int count = 0;
+    for (int c = 0; c < k.nchunks; c += 2) {
+        count = sweep_step(k, c, count, rows0, pend0);
+        if (count >= max_keep || c + 1 >= k.nchunks) break;
+        count = sweep_step(k, c + 1, count, rows1, pend1);
+        if (count >= max_keep) break;
+    }
+    if (k.tid == 0) num_keep[k.img] = min(count, max_keep);
+}
+
 int launch_nms_sweep(const unsigned long long *mask, const int *n_dev, int n_max, int n_images,
                      int max_keep, const int *order, int order_stride_img, int *keep,
                      int *num_keep, const float *boxes, int box_stride_img, float *rois_padded,
@@ -346,6 +527,12 @@ int launch_nms_sweep(const unsigned long long *mask, const int *n_dev, int n_max
     int ncb = cdiv(n_max, 64);
     if (n_images == 0) return WSSDL_OK;
     size_t lds = ((size_t)max_keep + 64) * sizeof(int);
+    if (lds <= SWEEP_LDS_LIMIT && max_keep <= SWEEP_LH * (SWEEP_BLOCK - 64)) {
+        hipLaunchKernelGGL(nms_sweep_pipelined_kernel, dim3(n_images), dim3(SWEEP_BLOCK), lds, st,
+                           mask, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep,
+                           num_keep, boxes, box_stride_img, rois_padded);
+        return check_launch();
+    }
     if (lds > SWEEP_LDS_LIMIT) {
         if (!kept_scratch) return WSSDL_ERR_WORKSPACE;
         lds = 0;
