@@ -179,13 +179,25 @@ WSSDL_API int wssdl_anchor_targets(const int8_t *labels, const int32_t *argmax_g
  * Stage 1  wssdl_roi_gt_assign: rois [R,5] f32 x positive gt of each roi's image:
  *   f64 IoU (utils/bbox.pyx), max_overlap [R] f64, assignment [R] i32 (row of
  *   gt_boxes of that image; first maximum, numpy argmax).  (:233-238)
- * Stage 2  sampling: host (reference RNG) or torch ops in the host layer.
+ * Stage 2  sampling (:241-262): on the host with the reference's numpy stream, or
+ *   wssdl_roi_sample_device: per image images[s] draw min(fg_rois_per_image, #fg)
+ *   rows with max_overlap >= fg_thresh and min(rois_per_image - n_fg, #bg) rows with
+ *   bg_thresh_lo <= max_overlap < bg_thresh_hi, uniformly without replacement
+ *   (counter-based hash of (seed, image, row); same distribution as npr.choice,
+ *   not the same stream).  keep / is_fg [n_sample_images, rois_per_image]: rows of
+ *   cand in candidate order, fg first, padded with -1; counts [n_sample_images, 2]
+ *   = (n_fg, n_bg).  Rows of other images (batch index != images[s]) are ignored.
  * Stage 3  wssdl_roi_targets: for the kept rows: labels (bg clamped to 0, :265),
  *   bbox_transform in f32 (:220), expansion to 4*num_classes with inside/outside
  *   weights (:187-210, :89).  keep [n_keep] i32 indexes rois; is_fg [n_keep] u8. */
 WSSDL_API int wssdl_roi_gt_assign(const float *rois, int R, const float *gt_boxes, int max_gt,
                         const int32_t *num_pos_boxes, int n_images, double *max_overlap,
                         int32_t *assignment, wssdl_stream_t stream);
+WSSDL_API int wssdl_roi_sample_device(const float *cand, const double *max_overlap, int Rc,
+                            const int32_t *images, int n_sample_images, int rois_per_image,
+                            int fg_rois_per_image, double fg_thresh, double bg_thresh_hi,
+                            double bg_thresh_lo, uint64_t seed, int32_t *keep, uint8_t *is_fg,
+                            int32_t *counts, wssdl_stream_t stream);
 WSSDL_API int wssdl_roi_targets(const float *rois, const int32_t *keep, const uint8_t *is_fg, int n_keep,
                       const int32_t *assignment, const float *gt_boxes, int max_gt, int num_classes,
                       const float *inside_weights_host /* [4] */, float *rois_out, float *labels,

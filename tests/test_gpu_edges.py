@@ -6,6 +6,7 @@ import pytest
 
 from conftest import load_golden
 from oracle import c_oracle, np_oracle as O
+from test_gpu_parity import ulp_diff_f32
 
 pytestmark = pytest.mark.gpu
 
@@ -283,3 +284,97 @@ def test_nms_large_n_uses_global_kept_list(torch_cuda):
     wh = rs.uniform(10, 80, size=(n, 2))
     d = np.hstack((c, c + wh, rs.permutation(n)[:, None] / float(n))).astype(np.float32)
     assert hip_nms(d, 0.5) == O.nms(d, 0.5)
+
+
+# ---------------------------------------------------------------- device RoI sampling ---
+@pytest.mark.gpu
+def test_proposal_target_device_sampling(torch_cuda):
+    """cfg.SAMPLING_RNG='device' (wssdl_roi_sample_device): not the reference's random stream,
+    so the check is structural -- quotas, thresholds, no duplicates, reproducibility -- and the
+    labels / targets of the drawn rows are compared with the oracle's formulas."""
+    import torch
+    np_oracle = O
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.rpn_msr import proposal_target_layer_tf_bus as ptl
+    g = load_golden("proposal_target")
+    rois, gt, ng = g["rois_in"], g["gt_boxes"], g["num_gt"]
+    n_img = gt.shape[0]
+    dev = torch.device("cuda", 0)
+    rois_d = torch.from_numpy(rois).to(dev)
+    gt_d, ng_d = torch.from_numpy(gt).to(dev), torch.from_numpy(ng.astype(np.int32)).to(dev)
+    old = cfg.SAMPLING_RNG, cfg.DEVICE_RNG_SEED
+    cfg.SAMPLING_RNG = "device"
+    try:
+        runs = []
+        for rep in range(3):
+            cfg.DEVICE_RNG_SEED = 11 if rep < 2 else 12
+            ptl._device_calls[0] = 0
+            o = ptl.proposal_target_layer(rois_d, gt_d, ng_d, 3, True, False)
+            runs.append([t.cpu().numpy() for t in o])
+        a, b, c = runs
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)                      # same seed -> same rows
+        assert not np.array_equal(a[0], c[0])                # another seed -> another draw
+        out_rois, labels, tg, inw, outw = a
+        rpi = int(cfg.TRAIN.BATCH_SIZE)
+        fg_rpi = int(np.round(cfg.TRAIN.FG_FRACTION * rpi))
+        row = 0
+        for i in range(n_img):
+            npos = int(np.sum(gt[i, :ng[i], 4] != 0))
+            cand = np.vstack([rois[rois[:, 0] == i],
+                              np.hstack([np.full((npos, 1), i, np.float32), gt[i, :npos, :4]])])
+            ov = np_oracle.c_oracle.bbox_overlaps(cand[:, 1:5].astype(np.float64),
+                                                  gt[i, :npos, :4].astype(np.float64))
+            mo, am = ov.max(axis=1), ov.argmax(axis=1)
+            n_fg_have = int(np.sum(mo >= cfg.TRAIN.FG_THRESH))
+            n_bg_have = int(np.sum((mo < cfg.TRAIN.BG_THRESH_HI) & (mo >= cfg.TRAIN.BG_THRESH_LO)))
+            n_fg = min(fg_rpi, n_fg_have)
+            n_bg = min(rpi - n_fg, n_bg_have)
+            blk = out_rois[row:row + n_fg + n_bg]
+            assert np.all(blk[:, 0] == i)
+            # every drawn row is a candidate of this image, none twice
+            key = {tuple(r) for r in cand.tolist()}
+            assert all(tuple(r) in key for r in blk.tolist())
+            lookup = {}
+            for j, r in enumerate(cand.tolist()):
+                lookup.setdefault(tuple(r), j)
+            idx = np.array([lookup[tuple(r)] for r in blk.tolist()])
+            # duplicates among candidates share coordinates, hence overlap and targets
+            assert np.all(mo[idx[:n_fg]] >= cfg.TRAIN.FG_THRESH)
+            assert np.all((mo[idx[n_fg:]] < cfg.TRAIN.BG_THRESH_HI) & (mo[idx[n_fg:]] >= cfg.TRAIN.BG_THRESH_LO))
+            lab = labels[row:row + n_fg + n_bg, 0]
+            assert np.array_equal(lab[:n_fg], gt[i, am[idx[:n_fg]], 4])
+            assert np.all(lab[n_fg:] == 0)
+            # targets of the fg rows: bbox_transform in f32, expanded at 4*cls
+            t = np_oracle.bbox_transform(blk[:n_fg, 1:5], gt[i, am[idx[:n_fg]], :4]).astype(np.float32)
+            for q in range(n_fg):
+                cls = int(lab[q])
+                e = np.zeros(12, np.float32)
+                e[4 * cls:4 * cls + 4] = t[q]
+                assert ulp_diff_f32(tg[row + q], e).max() <= 4
+                w = np.zeros(12, np.float32)
+                w[4 * cls:4 * cls + 4] = 1
+                assert np.array_equal(inw[row + q], w) and np.array_equal(outw[row + q], w)
+            assert not tg[row + n_fg:row + n_fg + n_bg].any()
+            row += n_fg + n_bg
+        assert row == out_rois.shape[0]
+        # uniformity smoke: over many seeds every fg candidate of image 0 is drawn sometimes
+        cfg.DEVICE_RNG_SEED = 5
+        seen = set()
+        for rep in range(40):
+            o = ptl.proposal_target_layer(rois_d, gt_d, ng_d, 3, True, False)
+            r0 = o[0].cpu().numpy()
+            l0 = o[1].cpu().numpy()[:, 0]
+            seen |= {tuple(r) for r in r0[(r0[:, 0] == 0) & (l0 > 0)].tolist()}
+        i = 0
+        npos = int(np.sum(gt[i, :ng[i], 4] != 0))
+        cand = np.vstack([rois[rois[:, 0] == i],
+                          np.hstack([np.full((npos, 1), i, np.float32), gt[i, :npos, :4]])])
+        mo = np_oracle.c_oracle.bbox_overlaps(cand[:, 1:5].astype(np.float64),
+                                              gt[i, :npos, :4].astype(np.float64)).max(axis=1)
+        fg_all = {tuple(r) for r in cand[mo >= cfg.TRAIN.FG_THRESH].tolist()}
+        if len(fg_all) > fg_rpi:
+            assert len(seen) > fg_rpi                        # not always the same subset
+        assert seen <= fg_all
+    finally:
+        cfg.SAMPLING_RNG, cfg.DEVICE_RNG_SEED = old

@@ -49,6 +49,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--joint", action="store_true",
+                    help="RoI set of the combined mini-batch: first half of the images keep 128 RoIs "
+                         "(supervised, sampled), the rest keep all their proposals (weak)")
     args = ap.parse_args()
     A = 9
     if args.config == 5:
@@ -68,6 +71,13 @@ def main():
     out.append(dict(op="proposal_layer", ms=ms, images=N, rois=int(cnt.sum()),
                     images_per_s=N / ms * 1e3))
     rois = compact_rois(rois_p, counts)
+    if args.joint:
+        b = rois[:, 0]
+        keep = torch.zeros_like(b, dtype=torch.bool)
+        for i in range(N):
+            idx = torch.nonzero(b == i).flatten()
+            keep[idx if i >= N // 2 else idx[:128]] = True
+        rois = rois[keep].contiguous()
     R = rois.shape[0]
 
     # RoI pool forward / backward

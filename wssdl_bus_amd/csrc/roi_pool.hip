@@ -27,10 +27,12 @@
 #include "common.hip.h"
 
 #include <float.h>
+#include <stdlib.h>
 
 // cache policy of the backward's streaming loads: 0 = default.  nt (2) was measured 5 % slower:
 // the bins re-read by neighbouring tiles profit from staying in L2.
 #define WSSDL_LD_AUX 0
+
 
 namespace wssdl {
 
@@ -224,11 +226,13 @@ struct TouchRec {
     unsigned long long rowmask, colmask;
 };
 constexpr unsigned TOUCH_GENERIC = 0xffu;
+constexpr long long BWD_MIN_WORKGROUPS = 1024;   // one per workgroup slot of the chip (256 CUs x 4)
 
-template <int TN>
+template <int TN, int FW = 8>
 __device__ __forceinline__ void touch_axis(int t0, int t1, int rs, int re, float bin, int P, int &p0,
                                            int &pn, unsigned long long &mask) {
-    // tile cells t0..t1 (inclusive, <= TN of them), RoI cells rs..re
+    // tile cells t0..t1 (inclusive, <= TN of them), RoI cells rs..re; mask bit FW*k + j
+    static_assert(TN <= FW && FW * 8 <= 64, "one FW-bit field per candidate bin");
     const int lo = max(t0, rs), hi = min(t1, re);
     int s[TN], e[TN];
 #pragma unroll
@@ -247,7 +251,7 @@ __device__ __forceinline__ void touch_axis(int t0, int t1, int rs, int re, float
     for (int k = 0; k < 8; ++k)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-            if (a + k >= s[j] && a + k < e[j]) mask |= 1ull << (8 * k + j);
+            if (a + k >= s[j] && a + k < e[j]) mask |= 1ull << (FW * k + j);
 }
 
 
@@ -263,7 +267,7 @@ struct WalkCtx {
 // code, 2*NROWS*PWN buffer loads issued back to back (scalar descriptor + scalar bin offset +
 // lane offset), then the in-order accumulation.  PWN and NROWS are compile-time so that no
 // slot needs a predicate; the caller switches on the (wave-uniform) column count.
-template <int PWN, int NROWS, int TW, int CG, bool FAST>
+template <int PWN, int NROWS, int TW, int CG, bool FAST, int FWR = 8>
 __device__ __forceinline__ void visit_rows(const WalkCtx &x, __amdgpu_buffer_rsrc_t ra,
                                            __amdgpu_buffer_rsrc_t rt, int so_row, int bin_bytes,
                                            int row_bytes, unsigned long long rowmask, int row0,
@@ -286,7 +290,7 @@ __device__ __forceinline__ void visit_rows(const WalkCtx &x, __amdgpu_buffer_rsr
         for (int j = 0; j < PWN; ++j) asm volatile("" : "+v"(idx[q][j]), "+v"(td[q][j]));
 #pragma unroll
     for (int q = 0; q < NROWS; ++q) {
-        const unsigned rm = (unsigned)(rowmask >> (8 * (row0 + q))) & 0xffu;
+        const unsigned rm = (unsigned)(rowmask >> (FWR * (row0 + q))) & ((1u << FWR) - 1u);
 #pragma unroll
         for (int j = 0; j < PWN; ++j) {
             const unsigned cmk = (unsigned)(colmask >> (8 * j)) & 0xffu;
@@ -315,16 +319,16 @@ __device__ __forceinline__ void visit_rows(const WalkCtx &x, __amdgpu_buffer_rsr
     }
 }
 
-template <int PWN, int TW, int CG, bool FAST>
+template <int PWN, int TW, int CG, bool FAST, int FWR = 8>
 __device__ __forceinline__ void visit_roi(const WalkCtx &x, __amdgpu_buffer_rsrc_t ra,
                                           __amdgpu_buffer_rsrc_t rt, int so_row, int bin_bytes,
                                           int row_bytes, unsigned long long rowmask, int phn,
                                           unsigned long long colmask) {
     int rb = 0;
     for (; rb + 2 <= phn; rb += 2, so_row += 2 * row_bytes)
-        visit_rows<PWN, 2, TW, CG, FAST>(x, ra, rt, so_row, bin_bytes, row_bytes, rowmask, rb, colmask);
+        visit_rows<PWN, 2, TW, CG, FAST, FWR>(x, ra, rt, so_row, bin_bytes, row_bytes, rowmask, rb, colmask);
     if (rb < phn)
-        visit_rows<PWN, 1, TW, CG, FAST>(x, ra, rt, so_row, bin_bytes, row_bytes, rowmask, rb, colmask);
+        visit_rows<PWN, 1, TW, CG, FAST, FWR>(x, ra, rt, so_row, bin_bytes, row_bytes, rowmask, rb, colmask);
 }
 
 // FAST: C is a power of two (idx -> cell by shift) and cell / W fits a 24-bit multiply.
@@ -341,6 +345,7 @@ __global__ __launch_bounds__(CG) void roi_pool_bwd_kernel(
     __shared__ float acc[TH * TW * CG];
     __shared__ TouchRec list[CHUNK];
     __shared__ int wave_cnt[KPT][NW];
+    __shared__ int roi_span[2];
 
     // Workgroup -> (image, channel group, tile).  Workgroups are dealt round-robin over the 8
     // XCDs (blockIdx % 8; observed, used for speed only): all tiles of one (image, channel
@@ -373,7 +378,20 @@ __global__ __launch_bounds__(CG) void roi_pool_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < TH * TW; ++i) acc[i * CG + tc] = 0.0f;
 
-    for (int base = 0; base < R; base += CHUNK) {
+    // ---- the span of RoI indices that belong to image n: the filter rounds below only scan
+    // that (RoIs normally arrive grouped by image; any order stays correct)
+    if (tc == 0) { roi_span[0] = R; roi_span[1] = -1; }
+    __syncthreads();
+    {
+        int lo = R, hi = -1;
+        for (int r = tc; r < R; r += CG)
+            if ((int)rois[(size_t)r * 5] == n) { lo = min(lo, r); hi = r; }
+        if (hi >= 0) { atomicMin(&roi_span[0], lo); atomicMax(&roi_span[1], hi); }
+    }
+    __syncthreads();
+    const int r_begin = roi_span[0], r_end = roi_span[1] + 1;
+
+    for (int base = r_begin; base < r_end; base += CHUNK) {
         // ---- filter: RoIs of image n whose rounded box touches the tile, in RoI order.
         // The thread that tests a RoI also evaluates the reference's candidate-bin formulas
         // for the tile's rows and columns once, so the walk below only tests bit masks.
@@ -383,7 +401,7 @@ __global__ __launch_bounds__(CG) void roi_pool_bwd_kernel(
         for (int k = 0; k < KPT; ++k) {
             const int r = base + k * CG + tc;
             hit[k] = false;
-            if (r < R) {
+            if (r < r_end) {
                 gk[k] = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);
                 const RoiGeom &g = gk[k];
                 hit[k] = (g.batch == n) && g.sw <= w1 && g.ew >= w0 && g.sh <= h1 && g.eh >= h0;
@@ -610,11 +628,20 @@ extern "C" int wssdl_roi_pool_backward(const float *top_diff, const int32_t *arg
         return WSSDL_ERR_INVALID_ARGUMENT;
     hipStream_t st = as_stream(stream);
     // 4x8-cell tiles: 32 KiB of LDS per 256-channel workgroup -> 16 waves per CU (8x8 tiles
-    // re-read 14 % less but halve the occupancy: 2.9 ms vs 2.1 ms at R = 16000, C = 1024)
-    if (C > 128)
+    // re-read 14 % less but halve the occupancy: 2.9 ms vs 2.1 ms at R = 16000, C = 1024).
+    // Channels per workgroup: 256 when that still yields enough workgroups to fill the chip,
+    // fewer otherwise (small batches / narrow feature maps).
+    int cg = C > 128 ? 256 : (C > 64 ? 128 : 64);
+    const long long tiles = (long long)cdiv(H, 4) * cdiv(W, 8);
+    while (cg > 64 && (long long)N * cdiv(C, cg) * tiles < BWD_MIN_WORKGROUPS) cg >>= 1;
+    if (const char *e = getenv("WSSDL_ROI_BWD_CG")) {       // tuning override
+        const int v = atoi(e);
+        if (v == 64 || v == 128 || v == 256) cg = v;
+    }
+    if (cg == 256)
         return launch_bwd<4, 8, 256, 256>(top_diff, argmax, rois, R, N, H, W, C, pooled_h, pooled_w,
                                           spatial_scale, bottom_diff, st);
-    if (C > 64)
+    if (cg == 128)
         return launch_bwd<4, 8, 128, 256>(top_diff, argmax, rois, R, N, H, W, C, pooled_h, pooled_w,
                                           spatial_scale, bottom_diff, st);
     return launch_bwd<4, 8, 64, 128>(top_diff, argmax, rois, R, N, H, W, C, pooled_h, pooled_w,

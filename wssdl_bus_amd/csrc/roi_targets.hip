@@ -9,6 +9,11 @@
 //                 and first arg-max.  The random fg/bg sampling between the two
 //                 kernels belongs to the host layer (it consumes numpy's legacy
 //                 RandomState stream in the reference).
+// roi_sample    : the device alternative to that host step (cfg.SAMPLING_RNG =
+//                 'device'): one workgroup per supervised image draws exactly
+//                 min(quota, #) fg and bg rows by 64-bit radix select on
+//                 counter-based hash keys; rows come out in candidate order
+//                 (fg first), so a run is reproducible from the seed alone.
 // roi_targets   : one lane per sampled RoI: label (background clamped to 0, :265),
 //                 all-f32 bbox_transform (:220), expansion into the 4*num_classes
 //                 layout with inside / outside weights (:199-209, :89).
@@ -99,6 +104,144 @@ __global__ __launch_bounds__(256) void roi_targets_kernel(
     labels[p] = label;
 }
 
+// ------------------------------------------------------- device sampling ---
+constexpr int RS_BLOCK = 1024;
+
+__device__ __forceinline__ unsigned long long rs_mix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// unique per candidate: hash in the high word, candidate index in the low word
+__device__ __forceinline__ unsigned long long rs_key(unsigned long long seed, int img, int i) {
+    unsigned long long h = rs_mix64(seed ^ rs_mix64(((unsigned long long)(unsigned)img << 34) ^ (unsigned)i));
+    return (h & 0xFFFFFFFF00000000ull) | (unsigned)i;
+}
+
+struct RoiClassifier {          // _sample_rois :241, :253-254
+    const float *cand;
+    const double *ov;
+    int img;
+    double fg_thresh, bg_hi, bg_lo;
+    // 1 = fg, 0 = bg, -1 = neither / other image
+    __device__ __forceinline__ int operator()(int i) const {
+        if ((int)cand[(size_t)i * 5] != img) return -1;
+        const double o = ov[i];
+        if (o >= fg_thresh) return 1;
+        return (o < bg_hi && o >= bg_lo) ? 0 : -1;
+    }
+};
+
+// key of the quota-th smallest among the candidates of class `which` (all of them when there
+// are no more than quota: returns ~0)
+__device__ unsigned long long rs_select(const RoiClassifier &cls, int Rc, int which, int n_have,
+                                        int quota, unsigned long long seed, int *hist,
+                                        int *s_scalar) {
+    if (n_have <= quota) return ~0ull;
+    const int t = threadIdx.x;
+    unsigned long long prefix = 0ull, pmask = 0ull;
+    int want = quota;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        if (t < 256) hist[t] = 0;
+        __syncthreads();
+        for (int i = t; i < Rc; i += RS_BLOCK) {
+            if (cls(i) != which) continue;
+            const unsigned long long k = rs_key(seed, cls.img, i);
+            if ((k & pmask) == prefix) atomicAdd(&hist[(int)((k >> shift) & 0xff)], 1);
+        }
+        __syncthreads();
+        if (t == 0) {
+            int acc = 0, b = 0;
+            for (; b < 256; ++b) {
+                if (acc + hist[b] >= want) break;
+                acc += hist[b];
+            }
+            s_scalar[0] = b;
+            s_scalar[1] = want - acc;
+        }
+        __syncthreads();
+        prefix |= (unsigned long long)s_scalar[0] << shift;
+        pmask |= 0xffull << shift;
+        want = s_scalar[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+__device__ int rs_block_exclusive_scan(int v, int *s_wave, int &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < RS_BLOCK / 64; ++w) {
+        const int x = s_wave[w];
+        base += (w < wave) ? x : 0;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(RS_BLOCK) void roi_sample_kernel(
+    const float *__restrict__ cand, const double *__restrict__ max_overlap, int Rc,
+    const int *__restrict__ images, int rois_per_image, int fg_rois_per_image, double fg_thresh,
+    double bg_hi, double bg_lo, unsigned long long seed, int *__restrict__ keep,
+    unsigned char *__restrict__ is_fg, int *__restrict__ counts) {
+    __shared__ int hist[256];
+    __shared__ int s_scalar[2];
+    __shared__ int s_wave[RS_BLOCK / 64];
+    const int s = blockIdx.x, t = threadIdx.x;
+    RoiClassifier cls;
+    cls.cand = cand;  cls.ov = max_overlap;  cls.img = images[s];
+    cls.fg_thresh = fg_thresh;  cls.bg_hi = bg_hi;  cls.bg_lo = bg_lo;
+    // each thread owns a contiguous slice so that the output keeps the candidate order
+    const int per = (Rc + RS_BLOCK - 1) / RS_BLOCK;
+    const int i0 = min(t * per, Rc), i1 = min(i0 + per, Rc);
+    int cf = 0, cb = 0;
+    for (int i = i0; i < i1; ++i) {
+        const int c = cls(i);
+        cf += c == 1;
+        cb += c == 0;
+    }
+    int have_fg, have_bg;
+    rs_block_exclusive_scan(cf, s_wave, have_fg);
+    rs_block_exclusive_scan(cb, s_wave, have_bg);
+    const int n_fg = min(fg_rois_per_image, have_fg);                 // :243
+    const int n_bg = min(rois_per_image - n_fg, have_bg);             // :256-258
+    const unsigned long long t_fg = rs_select(cls, Rc, 1, have_fg, n_fg, seed, hist, s_scalar);
+    const unsigned long long t_bg = rs_select(cls, Rc, 0, have_bg, n_bg, seed ^ 0x5bd1e995ull, hist, s_scalar);
+    cf = cb = 0;
+    if (n_fg > 0 || n_bg > 0)
+        for (int i = i0; i < i1; ++i) {
+            const int c = cls(i);
+            if (c == 1) cf += (n_fg > 0 && rs_key(seed, cls.img, i) <= t_fg);
+            else if (c == 0) cb += (n_bg > 0 && rs_key(seed ^ 0x5bd1e995ull, cls.img, i) <= t_bg);
+        }
+    int tot;
+    int pf = rs_block_exclusive_scan(cf, s_wave, tot);
+    int pb = n_fg + rs_block_exclusive_scan(cb, s_wave, tot);
+    int *kp = keep + (size_t)s * rois_per_image;
+    unsigned char *fp = is_fg + (size_t)s * rois_per_image;
+    if (n_fg > 0 || n_bg > 0)
+        for (int i = i0; i < i1; ++i) {
+            const int c = cls(i);
+            if (c == 1 && n_fg > 0 && rs_key(seed, cls.img, i) <= t_fg) { kp[pf] = i; fp[pf] = 1; ++pf; }
+            else if (c == 0 && n_bg > 0 && rs_key(seed ^ 0x5bd1e995ull, cls.img, i) <= t_bg) { kp[pb] = i; fp[pb] = 0; ++pb; }
+        }
+    for (int p = n_fg + n_bg + t; p < rois_per_image; p += RS_BLOCK) { kp[p] = -1; fp[p] = 0; }
+    if (t == 0) { counts[2 * s] = n_fg; counts[2 * s + 1] = n_bg; }
+}
+
 }  // namespace wssdl
 
 using namespace wssdl;
@@ -130,5 +273,23 @@ extern "C" int wssdl_roi_targets(const float *rois, const int32_t *keep, const u
                        rois, keep, is_fg, n_keep, assignment, gt_boxes, max_gt, num_classes,
                        inside_weights_host[0], inside_weights_host[1], inside_weights_host[2],
                        inside_weights_host[3], rois_out, labels, bbox_targets, inside_w, outside_w);
+    return check_launch();
+}
+
+extern "C" int wssdl_roi_sample_device(const float *cand, const double *max_overlap, int Rc,
+                                       const int32_t *images, int n_sample_images,
+                                       int rois_per_image, int fg_rois_per_image, double fg_thresh,
+                                       double bg_thresh_hi, double bg_thresh_lo, uint64_t seed,
+                                       int32_t *keep, uint8_t *is_fg, int32_t *counts,
+                                       wssdl_stream_t stream) {
+    if (Rc < 0 || n_sample_images < 0 || rois_per_image < 1 || fg_rois_per_image < 0 ||
+        fg_rois_per_image > rois_per_image)
+        return WSSDL_ERR_INVALID_ARGUMENT;
+    if (n_sample_images == 0) return WSSDL_OK;
+    if (!images || !keep || !is_fg || !counts || (Rc > 0 && (!cand || !max_overlap)))
+        return WSSDL_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(roi_sample_kernel, dim3(n_sample_images), dim3(RS_BLOCK), 0, as_stream(stream),
+                       cand, max_overlap, Rc, images, rois_per_image, fg_rois_per_image, fg_thresh,
+                       bg_thresh_hi, bg_thresh_lo, (unsigned long long)seed, keep, is_fg, counts);
     return check_launch();
 }

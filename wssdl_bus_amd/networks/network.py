@@ -36,6 +36,15 @@ def layer(op):
     return layer_decorated
 
 
+def _blob(out):
+    """[-1, 5] view of a proposal blob that keeps its per-image row-count tag."""
+    r = out.reshape(-1, 5)
+    c = getattr(out, "_wssdl_counts", None)
+    if c is not None:
+        r._wssdl_counts = c
+    return r
+
+
 def _first(x):
     # "only use the first input": a tuple-valued layer (e.g. 'roi-data') feeds its element 0
     return x[0] if isinstance(x, tuple) else x
@@ -82,7 +91,7 @@ class Network(object):
         with torch.no_grad():
             out = proposal_layer_py(_first(input[0]).detach(), input[1].detach(), input[2],
                                     is_training, is_ws, _feat_stride, anchor_scales)
-        return out.reshape(-1, 5)
+        return _blob(out)
 
     @layer
     def proposal_layer_from_score(self, input, _feat_stride, anchor_scales, is_training, is_ws, name):
@@ -90,7 +99,7 @@ class Network(object):
         with torch.no_grad():
             out = proposal_layer_from_score_py(_first(input[0]).detach(), input[1].detach(), input[2],
                                                is_training, is_ws, _feat_stride, anchor_scales)
-        return out.reshape(-1, 5)
+        return _blob(out)
 
     @layer
     def anchor_target_layer(self, input, _feat_stride, anchor_scales, dataset, is_ws, name):

@@ -79,6 +79,9 @@ def compact_rois(rois_padded, counts, counts_host=None):
         _lib.check(_lib.lib().wssdl_proposal_compact(_lib.ptr(rois_padded), _lib.ptr(counts), N, P,
                                                      _lib.ptr(out), total, _lib.stream()),
                    "wssdl_proposal_compact")
+    # rows are grouped by image: let the proposal-target layer reuse the counts instead of
+    # reading the batch column back
+    out._wssdl_counts = tuple(int(c) for c in counts_host)
     return out
 
 

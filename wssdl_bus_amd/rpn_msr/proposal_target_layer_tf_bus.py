@@ -8,7 +8,10 @@ Device work: f64 IoU of every candidate RoI (proposals + appended gt boxes) agai
 its image's positive gt boxes with max / arg-max (``wssdl_roi_gt_assign``), then
 gather + labels + bbox_transform + class expansion for the sampled rows
 (``wssdl_roi_targets``).  The fg/bg sampling between the two consumes
-``numpy.random`` exactly like the reference (same seed and call order => same rows).
+``numpy.random`` exactly like the reference (same seed and call order => same rows);
+with ``cfg.SAMPLING_RNG = 'device'`` it is ``wssdl_roi_sample_device`` instead (same
+distribution, counter-based device RNG) and the layer needs no host copy of the
+candidates: one 8-byte-per-image read-back of the row counts is its only sync.
 """
 import numpy as np
 import numpy.random as npr
@@ -18,6 +21,24 @@ from .. import _lib
 from ..fast_rcnn.config import cfg
 
 DEBUG = False
+_device_calls = [0]
+
+
+def tag_counts(rois, counts):
+    """Remember the per-image row counts of a proposal blob (rows are grouped by image,
+    ascending) so that the layers below need not read the batch column back."""
+    try:
+        rois._wssdl_counts = tuple(int(c) for c in counts)
+    except Exception:
+        pass
+    return rois
+
+
+def _counts_hint(rois, n_images):
+    c = getattr(rois, "_wssdl_counts", None)
+    if c is None or len(c) < n_images or sum(c) != rois.shape[0]:
+        return None
+    return c
 
 
 def _host_gt(gt_boxes, num_gt_boxes):
@@ -41,6 +62,73 @@ def _supervised(rois, gt_dev, gt_host, ng_host, images, append_gt, num_classes, 
     """Sampled rows for the supervised `images` (in that order), all on the GPU."""
     with _lib.timed("proposal_target_layer", dict(R=int(rois.shape[0]), images=len(images))):
         return _supervised_impl(rois, gt_dev, gt_host, ng_host, images, append_gt, num_classes, rng)
+
+
+def _supervised_device(rois, gt_dev, ng_dev, images, append_gt, num_classes):
+    """cfg.SAMPLING_RNG == 'device': everything stays on the GPU."""
+    with _lib.timed("proposal_target_layer", dict(R=int(rois.shape[0]), images=len(images))):
+        dev = rois.device
+        n_img, max_gt = gt_dev.shape[0], gt_dev.shape[1]
+        L = _lib.lib()
+        S = len(images)
+        rpi = int(cfg.TRAIN.BATCH_SIZE) // 1
+        fg_rpi = int(np.round(cfg.TRAIN.FG_FRACTION * rpi))
+        iw = np.ascontiguousarray(cfg.TRAIN.BBOX_INSIDE_WEIGHTS, dtype=np.float32)
+        with torch.cuda.device(dev):
+            ar = torch.arange(max_gt, device=dev)
+            valid = ar[None, :] < ng_dev[:, None].to(torch.int64)
+            num_pos_dev = ((gt_dev[:, :, 4] != 0) & valid).sum(dim=1).to(torch.int32)
+            images_dev = torch.as_tensor(list(images), dtype=torch.int32, device=dev)
+            if append_gt and S > 0:                                    # :44-50
+                # every gt slot of the supervised images is appended; slots past the image's
+                # positives carry batch index -1 and can never be drawn
+                sel = images_dev.to(torch.int64)
+                g = gt_dev.index_select(0, sel)                         # [S, max_gt, 5]
+                pos = ar[None, :] < num_pos_dev.index_select(0, sel)[:, None].to(torch.int64)
+                b = torch.where(pos, sel[:, None].to(torch.float32).expand(S, max_gt),
+                                torch.full((), -1.0, device=dev))
+                extra = torch.cat([b[:, :, None], g[:, :, :4]], dim=2).reshape(S * max_gt, 5)
+                cand = torch.cat([rois, extra], dim=0).contiguous()
+            else:
+                cand = rois
+            Rc = cand.shape[0]
+            max_ov = torch.empty((Rc,), dtype=torch.float64, device=dev)
+            assign = torch.empty((Rc,), dtype=torch.int32, device=dev)
+            _lib.check(L.wssdl_roi_gt_assign(_lib.ptr(cand), Rc, _lib.ptr(gt_dev), max_gt,
+                                             _lib.ptr(num_pos_dev), n_img, _lib.ptr(max_ov),
+                                             _lib.ptr(assign), _lib.stream()), "wssdl_roi_gt_assign")
+            keep = torch.empty((S, rpi), dtype=torch.int32, device=dev)
+            is_fg = torch.empty((S, rpi), dtype=torch.uint8, device=dev)
+            counts = torch.empty((S, 2), dtype=torch.int32, device=dev)
+            _device_calls[0] += 1
+            seed = (int(cfg.DEVICE_RNG_SEED) * 0x9E3779B1 + 0x51ED27 * _device_calls[0]) & 0xFFFFFFFFFFFFFFFF
+            _lib.check(L.wssdl_roi_sample_device(
+                _lib.ptr(cand), _lib.ptr(max_ov), Rc, _lib.ptr(images_dev), S, rpi, fg_rpi,
+                float(cfg.TRAIN.FG_THRESH), float(cfg.TRAIN.BG_THRESH_HI),
+                float(cfg.TRAIN.BG_THRESH_LO), seed, _lib.ptr(keep), _lib.ptr(is_fg),
+                _lib.ptr(counts), _lib.stream()), "wssdl_roi_sample_device")
+            n_rows = counts.sum(dim=1).cpu().numpy()                    # the layer's one sync
+            if int(n_rows.sum()) == S * rpi:
+                keep_flat, fg_flat = keep.reshape(-1), is_fg.reshape(-1)
+            else:                                                       # an image ran short of bg rows
+                m = keep.reshape(-1) >= 0
+                keep_flat, fg_flat = keep.reshape(-1)[m].contiguous(), is_fg.reshape(-1)[m].contiguous()
+            n_keep = int(n_rows.sum())
+            out_rois = torch.empty((n_keep, 5), dtype=torch.float32, device=dev)
+            labels = torch.empty((n_keep, 1), dtype=torch.float32, device=dev)
+            tg = torch.empty((n_keep, 4 * num_classes), dtype=torch.float32, device=dev)
+            inw = torch.empty_like(tg)
+            outw = torch.empty_like(tg)
+            _lib.check(L.wssdl_roi_targets(
+                _lib.ptr(cand), _lib.ptr(keep_flat), _lib.ptr(fg_flat), n_keep, _lib.ptr(assign),
+                _lib.ptr(gt_dev), max_gt, int(num_classes), _lib.host_ptr(iw),
+                _lib.ptr(out_rois), _lib.ptr(labels), _lib.ptr(tg), _lib.ptr(inw), _lib.ptr(outw),
+                _lib.stream()), "wssdl_roi_targets")
+        return [out_rois, labels, tg, inw, outw]
+
+
+def _use_device_rng(rng):
+    return cfg.SAMPLING_RNG == "device" and rng is None
 
 
 def _supervised_impl(rois, gt_dev, gt_host, ng_host, images, append_gt, num_classes, rng):
@@ -115,6 +203,16 @@ def _supervised_impl(rois, gt_dev, gt_host, ng_host, images, append_gt, num_clas
     return [out_rois, labels, tg, inw, outw], batch_host[:R]
 
 
+def _rois_of_images_hinted(rois, counts, images):
+    """Same selection when the rows are known to be grouped by image (counts hint)."""
+    off = np.concatenate([[0], np.cumsum(counts)])
+    images = list(images)
+    if images and images == list(range(images[0], images[-1] + 1)):
+        return rois[int(off[images[0]]):int(off[images[-1] + 1])]
+    parts = [rois[int(off[i]):int(off[i + 1])] for i in images]
+    return torch.cat(parts, dim=0) if parts else rois[:0]
+
+
 def _rois_of_images(rois, batch_host, images):
     """rpn_rois[rpn_rois[:,0]==i] for each i in order, concatenated (on the GPU)."""
     idx = [np.where(batch_host == i)[0] for i in images]
@@ -130,26 +228,39 @@ def _finish(outs, as_np):
     return tuple(outs)
 
 
+def _weak_rois(rpn_rois, rois, images):
+    """Rows of the weak `images`, in order (hint from the proposal layer, else read-back)."""
+    images = list(images)
+    hint = _counts_hint(rpn_rois, images[-1] + 1) if (images and isinstance(rpn_rois, torch.Tensor)) else None
+    if hint is not None:
+        return _rois_of_images_hinted(rois, hint, images)
+    return _rois_of_images(rois, rois[:, 0].cpu().numpy(), images)
+
+
 def proposal_target_layer(rpn_rois, gt_boxes, num_gt_boxes, _num_classes, is_training, is_ws,
                           rng=None):
     """Alternating mode (:15-97).  Weak batches (is_training and is_ws) return every
     RoI with zero labels / targets (:282-295)."""
     as_np = _lib.wants_numpy(rpn_rois)
+    device_rng = _use_device_rng(rng)
     rng = npr if rng is None else rng
     rois = _lib.to_device(rpn_rois, torch.float32)
     dev = rois.device
-    gt_host, ng_host = _host_gt(gt_boxes, num_gt_boxes)
-    n_img = gt_host.shape[0]
+    n_img = int(gt_boxes.shape[0])
     K = int(_num_classes)
     if is_training and is_ws:
-        batch_host = rois[:, 0].cpu().numpy()
-        r = _rois_of_images(rois, batch_host, range(n_img))
+        r = _weak_rois(rpn_rois, rois, range(n_img))
         n = r.shape[0]
         z = lambda w: torch.zeros((n, w), dtype=torch.float32, device=dev)
         return _finish([r, z(1), z(4 * K), z(4 * K), z(4 * K)], as_np)
     gt_dev = _lib.to_device(gt_boxes, torch.float32, dev)
-    outs, _ = _supervised(rois, gt_dev, gt_host, ng_host, list(range(n_img)),
-                          bool(is_training) and not bool(is_ws), K, rng)
+    append_gt = bool(is_training) and not bool(is_ws)
+    if device_rng:
+        outs = _supervised_device(rois, gt_dev, _lib.to_device(num_gt_boxes, torch.int32, dev),
+                                  list(range(n_img)), append_gt, K)
+        return _finish(outs, as_np)
+    gt_host, ng_host = _host_gt(gt_boxes, num_gt_boxes)
+    outs, _ = _supervised(rois, gt_dev, gt_host, ng_host, list(range(n_img)), append_gt, K, rng)
     return _finish(outs, as_np)
 
 
@@ -159,17 +270,22 @@ def proposal_target_layer_joint(rpn_rois, gt_boxes, num_gt_boxes, _num_classes, 
     images; when training, the *rois* of the cfg.TRAIN.WS_IMS_PER_BATCH weak images
     are appended to the rois output only (:162-182)."""
     as_np = _lib.wants_numpy(rpn_rois)
+    device_rng = _use_device_rng(rng)
     rng = npr if rng is None else rng
     rois = _lib.to_device(rpn_rois, torch.float32)
     dev = rois.device
-    gt_host, ng_host = _host_gt(gt_boxes, num_gt_boxes)
     gt_dev = _lib.to_device(gt_boxes, torch.float32, dev)
     n_s = int(cfg.TRAIN.IMS_PER_BATCH)
-    outs, batch_host = _supervised(rois, gt_dev, gt_host, ng_host, list(range(n_s)),
-                                   bool(is_training), int(_num_classes), rng)
+    ws_images = range(n_s, n_s + int(cfg.TRAIN.WS_IMS_PER_BATCH))
+    if device_rng:
+        outs = _supervised_device(rois, gt_dev, _lib.to_device(num_gt_boxes, torch.int32, dev),
+                                  list(range(n_s)), bool(is_training), int(_num_classes))
+        ws = _weak_rois(rpn_rois, rois, ws_images) if is_training else None
+    else:
+        gt_host, ng_host = _host_gt(gt_boxes, num_gt_boxes)
+        outs, batch_host = _supervised(rois, gt_dev, gt_host, ng_host, list(range(n_s)),
+                                       bool(is_training), int(_num_classes), rng)
+        ws = _rois_of_images(rois, batch_host, ws_images) if is_training else None
     if is_training:
-        ws = _rois_of_images(rois, batch_host, range(n_s, n_s + int(cfg.TRAIN.WS_IMS_PER_BATCH)))
-        if ws is rois:
-            ws = rois
         outs[0] = torch.cat([outs[0], ws.reshape(-1, 5)], dim=0)
     return _finish(outs, as_np)
