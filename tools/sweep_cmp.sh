@@ -4,7 +4,7 @@ python -m pytest tests -m gpu -x -q -k "nms or proposal or detect or train" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_sw -- python3 bench.py --steps 4 --warmup 3 --no-cpu-baseline > gpurun_out/prof_sw.log 2>&1
 python3 - <<PY
 import csv,glob
-f=sorted(glob.glob("gpurun_out/prof_sw/**/*kernel_stats.csv", recursive=True))[-1]
+import os; f=max(glob.glob("gpurun_out/prof_sw/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
 for r in csv.DictReader(open(f)):
     if "nms_" in r["Name"] or "topk" in r["Name"]: print("%-44s calls=%4s avg_us=%9.2f" % (r["Name"][:44], r["Calls"], float(r["AverageNs"])/1e3))
 PY

@@ -22,6 +22,7 @@
 //                    [n,4A,H,W] blobs; lanes run along W so all 13 output planes
 //                    are written with coalesced stores (13*A*K*4 B per image).
 #include "common.hip.h"
+#include "select.hip.h"
 
 namespace wssdl {
 
@@ -224,79 +225,44 @@ __device__ __forceinline__ unsigned long long sample_key(unsigned long long seed
 }
 
 constexpr int SS_BLOCK = 1024;
+constexpr int SS_LIST = 512;
 
 // keep exactly `quota` of the anchors with label == which (those with the smallest
-// keys); the rest become -1.  No-op when there are <= quota of them.
-__device__ void subsample_one(signed char *lab, int total, int which, int quota,
-                              unsigned long long seed, int img, int phase, int *hist,
-                              int *s_scalar) {
+// keys); the rest become -1.  No-op when there are <= quota of them.  Returns how many remain.
+__device__ int subsample_one(signed char *lab, int total, int which, int quota,
+                              unsigned long long seed, int img, int phase,
+                              SelectScratch<SS_LIST> &sc) {
     const int t = threadIdx.x;
-    if (t == 0) s_scalar[0] = 0;
-    __syncthreads();
-    int c = 0;
-    for (int i = t; i < total; i += SS_BLOCK) c += (lab[i] == which) ? 1 : 0;
-    atomicAdd(&s_scalar[0], c);
-    __syncthreads();
-    const int n = s_scalar[0];
-    __syncthreads();
-    if (n <= quota) return;
+    int n = 0;
+    // the quota-th smallest key (keys are unique) when there are more than quota members
+    const unsigned long long cut = block_radix_select<SS_BLOCK, SS_LIST, false>(
+        [=](int i, unsigned long long &v) {
+            if (lab[i] != which) return false;
+            v = sample_key(seed, img, phase, i);
+            return true;
+        }, total, [quota](int members) { return (members > quota && quota > 0) ? quota : 0; }, sc, &n);
+    if (n <= quota) return n;
     if (quota <= 0) {
         for (int i = t; i < total; i += SS_BLOCK)
             if (lab[i] == which) lab[i] = -1;
         __syncthreads();
-        return;
+        return 0;
     }
-    // radix-select the quota-th smallest key, 8 bits per pass, MSB first
-    unsigned long long prefix = 0ull, pmask = 0ull;
-    int want = quota;   // rank (1-based) inside the current prefix bucket
-    for (int shift = 56; shift >= 0; shift -= 8) {
-        if (t < 256) hist[t] = 0;
-        __syncthreads();
-        for (int i = t; i < total; i += SS_BLOCK) {
-            if (lab[i] != which) continue;
-            unsigned long long k = sample_key(seed, img, phase, i);
-            if ((k & pmask) == prefix) atomicAdd(&hist[(int)((k >> shift) & 0xff)], 1);
-        }
-        __syncthreads();
-        if (t == 0) {
-            int acc = 0, b = 0;
-            for (; b < 256; ++b) {
-                if (acc + hist[b] >= want) break;
-                acc += hist[b];
-            }
-            s_scalar[1] = b;
-            s_scalar[2] = want - acc;
-        }
-        __syncthreads();
-        prefix |= (unsigned long long)s_scalar[1] << shift;
-        pmask |= 0xffull << shift;
-        want = s_scalar[2];
-        __syncthreads();
-    }
-    // prefix is now the quota-th smallest key (keys are unique)
     for (int i = t; i < total; i += SS_BLOCK)
-        if (lab[i] == which && sample_key(seed, img, phase, i) > prefix) lab[i] = -1;
+        if (lab[i] == which && sample_key(seed, img, phase, i) > cut) lab[i] = -1;
     __syncthreads();
+    return quota;
 }
 
 __global__ __launch_bounds__(SS_BLOCK) void anchor_subsample_kernel(signed char *labels, int total,
                                                                     int batchsize, int num_fg,
                                                                     unsigned long long seed) {
-    __shared__ int hist[256];
-    __shared__ int s_scalar[4];
+    __shared__ SelectScratch<SS_LIST> sc;
     const int img = blockIdx.x;
     signed char *lab = labels + (size_t)img * total;
-    subsample_one(lab, total, 1, num_fg, seed, img, 0, hist, s_scalar);      // :202-207
+    const int fg_left = subsample_one(lab, total, 1, num_fg, seed, img, 0, sc);   // :202-207
     // num_bg = RPN_BATCHSIZE - #fg after the first sub-sampling, :212
-    if (threadIdx.x == 0) s_scalar[3] = 0;
-    __syncthreads();
-    int c = 0;
-    for (int i = threadIdx.x; i < total; i += SS_BLOCK) c += (lab[i] == 1) ? 1 : 0;
-    atomicAdd(&s_scalar[3], c);
-    __syncthreads();
-    const int num_bg = batchsize - s_scalar[3];
-    __syncthreads();
-    subsample_one(lab, total, 0, num_bg, seed, img, 1, hist, s_scalar);      // :213-217
+    subsample_one(lab, total, 0, batchsize - fg_left, seed, img, 1, sc);          // :213-217
 }
 
 // ---------------------------------------------------------------- targets ---

@@ -21,6 +21,7 @@
 //                 `removed` bitmap.  Stops as soon as max_keep boxes are kept
 //                 (the reference's caller truncates keep[:post_nms_topN]).
 #include "nms.hip.h"
+#include "select.hip.h"
 
 namespace wssdl {
 
@@ -34,54 +35,23 @@ namespace wssdl {
 // 64-bit keys = (order-preserving score bits << 32 | index) make the order total (ties:
 // higher index first) and the result deterministic.
 constexpr int SEL_BLOCK = 1024;
+constexpr int SEL_LIST = 512;
 
 __global__ __launch_bounds__(SEL_BLOCK) void topk_threshold_kernel(
     const unsigned long long *__restrict__ keys, int M, int topn,
     unsigned long long *__restrict__ thresh, int *__restrict__ n_sorted) {
-    __shared__ int hist[256];
-    __shared__ int s_sel[2];
-    __shared__ int s_valid;
+    __shared__ SelectScratch<SEL_LIST> sc;
     const int img = blockIdx.x, t = threadIdx.x;
     const unsigned long long *k = keys + (size_t)img * M;
-    if (t == 0) s_valid = 0;
-    __syncthreads();
-    int c = 0;
-    for (int i = t; i < M; i += SEL_BLOCK) c += (k[i] != 0ull) ? 1 : 0;
-    atomicAdd(&s_valid, c);
-    __syncthreads();
-    const int valid = s_valid;
-    __syncthreads();
-    if (t == 0) n_sorted[img] = min(valid, topn);
-    if (valid <= topn) {                       // every valid key is a candidate
-        if (t == 0) thresh[img] = 1ull;
-        return;
+    int valid = 0;
+    // topn-th largest key; with no more than topn valid keys every one of them is a candidate
+    const unsigned long long th = block_radix_select<SEL_BLOCK, SEL_LIST, true>(
+        [k](int i, unsigned long long &v) { v = k[i]; return v != 0ull; }, M,
+        [topn](int members) { return members > topn ? topn : 0; }, sc, &valid);
+    if (t == 0) {
+        n_sorted[img] = min(valid, topn);
+        thresh[img] = valid > topn ? th : 1ull;
     }
-    unsigned long long prefix = 0ull, pmask = 0ull;
-    int want = topn;                           // rank (1-based, from the top) inside the prefix bucket
-    for (int shift = 56; shift >= 0; shift -= 8) {
-        if (t < 256) hist[t] = 0;
-        __syncthreads();
-        for (int i = t; i < M; i += SEL_BLOCK) {
-            const unsigned long long v = k[i];
-            if (v != 0ull && (v & pmask) == prefix) atomicAdd(&hist[(int)((v >> shift) & 0xff)], 1);
-        }
-        __syncthreads();
-        if (t == 0) {
-            int acc = 0, b = 255;
-            for (; b > 0; --b) {
-                if (acc + hist[b] >= want) break;
-                acc += hist[b];
-            }
-            s_sel[0] = b;
-            s_sel[1] = want - acc;
-        }
-        __syncthreads();
-        prefix |= (unsigned long long)s_sel[0] << shift;
-        pmask |= 0xffull << shift;
-        want = s_sel[1];
-        __syncthreads();
-    }
-    if (t == 0) thresh[img] = prefix;          // the topn-th largest key
 }
 
 __global__ __launch_bounds__(256) void topk_compact_kernel(
@@ -128,9 +98,145 @@ __global__ __launch_bounds__(RANK_BLOCK) void rank_topk_kernel(
     if (i < n) sorted_index[(size_t)img * topn + cnt] = (int)(unsigned)(mine & 0xffffffffull);
 }
 
+// Bucketed ranking (sample sort) for large topn: rank_topk above compares every candidate with
+// every other (12000^2 per image); here 255 splitters taken from a sorted sample of 256
+// candidates cut them into 256 buckets first, and a candidate is only compared with its own bucket:
+//   rank_bucketize : one workgroup per image: sample -> splitters -> bucket sizes -> candidates
+//                    regrouped by bucket (any order inside a bucket) + bucket offsets;
+//   rank_in_bucket : position = bucket offset + number of greater keys in the bucket.
+// Keys are unique, so positions are a permutation and the result is the same total order.
+constexpr int RB_BLOCK = 1024;
+constexpr int RB_SAMPLES = 256;
+constexpr int RB_BUCKETS = 256;
+
+__device__ __forceinline__ int rb_bucket_of(const unsigned long long *split, int nb,
+                                            unsigned long long key) {
+    // splitters descending; bucket = number of splitters strictly greater than key
+    int lo = 0, hi = nb - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (split[mid] > key) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(RB_BLOCK) void rank_bucketize_kernel(
+    const unsigned long long *__restrict__ cand, const int *__restrict__ n_cand, int topn,
+    unsigned long long *__restrict__ grouped, int *__restrict__ bucket_off) {
+    __shared__ unsigned long long samp[RB_SAMPLES];
+    __shared__ unsigned long long ssort[RB_SAMPLES];
+    __shared__ unsigned long long split[RB_BUCKETS];
+    __shared__ int bcount[RB_BUCKETS];
+    __shared__ int bfill[RB_BUCKETS];
+    __shared__ int wsum[4];
+    const int img = blockIdx.x, t = threadIdx.x;
+    const int n = min(n_cand[img], topn);
+    const unsigned long long *k = cand + (size_t)img * topn;
+    unsigned long long *g = grouped + (size_t)img * topn;
+    int *boff = bucket_off + (size_t)img * (RB_BUCKETS + 1);
+    const int S = min(n, RB_SAMPLES);
+    const int nb = min(RB_BUCKETS, max(S, 1));
+    if (t < S) samp[t] = k[(long long)t * n / S];
+    if (t < RB_BUCKETS) bcount[t] = 0;
+    __syncthreads();
+    if (t < S) {
+        const unsigned long long mine = samp[t];
+        int r = 0;
+        for (int j = 0; j < S; ++j) r += (samp[j] > mine) ? 1 : 0;
+        ssort[r] = mine;                           // sample positions are distinct -> keys distinct
+    }
+    __syncthreads();
+    if (t < nb - 1) split[t] = ssort[(long long)(t + 1) * S / nb];
+    __syncthreads();
+    for (int i = t; i < n; i += RB_BLOCK) atomicAdd(&bcount[rb_bucket_of(split, nb, k[i])], 1);
+    __syncthreads();
+    {   // bucket offsets: 256-wide exclusive scan by the first four waves
+        static_assert(RB_BUCKETS == 256, "scan below is written for 4 waves");
+        const int lane = t & 63, wave = t >> 6;
+        int h = 0, inc = 0;
+        if (t < RB_BUCKETS) {
+            h = bcount[t];
+            inc = h;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += o;
+            }
+            if (lane == 63) wsum[wave] = inc;
+        }
+        __syncthreads();
+        if (t < RB_BUCKETS) {
+            int basev = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) basev += (w < wave) ? wsum[w] : 0;
+            inc += basev;
+            boff[t] = inc - h;
+            bfill[t] = inc - h;
+            if (t == RB_BUCKETS - 1) boff[RB_BUCKETS] = inc;
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += RB_BLOCK) {
+        const unsigned long long v = k[i];
+        g[atomicAdd(&bfill[rb_bucket_of(split, nb, v)], 1)] = v;
+    }
+}
+
+constexpr int RIB_BLOCK = 256;
+constexpr int RIB_TILE = 1024;
+
+__global__ __launch_bounds__(RIB_BLOCK) void rank_in_bucket_kernel(
+    const unsigned long long *__restrict__ grouped, const int *__restrict__ n_cand, int topn,
+    const int *__restrict__ bucket_off, int *__restrict__ sorted_index) {
+    __shared__ int s_boff[RB_BUCKETS + 1];
+    __shared__ unsigned long long tile[RIB_TILE];
+    const int img = blockIdx.y;
+    const int n = min(n_cand[img], topn);
+    const int p0 = blockIdx.x * RIB_BLOCK;
+    if (p0 >= n) return;
+    const unsigned long long *g = grouped + (size_t)img * topn;
+    for (int i = threadIdx.x; i <= RB_BUCKETS; i += RIB_BLOCK)
+        s_boff[i] = bucket_off[(size_t)img * (RB_BUCKETS + 1) + i];
+    __syncthreads();
+    const int p = p0 + threadIdx.x;
+    const bool live = p < n;
+    const unsigned long long mine = live ? g[p] : ~0ull;
+    // bucket of a position: last b with boff[b] <= p
+    auto bucket_at = [&](int pos) {
+        int lo = 0, hi = RB_BUCKETS - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_boff[mid] <= pos) lo = mid;
+            else hi = mid - 1;
+        }
+        return lo;
+    };
+    const int b = bucket_at(live ? p : n - 1);
+    const int lo = s_boff[b], hi = s_boff[b + 1];
+    // the workgroup's positions span the buckets of p0 .. min(p0 + 255, n - 1)
+    const int wlo = s_boff[bucket_at(p0)];
+    const int whi = s_boff[bucket_at(min(p0 + RIB_BLOCK, n) - 1) + 1];
+    int cnt = 0;
+    for (int j0 = wlo; j0 < whi; j0 += RIB_TILE) {
+        __syncthreads();
+        for (int u = threadIdx.x; u < RIB_TILE; u += RIB_BLOCK) tile[u] = (j0 + u < whi) ? g[j0 + u] : 0ull;
+        __syncthreads();
+        const int a = max(lo, j0) - j0, z = min(hi, j0 + RIB_TILE) - j0;
+        for (int u = a; u < z; ++u) cnt += (tile[u] > mine) ? 1 : 0;
+    }
+    if (live) sorted_index[(size_t)img * topn + lo + cnt] = (int)(unsigned)(mine & 0xffffffffull);
+}
+
+size_t rank_topk_scratch_bytes(int n_images, int topn) {
+    return (size_t)n_images * topn * sizeof(unsigned long long) +
+           (size_t)n_images * (RB_BUCKETS + 1) * sizeof(int);
+}
+
 int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int topn,
                      unsigned long long *cand, unsigned long long *thresh, int *cand_fill,
-                     int *sorted_index, int *n_sorted, hipStream_t st) {
+                     int *sorted_index, int *n_sorted, void *scratch, size_t scratch_bytes,
+                     hipStream_t st) {
     // sorted_index must be pre-filled with -1 and cand_fill with 0 by the caller
     hipLaunchKernelGGL(topk_threshold_kernel, dim3(n_images), dim3(SEL_BLOCK), 0, st, keys, M, topn,
                        thresh, n_sorted);
@@ -139,6 +245,16 @@ int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int to
     hipLaunchKernelGGL(topk_compact_kernel, dim3(cdiv(M, 256), n_images), dim3(256), 0, st, keys, M,
                        topn, thresh, cand, cand_fill);
     if ((rc = check_launch())) return rc;
+    if (topn >= 4096 && scratch && scratch_bytes >= rank_topk_scratch_bytes(n_images, topn)) {
+        unsigned long long *grouped = static_cast<unsigned long long *>(scratch);
+        int *boff = reinterpret_cast<int *>(grouped + (size_t)n_images * topn);
+        hipLaunchKernelGGL(rank_bucketize_kernel, dim3(n_images), dim3(RB_BLOCK), 0, st, cand, n_sorted,
+                           topn, grouped, boff);
+        if ((rc = check_launch())) return rc;
+        hipLaunchKernelGGL(rank_in_bucket_kernel, dim3(cdiv(topn, RIB_BLOCK), n_images), dim3(RIB_BLOCK),
+                           0, st, grouped, n_sorted, topn, boff, sorted_index);
+        return check_launch();
+    }
     hipLaunchKernelGGL(rank_topk_kernel, dim3(cdiv(topn, RANK_BLOCK), n_images), dim3(RANK_BLOCK), 0,
                        st, cand, n_sorted, topn, sorted_index);
     return check_launch();
@@ -614,7 +730,8 @@ extern "C" int wssdl_nms(const float *dets, int n, double thresh, int max_keep, 
     hipLaunchKernelGGL(nms_prepare_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dets, n, w.keys);
     int rc = check_launch();
     if (rc) return rc;
-    rc = launch_rank_topk(w.keys, n, 1, n, w.cand, w.thresh, w.cand_fill, w.order, w.n_sorted, st);
+    rc = launch_rank_topk(w.keys, n, 1, n, w.cand, w.thresh, w.cand_fill, w.order, w.n_sorted, w.mask,
+                          sizeof(unsigned long long) * (size_t)n * cdiv(n, 64), st);
     if (rc) return rc;
     hipLaunchKernelGGL(nms_gather_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dets, w.order,
                        w.n_sorted, n, w.boxes);

@@ -17,9 +17,13 @@ __host__ __device__ __forceinline__ unsigned long long score_key(float score, un
 // receives the index (low key word) of the element at each descending-score position < topn;
 // n_sorted [n_images] receives min(#valid, topn).  Scratch: cand [n_images, topn] u64,
 // thresh [n_images] u64, cand_fill [n_images] i32 (pre-zeroed).
+// `scratch` (optional, rank_topk_scratch_bytes; may alias memory that is only written after the
+// ranking, e.g. the suppression matrix) enables the bucketed ranking for large topn.
+size_t rank_topk_scratch_bytes(int n_images, int topn);
 int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int topn,
                      unsigned long long *cand, unsigned long long *thresh, int *cand_fill,
-                     int *sorted_index, int *n_sorted, hipStream_t st);
+                     int *sorted_index, int *n_sorted, void *scratch, size_t scratch_bytes,
+                     hipStream_t st);
 
 // boxes: per image [n_max, 4] f32 in score order (image stride box_stride_img floats);
 // mask: per image [n_max, ceil(n_max/64)] u64, upper triangle written.

@@ -186,7 +186,8 @@ static int proposal_layer_impl(int from_logits, const float *rpn_cls_prob, const
                        rpn_bbox_pred, im_info, im_info_stride, N, H, W, base, A, feat_stride,
                        min_size, from_logits, boxes, w.keys);
     if ((rc = check_launch())) return rc;
-    if ((rc = launch_rank_topk(w.keys, M, N, topn, w.cand, w.thresh, w.cand_fill, sidx, nsorted, st)))
+    if ((rc = launch_rank_topk(w.keys, M, N, topn, w.cand, w.thresh, w.cand_fill, sidx, nsorted, w.mask,
+                               sizeof(unsigned long long) * (size_t)N * topn * cdiv(topn, 64), st)))
         return rc;
     hipLaunchKernelGGL(proposal_gather_kernel, dim3(cdiv(topn, 256), N), dim3(256), 0, st, boxes,
                        sidx, nsorted, M, topn, w.sorted_boxes);

@@ -18,6 +18,7 @@
 //                 all-f32 bbox_transform (:220), expansion into the 4*num_classes
 //                 layout with inside / outside weights (:199-209, :89).
 #include "common.hip.h"
+#include "select.hip.h"
 
 namespace wssdl {
 
@@ -134,40 +135,20 @@ struct RoiClassifier {          // _sample_rois :241, :253-254
     }
 };
 
+constexpr int RS_LIST = 512;
+
 // key of the quota-th smallest among the candidates of class `which` (all of them when there
 // are no more than quota: returns ~0)
 __device__ unsigned long long rs_select(const RoiClassifier &cls, int Rc, int which, int n_have,
-                                        int quota, unsigned long long seed, int *hist,
-                                        int *s_scalar) {
-    if (n_have <= quota) return ~0ull;
-    const int t = threadIdx.x;
-    unsigned long long prefix = 0ull, pmask = 0ull;
-    int want = quota;
-    for (int shift = 56; shift >= 0; shift -= 8) {
-        if (t < 256) hist[t] = 0;
-        __syncthreads();
-        for (int i = t; i < Rc; i += RS_BLOCK) {
-            if (cls(i) != which) continue;
-            const unsigned long long k = rs_key(seed, cls.img, i);
-            if ((k & pmask) == prefix) atomicAdd(&hist[(int)((k >> shift) & 0xff)], 1);
-        }
-        __syncthreads();
-        if (t == 0) {
-            int acc = 0, b = 0;
-            for (; b < 256; ++b) {
-                if (acc + hist[b] >= want) break;
-                acc += hist[b];
-            }
-            s_scalar[0] = b;
-            s_scalar[1] = want - acc;
-        }
-        __syncthreads();
-        prefix |= (unsigned long long)s_scalar[0] << shift;
-        pmask |= 0xffull << shift;
-        want = s_scalar[1];
-        __syncthreads();
-    }
-    return prefix;
+                                        int quota, unsigned long long seed,
+                                        SelectScratch<RS_LIST> &sc) {
+    if (n_have <= quota || quota <= 0) return ~0ull;
+    return block_radix_select<RS_BLOCK, RS_LIST, false>(
+        [=](int i, unsigned long long &v) {
+            if (cls(i) != which) return false;
+            v = rs_key(seed, cls.img, i);
+            return true;
+        }, Rc, [quota](int) { return quota; }, sc);
 }
 
 __device__ int rs_block_exclusive_scan(int v, int *s_wave, int &total) {
@@ -197,8 +178,7 @@ __global__ __launch_bounds__(RS_BLOCK) void roi_sample_kernel(
     const int *__restrict__ images, int rois_per_image, int fg_rois_per_image, double fg_thresh,
     double bg_hi, double bg_lo, unsigned long long seed, int *__restrict__ keep,
     unsigned char *__restrict__ is_fg, int *__restrict__ counts) {
-    __shared__ int hist[256];
-    __shared__ int s_scalar[2];
+    __shared__ SelectScratch<RS_LIST> sc;
     __shared__ int s_wave[RS_BLOCK / 64];
     const int s = blockIdx.x, t = threadIdx.x;
     RoiClassifier cls;
@@ -218,8 +198,8 @@ __global__ __launch_bounds__(RS_BLOCK) void roi_sample_kernel(
     rs_block_exclusive_scan(cb, s_wave, have_bg);
     const int n_fg = min(fg_rois_per_image, have_fg);                 // :243
     const int n_bg = min(rois_per_image - n_fg, have_bg);             // :256-258
-    const unsigned long long t_fg = rs_select(cls, Rc, 1, have_fg, n_fg, seed, hist, s_scalar);
-    const unsigned long long t_bg = rs_select(cls, Rc, 0, have_bg, n_bg, seed ^ 0x5bd1e995ull, hist, s_scalar);
+    const unsigned long long t_fg = rs_select(cls, Rc, 1, have_fg, n_fg, seed, sc);
+    const unsigned long long t_bg = rs_select(cls, Rc, 0, have_bg, n_bg, seed ^ 0x5bd1e995ull, sc);
     cf = cb = 0;
     if (n_fg > 0 || n_bg > 0)
         for (int i = i0; i < i1; ++i) {
