@@ -280,7 +280,8 @@ constexpr int MASK_SEG = 16;     // column blocks per workgroup
 // are read as broadcasts.
 __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
     const float *__restrict__ boxes, int box_stride_img, const int *__restrict__ n_dev, int n_max,
-    double thresh, unsigned long long *__restrict__ mask, int ncb) {
+    double thresh, unsigned long long *__restrict__ mask, int ncb,
+    unsigned long long *__restrict__ diag_t) {
     const int rb = blockIdx.x, seg = blockIdx.y, img = blockIdx.z;
     const int n = min(n_dev[img], n_max);
     if (rb * 64 >= n || (seg + 1) * MASK_SEG <= rb || seg * MASK_SEG * 64 >= n) return;
@@ -321,7 +322,16 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
             if (den > 0.0f && inter < den * t_lo) sup = false;
             else if (den > 0.0f && inter > den * t_hi) sup = true;
             else sup = (double)(inter / den) >= thresh;
-            if (sup && cb * 64 + j > i) bits |= 1ull << j;
+            if (sup) bits |= 1ull << j;
+        }
+        if (cb == rb) {
+            // diagonal block.  The test is symmetric in the two boxes (max/min and the area sum
+            // commute), so the same word also holds the transposed block: bits below the
+            // lane's own index = the EARLIER boxes of this chunk that suppress box i (what the
+            // sweep's resolver wants per lane); the mask proper keeps the bits above it.
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (row_ok && diag_t) diag_t[(size_t)img * n_max + i] = bits & below;
+            bits &= ~(below | (1ull << lane));
         }
         if (row_ok) mask[((size_t)img * n_max + i) * ncb + cb] = bits;
         __builtin_amdgcn_wave_barrier();
@@ -329,11 +339,12 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
 }
 
 int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, int n_max,
-                    int n_images, double thresh, unsigned long long *mask, hipStream_t st) {
+                    int n_images, double thresh, unsigned long long *mask,
+                    unsigned long long *diag_t, hipStream_t st) {
     int ncb = cdiv(n_max, 64);
     if (ncb == 0 || n_images == 0) return WSSDL_OK;
     hipLaunchKernelGGL(nms_mask_kernel, dim3(ncb, cdiv(ncb, MASK_SEG), n_images), dim3(64 * MASK_WAVES), 0, st, boxes,
-                       box_stride_img, n_dev, n_max, thresh, mask, ncb);
+                       box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t);
     return check_launch();
 }
 
@@ -480,172 +491,233 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_kernel(
 }
 
 
-// ------------------------------------------------- nms sweep, latency-pipelined ---
-// Same greedy sweep, restructured so that no global-memory latency sits on the per-chunk
-// critical path (the version above spends ~1.6 us per 64-box chunk, most of it waiting for one
-// dependent load; 188 chunks at 12000 boxes).  Contributions to removed[w] are split by age:
-//   * boxes kept in chunks w-3..w-1: wave 0 holds words c+1..c+3 of every row of chunk c in
-//     registers (loaded two chunks ahead, together with the diagonal word) and ORs the
-//     survivors' words into the ring slots of words c+1..c+3 right after resolving chunk c;
-//   * boxes kept in chunks < w-3: the helper waves issue word c+3 of every box kept before
-//     chunk c during iteration c and consume it two iterations later, so each of their loads
-//     has two full iterations to complete.
-// removed[] lives in a 4-slot LDS ring (slot = word & 3) updated with ds_or_b64.  The barrier
-// waits for LDS traffic only, so the loads stay in flight across it.  Needs the kept list in
-// LDS and max_keep <= LH * (SWEEP_BLOCK - 64); the kernel above is the general fallback.
-constexpr int SWEEP_LH = 3;
+// ------------------------------------------- nms sweep, role-pipelined ---
+// Same greedy sweep with the per-chunk critical path cut down to what is inherently serial.
+// Measured on the version above (12000 boxes, 188 chunks): ~1.6 us per chunk, of which the
+// resolver's scalar loop costs ~36 ns per kept box and the rest is wave 0 fetching mask words,
+// storing results, reducing the next `removed` word, and global-memory latency between chunks.
+// Here the 16 waves of the workgroup have four roles:
+//   wave 0  (resolver) per chunk c: reads removed[c], the TRANSPOSED diagonal block (lane j:
+//           which earlier boxes of the chunk suppress box j; written by the mask kernel) and
+//           the chunk's words c+1..c+4 from LDS.  The kept set K is the unique fixed point of
+//               K[j] = cand[j] and not (T[j] & K)
+//           (a bit only depends on lower bits), reached by iterating K <- cand & ~ballot(T & K)
+//           from K = cand: each round is 4 vector + 3 scalar instructions for the whole chunk and
+//           fixes at least one more position; 2-4 rounds in practice instead of one scalar
+//           round per kept box.  Then the survivors' words c+1..c+4 are ORed into the LDS ring
+//           of future `removed` words (ds_or, no reduction) and the kept bitmask is published;
+//   waves 1-2 (scribes) one chunk behind: expand the published bitmask into the kept list (LDS)
+//           and fetch what the global outputs need (score-order index, box); the global stores
+//           follow two iterations later;
+//   waves 3-4 (stagers) bring T and the mask words c+1..c+4 of the rows of chunk c into LDS:
+//           loaded into registers at iteration c-3, written to LDS at iteration c-1;
+//   waves 6..15 (helpers) cover the boxes kept five or more chunks before a word: at iteration
+//           c they issue word c+3 of every box in the kept list and consume it at iteration c+2.
+// Scribes, stagers and helpers work in two alternating groups (one acts on even, one on odd
+// iterations), so a wave never has a newer batch of loads in flight when it consumes an older
+// one: the compiler cannot count loads in flight across loop iterations and waits for ALL of
+// them (s_waitcnt vmcnt(0)); with interleaved batches that put a full memory latency into
+// every iteration, with alternating groups the wait is for loads issued two iterations earlier.
+// removed[w] = ring[w & 7]: wave 0 contributes chunks w-4..w-1, the helpers chunks <= w-5.
+// The per-iteration barrier waits for LDS traffic only; global loads stay in flight across it.
+// Needs the kept list in LDS and max_keep <= SWEEP_LH * SWEEP_GROUP; the kernel above is the
+// general fallback.
+constexpr int SWEEP_LH = 7;
+constexpr int SWEEP_FIRST_HELPER = 6;                                   // wave index
+constexpr int SWEEP_GROUP = (SWEEP_BLOCK / 64 - SWEEP_FIRST_HELPER) / 2 * 64;   // threads per helper group
+constexpr int SWEEP_AHEAD = 4;          // words right of the diagonal that wave 0 handles itself
 
 __device__ __forceinline__ void lds_only_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-struct SweepRows {                  // wave 0: one row per lane, words c..c+3 of chunk c
-    unsigned long long w[4];
+struct SweepShared {
+    unsigned long long ring[8];
+    unsigned long long rowbuf[2][SWEEP_AHEAD + 1][64];   // [parity][0 = T, j = word c+j][row]
+    struct __attribute__((aligned(16))) Publish {   // written by the resolver with one 16-byte store
+        unsigned long long kept;                    // kept bitmask of the chunk
+        int base;                                   // boxes kept before the chunk
+        int count;                                  // boxes kept after it
+    } pub[2];                                       // by chunk parity
 };
-struct SweepPend {                  // helpers: loads in flight for one future word
-    unsigned long long v[SWEEP_LH];
-};
-
-struct SweepCtx {
-    const unsigned long long *m;
-    int n, ncb, nchunks, max_keep, img;
-    const int *order; int order_stride_img;
-    int *keep; const float *boxes; int box_stride_img; float *rois_padded;
-    int *kept_rows; unsigned long long *ring; int *s_count;
-    int tid, lane, wave;
-};
-
-__device__ __forceinline__ void sweep_load_rows(const SweepCtx &k, int chunk, SweepRows &r) {
-    const int row = chunk * 64 + k.lane;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        r.w[j] = 0ull;
-        if (row < k.n && chunk + j < k.nchunks) r.w[j] = k.m[(size_t)row * k.ncb + chunk + j];
-    }
-}
-
-// one chunk; `rows` holds chunk c (refilled with chunk c+2), `pend` holds the helpers' word c+1
-// loads issued at iteration c-2 (refilled with word c+3).  Returns the kept count after c.
-__device__ __forceinline__ int sweep_step(const SweepCtx &k, int c, int count, SweepRows &rows,
-                                          SweepPend &pend) {
-    constexpr int NHELP = SWEEP_BLOCK - 64;
-    if (k.wave == 0) {
-        unsigned long long rem = 0ull;
-        if (k.lane == 0) { rem = k.ring[c & 3]; k.ring[c & 3] = 0ull; }   // slot reused by word c+4
-        rem = readlane_u64(rem, 0);
-        const int row = c * 64 + k.lane;
-        const int nv = k.n - c * 64;
-        const unsigned long long valid = (nv >= 64) ? ~0ull : ((1ull << nv) - 1ull);
-        unsigned long long cur = rem | ~valid;
-        unsigned long long kept = 0ull;
-        unsigned long long cand = ~cur;
-        const unsigned long long diag = rows.w[0];
-        while (cand != 0ull) {
-            const int bsel = __builtin_amdgcn_readfirstlane(__ffsll((long long)cand) - 1);
-            kept |= 1ull << bsel;
-            unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)diag, bsel);
-            unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(diag >> 32), bsel);
-            cur |= (((unsigned long long)hi << 32) | lo) | (1ull << bsel);
-            cand = ~cur & ((bsel == 63) ? 0ull : (~0ull << (bsel + 1)));
-        }
-        const bool mine = (kept >> k.lane) & 1ull;
-        // hand the survivors' next three words on first: this is what the next chunk waits for
-        const unsigned long long n1 = wave_or_u64(mine ? rows.w[1] : 0ull);
-        const unsigned long long n2 = wave_or_u64(mine ? rows.w[2] : 0ull);
-        const unsigned long long n3 = wave_or_u64(mine ? rows.w[3] : 0ull);
-        if (k.lane == 0) {
-            atomicOr(&k.ring[(c + 1) & 3], n1);
-            atomicOr(&k.ring[(c + 2) & 3], n2);
-            atomicOr(&k.ring[(c + 3) & 3], n3);
-            *k.s_count = count + __popcll(kept);
-        }
-        if (mine) {
-            const int pos = count + __popcll(kept & ((1ull << k.lane) - 1ull));
-            if (pos < k.max_keep) {
-                k.kept_rows[pos] = row;
-                if (k.keep)
-                    k.keep[(size_t)k.img * k.max_keep + pos] =
-                        k.order ? k.order[(size_t)k.img * k.order_stride_img + row] : row;
-                if (k.rois_padded) {
-                    const float *bx = k.boxes + (size_t)k.img * k.box_stride_img + (size_t)row * 4;
-                    float *o = k.rois_padded + ((size_t)k.img * k.max_keep + pos) * 5;
-                    o[0] = (float)k.img; o[1] = bx[0]; o[2] = bx[1]; o[3] = bx[2]; o[4] = bx[3];
-                }
-            }
-        }
-        sweep_load_rows(k, c + 2, rows);
-    } else {
-        // consume word c+1 (issued at iteration c-2: boxes kept before chunk c-2)
-        unsigned long long acc = 0ull;
-#pragma unroll
-        for (int j = 0; j < SWEEP_LH; ++j) acc |= pend.v[j];
-        acc = wave_or_u64(acc);
-        if (k.lane == 0 && acc != 0ull) atomicOr(&k.ring[(c + 1) & 3], acc);
-        // issue word c+3 of every box kept before chunk c
-        const int lim = min(count, k.max_keep);
-#pragma unroll
-        for (int j = 0; j < SWEEP_LH; ++j) {
-            const int i = k.tid - 64 + j * NHELP;
-            pend.v[j] = 0ull;
-            if (i < lim && c + 3 < k.nchunks) pend.v[j] = k.m[(size_t)k.kept_rows[i] * k.ncb + c + 3];
-        }
-    }
-    lds_only_barrier();
-    return *k.s_count;
-}
 
 __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(
-    const unsigned long long *__restrict__ mask, const int *__restrict__ n_dev, int n_max, int ncb,
+    const unsigned long long *__restrict__ mask, const unsigned long long *__restrict__ diag_t,
+    const int *__restrict__ n_dev, int n_max, int ncb,
     int max_keep, const int *__restrict__ order, int order_stride_img,
     int *__restrict__ keep, int *__restrict__ num_keep,
     const float *__restrict__ boxes, int box_stride_img, float *__restrict__ rois_padded) {
-    extern __shared__ int kept_lds[];                // [max_keep + 64]
-    __shared__ unsigned long long s_ring[4];
-    __shared__ int s_count;
-    SweepCtx k;
-    k.img = blockIdx.x;
-    k.n = min(n_dev[k.img], n_max);
-    k.ncb = ncb;
-    k.nchunks = (k.n + 63) / 64;
-    k.max_keep = max_keep;
-    k.m = mask + (size_t)k.img * n_max * ncb;
-    k.order = order; k.order_stride_img = order_stride_img;
-    k.keep = keep; k.boxes = boxes; k.box_stride_img = box_stride_img; k.rois_padded = rois_padded;
-    k.kept_rows = kept_lds; k.ring = s_ring; k.s_count = &s_count;
-    k.tid = threadIdx.x; k.lane = k.tid & 63; k.wave = k.tid >> 6;
-    if (k.tid < 4) s_ring[k.tid] = 0ull;
-    if (k.tid == 0) s_count = 0;
-    __syncthreads();
-    SweepRows rows0, rows1;
-    SweepPend pend0, pend1;
+    static_assert(SWEEP_BLOCK / 64 >= SWEEP_FIRST_HELPER + 2, "resolver + scribes + stagers + helpers");
+    extern __shared__ int kept_rows[];               // [max_keep + 64]
+    __shared__ SweepShared sh;
+    const int img = blockIdx.x;
+    const int n = min(n_dev[img], n_max);
+    const int nchunks = (n + 63) / 64;
+    const unsigned long long *m = mask + (size_t)img * n_max * ncb;
+    const unsigned long long *dt = diag_t + (size_t)img * n_max;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 8) sh.ring[tid] = 0ull;
+    if (tid < 2) { sh.pub[tid].kept = 0ull; sh.pub[tid].base = 0; sh.pub[tid].count = 0; }
+
+    // role and group of this wave; a group acts on the iterations with (c & 1) == group
+    const bool scribe = wave == 1 || wave == 2;
+    const bool stager = wave == 3 || wave == 4;
+    const bool helper = wave >= SWEEP_FIRST_HELPER;
+    const int hw = wave - SWEEP_FIRST_HELPER;
+    const int group = helper ? (hw & 1) : (wave & 1);
+    const int hidx = (hw >> 1) * 64 + lane;                   // index inside the helper group
+    unsigned long long rows[SWEEP_AHEAD + 1];                 // stager: T + words of one chunk's rows
+    unsigned long long pend[SWEEP_LH];                        // helper: one word of kept boxes
+    // scribe: outputs of one kept box, fetched but not yet stored
+    int out_pos = -1, out_idx = 0;
+    float out_box[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rows0.w[j] = rows1.w[j] = 0ull;
+    for (int j = 0; j <= SWEEP_AHEAD; ++j) rows[j] = 0ull;
 #pragma unroll
-    for (int j = 0; j < SWEEP_LH; ++j) pend0.v[j] = pend1.v[j] = 0ull;
-    if (k.wave == 0) {
-        sweep_load_rows(k, 0, rows0);
-        sweep_load_rows(k, 1, rows1);
+    for (int j = 0; j < SWEEP_LH; ++j) pend[j] = 0ull;
+
+    auto load_rows = [&](int chunk) {
+        const int row = chunk * 64 + lane;
+#pragma unroll
+        for (int j = 0; j <= SWEEP_AHEAD; ++j) rows[j] = 0ull;
+        if (row < n) {
+            rows[0] = dt[row];
+#pragma unroll
+            for (int j = 1; j <= SWEEP_AHEAD; ++j)
+                if (chunk + j < nchunks) rows[j] = m[(size_t)row * ncb + chunk + j];
+        }
+    };
+    // kept bitmask of `chunk` -> kept list (LDS, at once) + fetch of the global outputs
+    auto expand = [&](int chunk) {
+        const unsigned long long kept = sh.pub[chunk & 1].kept;
+        const int base = sh.pub[chunk & 1].base;
+        out_pos = -1;
+        if ((kept >> lane) & 1ull) {
+            const int row = chunk * 64 + lane;
+            const int pos = base + __popcll(kept & ((1ull << lane) - 1ull));
+            if (pos < max_keep) {
+                kept_rows[pos] = row;
+                out_pos = pos;
+                out_idx = row;
+                if (keep && order) out_idx = order[(size_t)img * order_stride_img + row];
+                if (rois_padded) {
+                    const float *bx = boxes + (size_t)img * box_stride_img + (size_t)row * 4;
+                    out_box[0] = bx[0]; out_box[1] = bx[1]; out_box[2] = bx[2]; out_box[3] = bx[3];
+                }
+            }
+        }
+    };
+    auto flush = [&]() {
+        if (out_pos >= 0) {
+            if (keep) keep[(size_t)img * max_keep + out_pos] = out_idx;
+            if (rois_padded) {
+                float *o = rois_padded + ((size_t)img * max_keep + out_pos) * 5;
+                o[0] = (float)img; o[1] = out_box[0]; o[2] = out_box[1]; o[3] = out_box[2]; o[4] = out_box[3];
+            }
+        }
+        out_pos = -1;
+    };
+    // stager `group` acts at even/odd c: writes chunk c+1, loads chunk c+3.  Prologue: chunk 0
+    // straight into LDS (group 1 would have written it at c = -1), then chunk 1 (for c = 0) into
+    // group 0's registers and chunk 2 (for c = 1) into group 1's.
+    if (stager && group == 1) {
+        load_rows(0);
+#pragma unroll
+        for (int j = 0; j <= SWEEP_AHEAD; ++j) sh.rowbuf[0][j][lane] = rows[j];
+        load_rows(2);
+    } else if (stager) {
+        load_rows(1);
     }
-    int count = 0;
-    for (int c = 0; c < k.nchunks; c += 2) {
-        count = sweep_step(k, c, count, rows0, pend0);
-        if (count >= max_keep || c + 1 >= k.nchunks) break;
-        count = sweep_step(k, c + 1, count, rows1, pend1);
+    __syncthreads();
+
+    int count = 0, last = -1;
+    for (int c = 0; c < nchunks; ++c) {
+        if (wave == 0) {
+            unsigned long long rem = 0ull;
+            if (lane == 0) { rem = sh.ring[c & 7]; sh.ring[c & 7] = 0ull; }   // slot reused by word c+8
+            unsigned long long w[SWEEP_AHEAD + 1];
+#pragma unroll
+            for (int j = 0; j <= SWEEP_AHEAD; ++j) w[j] = sh.rowbuf[c & 1][j][lane];
+            rem = readlane_u64(rem, 0);
+            const int nv = n - c * 64;
+            const unsigned long long valid = (nv >= 64) ? ~0ull : ((1ull << nv) - 1ull);
+            const unsigned long long cand = ~rem & valid;
+            const unsigned long long t_mine = w[0];
+            unsigned long long kept = cand;
+            for (;;) {
+                const unsigned long long nk = cand & ~__ballot((t_mine & kept) != 0ull);
+                if (nk == kept) break;
+                kept = nk;
+            }
+            if ((kept >> lane) & 1ull) {
+#pragma unroll
+                for (int j = 1; j <= SWEEP_AHEAD; ++j)
+                    if (w[j] != 0ull) atomicOr(&sh.ring[(c + j) & 7], w[j]);
+            }
+            if (lane == 0) {
+                SweepShared::Publish pr;
+                pr.kept = kept;  pr.base = count;  pr.count = count + __popcll(kept);
+                sh.pub[c & 1] = pr;
+            }
+            count += __popcll(kept);                   // the resolver keeps its own running count
+        } else if (wave == 5) {
+            // spare
+        } else if ((c & 1) == group) {
+            if (scribe) {
+                flush();                               // outputs fetched two iterations ago
+                if (c > 0) expand(c - 1);
+            } else if (stager) {
+#pragma unroll
+                for (int j = 0; j <= SWEEP_AHEAD; ++j) sh.rowbuf[(c + 1) & 1][j][lane] = rows[j];
+                load_rows(c + 3);
+            } else {
+                // consume word c+1 (issued at iteration c-2; slots beyond the list were zeroed)
+                unsigned long long acc = 0ull;
+#pragma unroll
+                for (int j = 0; j < SWEEP_LH; ++j) acc |= pend[j];
+                acc = wave_or_u64(acc);
+                if (lane == 0 && acc != 0ull) atomicOr(&sh.ring[(c + 1) & 7], acc);
+                // issue word c+3 of every box in the kept list (chunks <= c-2); 32-bit word
+                // offsets (n_max * ncb < 2^31 checked by the launcher)
+                const int lim = (c >= 1 && c + 3 < nchunks) ? min(sh.pub[(c - 1) & 1].base, max_keep) : 0;
+                unsigned off[SWEEP_LH];
+#pragma unroll
+                for (int j = 0; j < SWEEP_LH; ++j) {
+                    const int i = hidx + j * SWEEP_GROUP;
+                    off[j] = (i < lim) ? __umul24((unsigned)kept_rows[i], (unsigned)ncb) + (unsigned)(c + 3) : 0xffffffffu;
+                }
+#pragma unroll
+                for (int j = 0; j < SWEEP_LH; ++j) {
+                    pend[j] = 0ull;
+                    if (off[j] != 0xffffffffu) pend[j] = m[off[j]];
+                }
+            }
+        }
+        lds_only_barrier();
+        if (wave != 0) count = sh.pub[c & 1].count;
+        last = c;
         if (count >= max_keep) break;
     }
-    if (k.tid == 0) num_keep[k.img] = min(count, max_keep);
+    if (scribe && last >= 0) {
+        // chunk `last` was resolved but not expanded yet: it belongs to the group of last + 1
+        flush();
+        if (((last + 1) & 1) == group) { expand(last); flush(); }
+    }
+    if (tid == 0) num_keep[img] = min(count, max_keep);
 }
 
-int launch_nms_sweep(const unsigned long long *mask, const int *n_dev, int n_max, int n_images,
+int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *diag_t,
+                     const int *n_dev, int n_max, int n_images,
                      int max_keep, const int *order, int order_stride_img, int *keep,
                      int *num_keep, const float *boxes, int box_stride_img, float *rois_padded,
                      int *kept_scratch, hipStream_t st) {
     int ncb = cdiv(n_max, 64);
     if (n_images == 0) return WSSDL_OK;
     size_t lds = ((size_t)max_keep + 64) * sizeof(int);
-    if (lds <= SWEEP_LDS_LIMIT && max_keep <= SWEEP_LH * (SWEEP_BLOCK - 64)) {
+    if (diag_t && lds <= SWEEP_LDS_LIMIT && max_keep <= SWEEP_LH * SWEEP_GROUP && n_max < (1 << 24) &&
+        (long long)n_max * ncb < (1LL << 31)) {
         hipLaunchKernelGGL(nms_sweep_pipelined_kernel, dim3(n_images), dim3(SWEEP_BLOCK), lds, st,
-                           mask, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep,
+                           mask, diag_t, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep,
                            num_keep, boxes, box_stride_img, rois_padded);
         return check_launch();
     }
@@ -737,8 +809,8 @@ extern "C" int wssdl_nms(const float *dets, int n, double thresh, int max_keep, 
                        w.n_sorted, n, w.boxes);
     rc = check_launch();
     if (rc) return rc;
-    rc = launch_nms_mask(w.boxes, n * 4, w.n_sorted, n, 1, thresh, w.mask, st);
+    rc = launch_nms_mask(w.boxes, n * 4, w.n_sorted, n, 1, thresh, w.mask, w.cand, st);
     if (rc) return rc;
-    return launch_nms_sweep(w.mask, w.n_sorted, n, 1, max_keep, w.order, n, keep, num_keep,
+    return launch_nms_sweep(w.mask, w.cand, w.n_sorted, n, 1, max_keep, w.order, n, keep, num_keep,
                             nullptr, 0, nullptr, w.kept, st);
 }

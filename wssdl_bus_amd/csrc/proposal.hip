@@ -192,11 +192,12 @@ static int proposal_layer_impl(int from_logits, const float *rpn_cls_prob, const
     hipLaunchKernelGGL(proposal_gather_kernel, dim3(cdiv(topn, 256), N), dim3(256), 0, st, boxes,
                        sidx, nsorted, M, topn, w.sorted_boxes);
     if ((rc = check_launch())) return rc;
-    if ((rc = launch_nms_mask(w.sorted_boxes, topn * 4, nsorted, topn, N, nms_thresh, w.mask, st)))
+    // w.cand is free once the ranking is done: it receives the transposed diagonal blocks
+    if ((rc = launch_nms_mask(w.sorted_boxes, topn * 4, nsorted, topn, N, nms_thresh, w.mask, w.cand, st)))
         return rc;
     // the sweep writes (batch_idx, box) rows straight into rois_padded and stops
     // after `pitch` kept boxes
-    if ((rc = launch_nms_sweep(w.mask, nsorted, topn, N, pitch, nullptr, 0, nullptr, roi_counts,
+    if ((rc = launch_nms_sweep(w.mask, w.cand, nsorted, topn, N, pitch, nullptr, 0, nullptr, roi_counts,
                                w.sorted_boxes, topn * 4, rois_padded,
                                pitch <= topn ? w.kept : nullptr, st)))
         return rc;
