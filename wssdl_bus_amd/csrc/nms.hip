@@ -4,22 +4,25 @@
 // fast_rcnn/config.py:321 USE_GPU_NMS=False) via fast_rcnn/nms_wrapper.py:13-21;
 // sort: rpn_msr/proposal_layer_tf_bus.py:129-133.
 //
-// Three kernels, each launched once for ALL images of a step:
-//   rank_topk   : position of every candidate in descending score order by
-//                 counting (key_j > key_i) over LDS-staged key tiles; 64-bit keys
-//                 = (order-preserving score bits << 32 | index) make the order
-//                 total (ties: higher index first) and the result deterministic.
+// Three stages, each launched once for ALL images of a step:
+//   top-K rank  : 64-bit keys = (order-preserving score bits << 32 | index) make the
+//                 order total (ties: higher index first) and the result
+//                 deterministic.  Threshold by radix select (select.hip.h),
+//                 compaction, then a sample sort: splitters from a sorted sample,
+//                 position = bucket offset + number of greater keys in the bucket
+//                 (all-pairs counting rank_topk_kernel remains for small topn).
 //   nms_mask    : 64x64 tiles of the upper triangle of the suppression matrix,
 //                 one u64 word per (row box, column block): 64 column boxes in
 //                 LDS, one row box per lane.  f32 arithmetic in cpu_nms.pyx's
 //                 operation order, test (double)iou >= thresh (vendored
-//                 cpu_nms.c:2495 compares PyFloat objects).
-//   nms_sweep   : one workgroup per image walks the 64-row chunks in order.
-//                 Wave 0 resolves a chunk against its diagonal word entirely in
-//                 scalar registers (v_readlane), appends the kept rows, then all
-//                 waves OR the kept rows' mask words into the LDS-resident
-//                 `removed` bitmap.  Stops as soon as max_keep boxes are kept
-//                 (the reference's caller truncates keep[:post_nms_topN]).
+//                 cpu_nms.c:2495 compares PyFloat objects).  The diagonal block
+//                 is also emitted transposed (diag_t) for the sweep's resolver.
+//   nms_sweep   : one workgroup per image walks the 64-row chunks in order and
+//                 stops as soon as max_keep boxes are kept (the reference's caller
+//                 truncates keep[:post_nms_topN]).  nms_sweep_pipelined_kernel
+//                 (roles: resolver / scribes / stagers / helpers, see there) is
+//                 the fast path; nms_sweep_kernel the general fallback (kept list
+//                 too long for LDS or for the helpers' registers).
 #include "nms.hip.h"
 #include "select.hip.h"
 
