@@ -378,3 +378,40 @@ def test_proposal_target_device_sampling(torch_cuda):
         assert seen <= fg_all
     finally:
         cfg.SAMPLING_RNG, cfg.DEVICE_RNG_SEED = old
+
+
+# ----------------------------------------------------------- NMS: suppression chains ---
+def test_nms_suppression_chains(torch_cuda):
+    """Worst cases for the sweep's fixed-point resolver: inside a 64-box chunk every box
+    suppresses the next one but not the one after (the kept set alternates and each round of
+    K <- cand & ~ballot(T & K) only settles one more position), chains that run across chunk
+    borders, and dense clusters where one box suppresses a whole chunk."""
+    from wssdl_bus_amd.nms.hip_nms import hip_nms
+    # chain: unit-height boxes of width 100 shifted by 15 px: IoU(i, i+1) = 86/116 = 0.741 (> 0.7),
+    # IoU(i, i+2) = 71/131 = 0.54
+    for n in (64, 65, 200, 1000):
+        x1 = 15.0 * np.arange(n)
+        d = np.stack([x1, np.zeros(n), x1 + 100.0, np.full(n, 50.0), 1.0 - np.arange(n) / float(n + 1)],
+                     axis=1).astype(np.float32)
+        k = hip_nms(d, 0.7)
+        assert k == O.nms(d, 0.7), n
+        assert k == list(range(0, n, 2))                       # the alternating pattern
+        # the same boxes in reversed score order, and with a max_keep cut
+        d2 = d.copy()
+        d2[:, 4] = d[::-1, 4]
+        assert hip_nms(d2, 0.7) == O.nms(d2, 0.7)
+        assert hip_nms(d, 0.7, max_keep=10) == O.nms(d, 0.7)[:10]
+    # dense clusters: 40 clusters of 100 near-identical boxes, random scores
+    rs = np.random.RandomState(5)
+    centers = rs.uniform(100, 900, size=(40, 2))
+    c = np.repeat(centers, 100, axis=0) + rs.uniform(-3, 3, size=(4000, 2))
+    wh = 120.0 + rs.uniform(-4, 4, size=(4000, 2))
+    d = np.hstack((c - wh / 2, c + wh / 2, rs.permutation(4000)[:, None] / 4000.0)).astype(np.float32)
+    for th in (0.5, 0.7, 0.9):
+        assert hip_nms(d, th) == O.nms(d, th), th
+    # 12000 boxes in a tight field: long runs of chunks with few survivors
+    n = 12000
+    c = rs.uniform(0, 120, size=(n, 2)) * [1.0, 0.6]
+    wh = np.exp(rs.normal(4.5, 0.4, size=(n, 2)))
+    d = np.hstack((c - wh / 2, c + wh / 2, rs.permutation(n)[:, None] / float(n))).astype(np.float32)
+    assert hip_nms(d, 0.7, max_keep=2000) == O.nms(d, 0.7)[:2000]
