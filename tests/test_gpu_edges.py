@@ -415,3 +415,79 @@ def test_nms_suppression_chains(torch_cuda):
     wh = np.exp(rs.normal(4.5, 0.4, size=(n, 2)))
     d = np.hstack((c - wh / 2, c + wh / 2, rs.permutation(n)[:, None] / float(n))).astype(np.float32)
     assert hip_nms(d, 0.7, max_keep=2000) == O.nms(d, 0.7)[:2000]
+
+
+# ------------------------------------------------ plumbing: fused row batch-norm (+ReLU) ---
+def test_fused_row_batchnorm_matches_torch_ops(torch_cuda):
+    """csrc/plumbing/rowbn.hip against the stock-PyTorch formulation of the same layer
+    (float tolerance: different summation order, f64 column sums)."""
+    import torch
+    from wssdl_bus_amd.networks import _plumbing
+    from wssdl_bus_amd.networks.roi_head import RowBatchNorm, _RowBatchNormFn
+    assert _plumbing.lib() is not None
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for M, C in ((1000, 512), (4097, 2048), (333, 64), (50000, 1024), (7, 256)):
+        x = (torch.randn((M, C), device="cuda", generator=g) * 2.0 + 0.5)
+        w = torch.rand((C,), device="cuda", generator=g) + 0.5
+        b = torch.randn((C,), device="cuda", generator=g)
+        dy = torch.randn((M, C), device="cuda", generator=g)
+        for relu in (False, True):
+            assert _plumbing.usable(x)
+            bn = RowBatchNorm(C).cuda()
+            with torch.no_grad():
+                bn.weight.copy_(w)
+                bn.bias.copy_(b)
+            xa = x.clone().requires_grad_(True)
+            ya = bn(xa, relu=relu)
+            ya.backward(dy)
+            xb = x.clone().requires_grad_(True)
+            wb, bb = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            yb, mean, var = _RowBatchNormFn.apply(xb, wb, bb, bn.eps)
+            if relu:
+                yb = torch.relu(yb)
+            yb.backward(dy)
+            def close(a, e, tol):
+                return float((a - e).abs().max()) <= tol * (1.0 + float(e.abs().max()))
+            assert close(ya, yb, 1e-5), (M, C, relu)
+            assert close(xa.grad, xb.grad, 2e-4), (M, C, relu, float((xa.grad - xb.grad).abs().max()))
+            assert close(bn.weight.grad, wb.grad, 2e-4), (M, C, relu)
+            assert close(bn.bias.grad, bb.grad, 2e-4), (M, C, relu)
+            assert close(bn.running_mean, 0.01 * mean, 1e-5)
+            # inference statistics path
+            bn.eval()
+            with torch.no_grad():
+                ye = bn(x, relu=relu)
+                scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                ref = x * scale + (bn.bias - bn.running_mean * scale)
+                ref = torch.relu(ref) if relu else ref
+            assert close(ye, ref, 1e-5)
+    # unsupported width falls back to the stock ops
+    assert not _plumbing.usable(torch.zeros((10, 96), device="cuda"))
+
+
+def test_fused_batchnorm2d_channels_last_matches_stock(torch_cuda):
+    import torch
+    from wssdl_bus_amd.networks.backbones import BatchNormAct2d
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for shape in ((2, 64, 37, 50), (3, 256, 10, 17)):
+        x = torch.randn(shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+        for relu in (False, True):
+            a = BatchNormAct2d(shape[1], eps=1e-3, momentum=0.01).cuda()
+            b = torch.nn.BatchNorm2d(shape[1], eps=1e-3, momentum=0.01).cuda()
+            with torch.no_grad():
+                a.weight.uniform_(0.5, 1.5); a.bias.normal_()
+                b.weight.copy_(a.weight); b.bias.copy_(a.bias)
+            xa = x.clone().requires_grad_(True)
+            xb = x.clone().requires_grad_(True)
+            ya = a(xa, relu=relu)
+            yb = b(xb)
+            yb = torch.relu(yb) if relu else yb
+            assert ya.shape == yb.shape and ya.is_contiguous(memory_format=torch.channels_last)
+            ya.backward(dy)
+            yb.backward(dy)
+            for u, v, tol in ((ya, yb, 1e-5), (xa.grad, xb.grad, 2e-4), (a.weight.grad, b.weight.grad, 2e-4),
+                              (a.bias.grad, b.bias.grad, 2e-4), (a.running_mean, b.running_mean, 1e-5),
+                              (a.running_var, b.running_var, 1e-5)):
+                assert float((u - v).abs().max()) <= tol * (1.0 + float(v.abs().max())), (shape, relu)
+            assert int(a.num_batches_tracked) == 1

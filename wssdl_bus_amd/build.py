@@ -48,6 +48,29 @@ def build(force=False, verbose=True):
     return OUT
 
 
+# Second, separate library: kernels for the plumbing AROUND the hot path (fused row batch-norm
+# of the per-RoI head).  Not part of the drop-in C ABI, so it does not share its header.
+PLUMB_OUT = os.path.join(HERE, "libwssdl_plumbing_hip.so")
+PLUMB_SOURCES = [os.path.join("plumbing", "rowbn.hip")]
+PLUMB_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
+               "-Wall"]
+
+
+def build_plumbing(force=False, verbose=True):
+    srcs = [os.path.join(CSRC, s) for s in PLUMB_SOURCES]
+    if not force and os.path.exists(PLUMB_OUT) and \
+            all(os.path.getmtime(f) <= os.path.getmtime(PLUMB_OUT) for f in srcs + [os.path.abspath(__file__)]):
+        return PLUMB_OUT
+    cmd = [hipcc()] + PLUMB_FLAGS + srcs + ["-o", PLUMB_OUT + ".tmp"]
+    if verbose:
+        print("[wssdl_bus_amd] " + " ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(PLUMB_OUT + ".tmp", PLUMB_OUT)
+    return PLUMB_OUT
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_plumbing(force="--force" in sys.argv)
     print(OUT)
+    print(PLUMB_OUT)

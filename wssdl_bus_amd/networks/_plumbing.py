@@ -1,0 +1,109 @@
+"""ctypes binding of ``libwssdl_plumbing_hip.so``: fused row batch-norm (+ReLU) kernels for the
+per-RoI head (``csrc/plumbing/rowbn.hip``).  Plumbing around the hot path, not the drop-in C
+ABI; when the library has not been built the head falls back to stock PyTorch ops (slower,
+same maths) and says so once."""
+import ctypes
+import os
+import warnings
+
+import torch
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_HERE, "libwssdl_plumbing_hip.so")
+_lib = None
+_warned = [False]
+
+_vp, _i, _ll, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_size_t
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            if not _warned[0]:
+                _warned[0] = True
+                warnings.warn("%s not built: the per-RoI head uses stock PyTorch batch-norm ops "
+                              "(python -m wssdl_bus_amd.build builds it)" % LIB_PATH)
+            return None
+        L = ctypes.CDLL(LIB_PATH)
+        L.wsplumb_rowbn_workspace_bytes.restype = _sz
+        L.wsplumb_rowbn_workspace_bytes.argtypes = [_ll, _i]
+        L.wsplumb_rowbn_supported.restype = _i
+        L.wsplumb_rowbn_supported.argtypes = [_ll, _i]
+        L.wsplumb_rowbn_forward.restype = _i
+        L.wsplumb_rowbn_forward.argtypes = [_vp, _ll, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                            _vp, _sz, _vp]
+        L.wsplumb_rowbn_apply.restype = _i
+        L.wsplumb_rowbn_apply.argtypes = [_vp, _ll, _i, _vp, _vp, _i, _vp, _vp]
+        L.wsplumb_rowbn_backward.restype = _i
+        L.wsplumb_rowbn_backward.argtypes = [_vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
+                                             _vp, _vp, _sz, _vp]
+        _lib = L
+    return _lib
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def usable(x):
+    """True when the fused kernels can take this [M, C] tensor."""
+    if os.environ.get("WSSDL_DISABLE_FUSED_BN"):           # A/B switch for measurements
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()):
+        return False
+    L = lib()
+    return L is not None and bool(L.wsplumb_rowbn_supported(x.shape[0], x.shape[1]))
+
+
+def _workspace(L, M, C, dev):
+    n = L.wsplumb_rowbn_workspace_bytes(M, C)
+    return torch.empty((n,), dtype=torch.uint8, device=dev), n
+
+
+def rowbn_forward(x, weight, bias, eps, relu):
+    L = lib()
+    M, C = x.shape
+    dev = x.device
+    y = torch.empty_like(x)
+    stats = torch.empty((5, C), dtype=torch.float32, device=dev)   # mean, var, rstd, scale, shift
+    with torch.cuda.device(dev):
+        ws, n = _workspace(L, M, C, dev)
+        rc = L.wsplumb_rowbn_forward(_p(x), M, C, _p(weight), _p(bias), float(eps), int(relu), _p(y),
+                                     _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
+                                     _p(stats[4]), _p(ws), n, _stream())
+    if rc:
+        raise RuntimeError("wsplumb_rowbn_forward failed (%d)" % rc)
+    return y, stats
+
+
+def rowbn_apply(x, scale, shift, relu):
+    L = lib()
+    M, C = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = L.wsplumb_rowbn_apply(_p(x), M, C, _p(scale), _p(shift), int(relu), _p(y), _stream())
+    if rc:
+        raise RuntimeError("wsplumb_rowbn_apply failed (%d)" % rc)
+    return y
+
+
+def rowbn_backward(x, dy, weight, stats, relu):
+    L = lib()
+    M, C = x.shape
+    dev = x.device
+    dx = torch.empty_like(x)
+    dwb = torch.empty((2, C), dtype=torch.float32, device=dev)
+    coef = torch.empty((3, C), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws, n = _workspace(L, M, C, dev)
+        rc = L.wsplumb_rowbn_backward(_p(x), _p(dy), M, C, _p(weight), _p(stats[0]), _p(stats[2]),
+                                      _p(stats[3]), _p(stats[4]), int(relu), _p(dx), _p(dwb[0]),
+                                      _p(dwb[1]), _p(coef), _p(ws), n, _stream())
+    if rc:
+        raise RuntimeError("wsplumb_rowbn_backward failed (%d)" % rc)
+    return dx, dwb[0], dwb[1]

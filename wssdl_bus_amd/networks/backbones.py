@@ -13,6 +13,33 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class BatchNormAct2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters and buffers) whose forward can also apply the ReLU that
+    follows it.  On channels_last GPU tensors in training mode the layer runs on the fused row
+    batch-norm kernels of the plumbing library ([N,H,W,C] is an [N*H*W, C] row matrix there);
+    anywhere else it is the stock module followed by F.relu."""
+
+    def forward(self, x, relu=False):
+        if self.training and x.dim() == 4 and x.is_cuda and self.track_running_stats:
+            rows = x.permute(0, 2, 3, 1)
+            if rows.is_contiguous():
+                from . import _plumbing
+                from .roi_head import _FusedRowBatchNormFn
+                n, h, w, c = rows.shape
+                r2 = rows.reshape(-1, c)
+                if _plumbing.usable(r2):
+                    y, mean, var = _FusedRowBatchNormFn.apply(r2, self.weight, self.bias, self.eps, bool(relu))
+                    with torch.no_grad():
+                        m = r2.shape[0]
+                        mom = self.momentum if self.momentum is not None else 0.1
+                        self.running_mean.lerp_(mean, mom)
+                        self.running_var.lerp_(var * (m / max(m - 1, 1)), mom)
+                        self.num_batches_tracked += 1
+                    return y.view(n, h, w, c).permute(0, 3, 1, 2)
+        y = super().forward(x)
+        return F.relu(y) if relu else y
+
+
 def _same_pad(size, k, s):
     """TF 'SAME' padding along one axis: (before, after)."""
     out = -(-size // s)
@@ -31,7 +58,7 @@ class Conv(nn.Module):
         nn.init.trunc_normal_(self.conv.weight, std=0.01, a=-0.02, b=0.02)     # :110
         if self.conv.bias is not None:
             nn.init.zeros_(self.conv.bias)
-        self.bn = nn.BatchNorm2d(c_o, eps=1e-3, momentum=0.01) if norm == "BN" else None
+        self.bn = BatchNormAct2d(c_o, eps=1e-3, momentum=0.01) if norm == "BN" else None
 
     def forward(self, x):
         if self.padding == "SAME" and self.k > 1:
@@ -40,7 +67,7 @@ class Conv(nn.Module):
             x = F.pad(x, (pl, pr, pt, pb))
         x = self.conv(x)
         if self.bn is not None:
-            x = self.bn(x)
+            return self.bn(x, relu=self.relu)
         return F.relu(x) if self.relu else x
 
 
@@ -52,7 +79,7 @@ class Bottleneck(nn.Module):
         super().__init__()
         self.preact = preact
         if preact != "no_preact":
-            self.pre_bn = nn.BatchNorm2d(c_i, eps=1e-3, momentum=0.01) if norm == "BN" else None
+            self.pre_bn = BatchNormAct2d(c_i, eps=1e-3, momentum=0.01) if norm == "BN" else None
         self.conv1 = Conv(c_i, c_o, 1, 1, norm)
         self.conv2 = Conv(c_o, c_o, 3, s, norm)
         self.conv3 = Conv(c_o, c_o * 4, 1, 1, norm, relu=False)
@@ -61,8 +88,7 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         ori = x
         if self.preact != "no_preact":
-            y = self.pre_bn(x) if self.pre_bn is not None else x
-            y = F.relu(y)
+            y = self.pre_bn(x, relu=True) if self.pre_bn is not None else F.relu(x)
             if self.preact == "both_preact":
                 ori = y
             x = y
@@ -78,7 +104,7 @@ class BasicBlock(nn.Module):
         super().__init__()
         self.preact = preact
         if preact != "no_preact":
-            self.pre_bn = nn.BatchNorm2d(c_i, eps=1e-3, momentum=0.01) if norm == "BN" else None
+            self.pre_bn = BatchNormAct2d(c_i, eps=1e-3, momentum=0.01) if norm == "BN" else None
         self.conv1 = Conv(c_i, c_o, 3, s, norm)
         self.conv2 = Conv(c_o, c_o, 3, 1, norm, relu=False)
         self.short = Conv(c_i, c_o, 1, s, norm, relu=False) if c_i != c_o else None
@@ -86,8 +112,7 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         ori = x
         if self.preact != "no_preact":
-            y = self.pre_bn(x) if self.pre_bn is not None else x
-            y = F.relu(y)
+            y = self.pre_bn(x, relu=True) if self.pre_bn is not None else F.relu(x)
             if self.preact == "both_preact":
                 ori = y
             x = y
@@ -118,14 +143,14 @@ class ResNetTrunk(nn.Module):
         self.group0 = layer_group(block, 64, 64, defs[0], 1, norm, first=True)
         self.group1 = layer_group(block, 64 * e, 128, defs[1], 2, norm)
         self.group2 = layer_group(block, 128 * e, 256, defs[2], 2, norm)
-        self.norm = nn.BatchNorm2d(256 * e, eps=1e-3, momentum=0.01) if norm == "BN" else nn.Identity()
+        self.norm = BatchNormAct2d(256 * e, eps=1e-3, momentum=0.01) if norm == "BN" else None
         self.out_channels = 256 * e
 
     def forward(self, x):
         x = self.conv0(x)
         x = F.max_pool2d(x, 3, 2)                         # 'VALID'
         x = self.group2(self.group1(self.group0(x)))
-        return F.relu(self.norm(x))
+        return self.norm(x, relu=True) if self.norm is not None else F.relu(x)
 
 
 class ResNetHead(nn.Module):
@@ -136,11 +161,12 @@ class ResNetHead(nn.Module):
         defs, block = RESNET_DEFS[depth]
         e = block.expansion
         self.group3 = layer_group(block, 256 * e, 512, defs[3], 2, norm)
-        self.norm = nn.BatchNorm2d(512 * e, eps=1e-3, momentum=0.01) if norm == "BN" else nn.Identity()
+        self.norm = BatchNormAct2d(512 * e, eps=1e-3, momentum=0.01) if norm == "BN" else None
         self.out_features = 512 * e
 
     def forward(self, x):
-        x = F.relu(self.norm(self.group3(x)))
+        x = self.group3(x)
+        x = self.norm(x, relu=True) if self.norm is not None else F.relu(x)
         return x.mean(dim=(2, 3))
 
 

@@ -7,20 +7,24 @@ batch dimension (tens of seconds per new R on this stack), so the head does not 
 convolution kernels at all: RoI-pool output is already [R,7,7,C] NHWC, 1x1 convs are
 F.linear on [R*h*w, C] rows, 3x3 convs gather their TF-'SAME' patches and run one GEMM, and
 normalisation is batch-norm over rows.  GEMMs (rocBLAS/hipBLASLt) are shape-agnostic.
-Plumbing, not the product: stock PyTorch ops only.
+Plumbing, not the product: stock PyTorch ops, except that batch-norm (+ReLU) runs on the
+fused kernels of csrc/plumbing/rowbn.hip when that library is built (the activations are
+[R*h*w, C] with up to ~4e5 rows: separate elementwise passes over them were a third of the
+step).
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _plumbing
 from .backbones import RESNET_DEFS, _same_pad
 
 
 class _RowBatchNormFn(torch.autograd.Function):
     """Training-mode batch norm over the rows of [M, C] built from column reductions
-    (`var_mean`, `sum`) and fused elementwise ops.  PyTorch's native channels-last batch-norm
-    kernels take 12 ms forward+backward on a [136k, 2048] f32 tensor on MI355X; this form
-    takes about 2.5 ms.  Same maths (biased variance for normalisation)."""
+    (`var_mean`, `sum`) and fused elementwise ops (stock PyTorch; used on the CPU and when the
+    plumbing library is not built).  PyTorch's native channels-last batch-norm kernels take
+    12 ms forward+backward on a [136k, 2048] f32 tensor on MI355X; this form about 2.5 ms."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, eps):
@@ -48,8 +52,30 @@ class _RowBatchNormFn(torch.autograd.Function):
         return dx, sum_dy_xhat, sum_dy, None
 
 
+class _FusedRowBatchNormFn(torch.autograd.Function):
+    """The same layer (optionally with its ReLU) on the fused HIP kernels of
+    csrc/plumbing/rowbn.hip: 3 passes over the tensor forward, 5 backward, instead of 5 + 14
+    with separate elementwise ops; the ReLU mask is recomputed from x in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, relu):
+        y, stats = _plumbing.rowbn_forward(x, weight, bias, eps, relu)
+        ctx.save_for_backward(x, weight, stats)
+        ctx.relu = relu
+        mean, var = stats[0], stats[1]
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dmean, _dvar):
+        x, weight, stats = ctx.saved_tensors
+        dx, dw, db = _plumbing.rowbn_backward(x, dy.contiguous(), weight, stats, ctx.relu)
+        return dx, dw, db, None, None
+
+
 class RowBatchNorm(nn.Module):
-    """BatchNorm over rows ([M, C] input) with the usual running statistics."""
+    """BatchNorm over rows ([M, C] input) with the usual running statistics; `relu=True`
+    applies the ReLU that follows it in the network inside the same kernels."""
 
     def __init__(self, num_features, eps=1e-3, momentum=0.01):
         super().__init__()
@@ -59,11 +85,21 @@ class RowBatchNorm(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
 
-    def forward(self, x):
+    def forward(self, x, relu=False):
+        fused = _plumbing.usable(x)
         if not self.training:
             scale = self.weight * torch.rsqrt(self.running_var + self.eps)
-            return torch.addcmul(self.bias - self.running_mean * scale, x, scale)
-        y, mean, var = _RowBatchNormFn.apply(x, self.weight, self.bias, self.eps)
+            shift = self.bias - self.running_mean * scale
+            if fused and not torch.is_grad_enabled():
+                return _plumbing.rowbn_apply(x, scale.contiguous(), shift.contiguous(), relu)
+            y = torch.addcmul(shift, x, scale)
+            return F.relu(y) if relu else y
+        if fused:
+            y, mean, var = _FusedRowBatchNormFn.apply(x, self.weight, self.bias, self.eps, bool(relu))
+        else:
+            y, mean, var = _RowBatchNormFn.apply(x, self.weight, self.bias, self.eps)
+            if relu:
+                y = F.relu(y)
         with torch.no_grad():
             m = x.shape[0]
             self.running_mean.lerp_(mean, self.momentum)
@@ -100,15 +136,15 @@ class ConvNHWC(nn.Module):
             rows = p.permute(0, 1, 2, 4, 5, 3).reshape(-1, k * k * c)
         y = F.linear(rows, self.weight, self.bias)
         if self.bn is not None:
-            y = self.bn(y)
-        if self.relu:
+            y = self.bn(y, relu=self.relu)
+        elif self.relu:
             y = F.relu(y)
         return y.view(r, oh, ow, self.c_o)
 
 
-def _bn_rows(bn, x):
+def _bn_rows(bn, x, relu=False):
     r, h, w, c = x.shape
-    return bn(x.reshape(-1, c)).view(r, h, w, c)
+    return bn(x.reshape(-1, c), relu=relu).view(r, h, w, c)
 
 
 class BottleneckNHWC(nn.Module):
@@ -126,7 +162,7 @@ class BottleneckNHWC(nn.Module):
     def forward(self, x):
         ori = x
         if self.preact != "no_preact":
-            y = F.relu(_bn_rows(self.pre_bn, x) if self.pre_bn is not None else x)
+            y = _bn_rows(self.pre_bn, x, relu=True) if self.pre_bn is not None else F.relu(x)
             if self.preact == "both_preact":
                 ori = y
             x = y
@@ -148,7 +184,7 @@ class BasicBlockNHWC(nn.Module):
     def forward(self, x):
         ori = x
         if self.preact != "no_preact":
-            y = F.relu(_bn_rows(self.pre_bn, x) if self.pre_bn is not None else x)
+            y = _bn_rows(self.pre_bn, x, relu=True) if self.pre_bn is not None else F.relu(x)
             if self.preact == "both_preact":
                 ori = y
             x = y
@@ -173,6 +209,5 @@ class ResNetHeadNHWC(nn.Module):
 
     def forward(self, x):
         x = self.group3(x)
-        if self.norm is not None:
-            x = _bn_rows(self.norm, x)
-        return F.relu(x).mean(dim=(1, 2))
+        x = _bn_rows(self.norm, x, relu=True) if self.norm is not None else F.relu(x)
+        return x.mean(dim=(1, 2))
