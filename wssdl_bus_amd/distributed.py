@@ -19,7 +19,9 @@ class DistContext(object):
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.bucket_bytes = bucket_bytes
         self.backend = backend
-        self.enabled = self.world_size > 1
+        # WSSDL_FORCE_DIST=1: run the collective code path even with one rank (RCCL smoke test
+        # on a single-GPU box)
+        self.enabled = self.world_size > 1 or bool(os.environ.get("WSSDL_FORCE_DIST"))
         if self.enabled and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
