@@ -1,6 +1,6 @@
 # kernel-time breakdown of the default bench step (rocprofv3 kernel trace, timed steps only)
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_step -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline > gpurun_out/prof_step.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_step -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline $BENCH_ARGS > gpurun_out/prof_step.log 2>&1
 python3 - <<PY
 import csv,glob,os
 f=max(glob.glob("gpurun_out/prof_step/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)

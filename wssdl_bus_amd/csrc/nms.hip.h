@@ -29,15 +29,18 @@ int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int to
 // mask: per image [n_max, ceil(n_max/64)] u64, upper triangle written.
 // diag_t (optional): per image [n_max] u64, for box i the boxes of ITS OWN 64-chunk with a lower
 // index that suppress it (the transposed diagonal block), consumed by the pipelined sweep.
+// summ (optional): per image [n_max, nms_summary_words(n_max)] u64, bit w of a row = its mask
+// word w is non-zero (zeroed here); lets the sweep skip the loads of all-zero words.
+int nms_summary_words(int n_max);
 int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, int n_max,
                     int n_images, double thresh, unsigned long long *mask,
-                    unsigned long long *diag_t, hipStream_t st);
+                    unsigned long long *diag_t, unsigned long long *summ, hipStream_t st);
 
 // keep (optional) [n_images, max_keep] i32; rois_padded (optional) [n_images, max_keep, 5];
 // kept_scratch [n_images, max_keep + 64] i32: only needed when the kept list does not fit in
 // LDS (max_keep > ~15k), may be NULL otherwise.
 int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *diag_t,
-                     const int *n_dev, int n_max, int n_images,
+                     const unsigned long long *summ, const int *n_dev, int n_max, int n_images,
                      int max_keep, const int *order, int order_stride_img, int *keep,
                      int *num_keep, const float *boxes, int box_stride_img, float *rois_padded,
                      int *kept_scratch, hipStream_t st);

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void proposal_compact_kernel(
 }
 
 struct ProposalWs {
-    unsigned long long *keys, *cand, *thresh, *mask;
+    unsigned long long *keys, *cand, *thresh, *mask, *summ;
     float *boxes, *sorted_boxes;
     int *sorted_index, *n_sorted, *cand_fill, *kept;
 };
@@ -124,6 +124,7 @@ static size_t carve_proposal(void *ws, int N, int M, int topn, ProposalWs *out) 
     w.kept = c.take<int>((size_t)N * ((size_t)topn + 64));
     w.sorted_boxes = c.take<float>((size_t)N * topn * 4);
     w.mask = c.take<unsigned long long>((size_t)N * topn * ncb);
+    w.summ = c.take<unsigned long long>((size_t)N * topn * nms_summary_words(topn));
     if (out) *out = w;
     return c.off;
 }
@@ -193,11 +194,11 @@ static int proposal_layer_impl(int from_logits, const float *rpn_cls_prob, const
                        sidx, nsorted, M, topn, w.sorted_boxes);
     if ((rc = check_launch())) return rc;
     // w.cand is free once the ranking is done: it receives the transposed diagonal blocks
-    if ((rc = launch_nms_mask(w.sorted_boxes, topn * 4, nsorted, topn, N, nms_thresh, w.mask, w.cand, st)))
+    if ((rc = launch_nms_mask(w.sorted_boxes, topn * 4, nsorted, topn, N, nms_thresh, w.mask, w.cand, w.summ, st)))
         return rc;
     // the sweep writes (batch_idx, box) rows straight into rois_padded and stops
     // after `pitch` kept boxes
-    if ((rc = launch_nms_sweep(w.mask, w.cand, nsorted, topn, N, pitch, nullptr, 0, nullptr, roi_counts,
+    if ((rc = launch_nms_sweep(w.mask, w.cand, w.summ, nsorted, topn, N, pitch, nullptr, 0, nullptr, roi_counts,
                                w.sorted_boxes, topn * 4, rois_padded,
                                pitch <= topn ? w.kept : nullptr, st)))
         return rc;
