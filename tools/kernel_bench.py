@@ -116,6 +116,14 @@ def main():
     ms = timeit(lambda: hip_nms(dd, 0.7, max_keep=2000), args.iters)
     byt = n * 20 + 2 * n * ((n + 63) // 64) * 8 // 2
     out.append(dict(op="nms_12000_keep2000", ms=ms, alg_bytes=byt, GBps=byt / ms / 1e6))
+    # what this box sustains: device-to-device copy (read + write) and a pure write stream
+    nb = 1 << 30
+    a = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+    b = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+    ms = timeit(lambda: b.copy_(a), 10)
+    out.append(dict(op="d2d_copy_1GiB", ms=ms, alg_bytes=2 * nb, GBps=2 * nb / ms / 1e6))
+    ms = timeit(lambda: b.zero_(), 10)
+    out.append(dict(op="fill_1GiB", ms=ms, alg_bytes=nb, GBps=nb / ms / 1e6))
     for o in out:
         print(json.dumps(o))
 
