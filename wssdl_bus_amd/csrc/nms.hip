@@ -264,8 +264,27 @@ int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int to
 }
 
 // ------------------------------------------------------------------ nms mask ---
-__device__ __forceinline__ float fmax_ref(float a, float b) { return a >= b ? a : b; }  // cpu_nms.pyx:11
-__device__ __forceinline__ float fmin_ref(float a, float b) { return a <= b ? a : b; }  // cpu_nms.pyx:14
+// cpu_nms.pyx:11-15 define max(a, b) = a if a >= b else b (min likewise).  For finite operands
+// v_max_f32 / v_min_f32 return the same value up to the sign of a zero result, and a zero
+// result only ever feeds `x - zero` or `zero + 1.0f` here, which do not depend on that sign;
+// one instruction instead of compare + hazard nop + select (the kernel is VALU-bound).  NaN
+// coordinates (not a valid input) would differ.
+// (inline asm: __builtin_fmaxf would add a v_max x, x canonicalisation per operand in IEEE mode)
+__device__ __forceinline__ float fmax_ref(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fmin_ref(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fmax0_ref(float a) {      // max(0.0f, a)
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
+    return r;
+}
 
 __device__ __forceinline__ float box_area_ref(float x1, float y1, float x2, float y2) {
     float w = x2 - x1;  w = w + 1.0f;       // numpy f32: (x2 - x1 + 1) * (y2 - y1 + 1), cpu_nms.pyx:24
@@ -290,7 +309,9 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
     if (rb * 64 >= n || (seg + 1) * MASK_SEG <= rb || seg * MASK_SEG * 64 >= n) return;
     __shared__ float cbox[MASK_WAVES][5][64];
     const float *b = boxes + (size_t)img * box_stride_img;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // wave index through readfirstlane: the column-block loop and its trip counts are then
+    // scalar (loop control on the SALU)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = rb * 64 + lane;
     const bool row_ok = i < n;
     float ix1 = 0.f, iy1 = 0.f, ix2 = 0.f, iy2 = 0.f;
@@ -307,25 +328,57 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
         cbox[wave][3][lane] = y2; cbox[wave][4][lane] = box_area_ref(x1, y1, x2, y2);
         __builtin_amdgcn_wave_barrier();
         const int jn = min(64, n - cb * 64);
-        unsigned long long bits = 0ull;
-        for (int j = 0; j < jn; ++j) {
-            float xx1 = fmax_ref(ix1, cbox[wave][0][j]);
-            float yy1 = fmax_ref(iy1, cbox[wave][1][j]);
-            float xx2 = fmin_ref(ix2, cbox[wave][2][j]);
-            float yy2 = fmin_ref(iy2, cbox[wave][3][j]);
-            float w = xx2 - xx1;  w = fmax_ref(0.0f, w + 1.0f);
-            float h = yy2 - yy1;  h = fmax_ref(0.0f, h + 1.0f);
-            float inter = w * h;
+        // Pass 1, straight-line per column box: decide (double)(inter / den) >= thresh without
+        // the IEEE division whenever the quotient is at least 1e-4 (relative) away from the
+        // threshold -- the f32 rounding of the quotient (2^-24) cannot cross that margin;
+        // the undecided pairs (and den <= 0) are only marked.  Pass 2 settles the marked pairs
+        // with the exact test; they are rare, so pass 1 carries no branch.
+        // (two 32-column halves: 32-bit shift-or per flag instead of 64-bit shifts)
+        auto pair_flags = [&](int j, unsigned &yes_bit, unsigned &und_bit) {
+            const float xx1 = fmax_ref(ix1, cbox[wave][0][j]);
+            const float yy1 = fmax_ref(iy1, cbox[wave][1][j]);
+            const float xx2 = fmin_ref(ix2, cbox[wave][2][j]);
+            const float yy2 = fmin_ref(iy2, cbox[wave][3][j]);
+            float w = xx2 - xx1;  w = fmax0_ref(w + 1.0f);
+            float h = yy2 - yy1;  h = fmax0_ref(h + 1.0f);
+            const float inter = w * h;
             float den = iarea + cbox[wave][4][j];
             den = den - inter;
-            // (double)(inter / den) >= thresh, deciding without the IEEE division whenever the
-            // quotient is at least 1e-4 (relative) away from the threshold -- the f32 rounding
-            // of the quotient (2^-24) cannot cross that margin; otherwise the exact test
-            bool sup;
-            if (den > 0.0f && inter < den * t_lo) sup = false;
-            else if (den > 0.0f && inter > den * t_hi) sup = true;
-            else sup = (double)(inter / den) >= thresh;
-            if (sup) bits |= 1ull << j;
+            const bool yes = inter > den * t_hi;
+            const bool no = inter < den * t_lo;
+            const bool sure = (den > 0.0f) & (yes | no);
+            yes_bit = (sure & yes) ? 1u : 0u;
+            und_bit = sure ? 0u : 1u;
+        };
+        unsigned b_lo = 0u, b_hi = 0u, u_lo = 0u, u_hi = 0u;
+        const int j_lo = min(jn, 32);
+        for (int j = 0; j < j_lo; ++j) {
+            unsigned y, u;
+            pair_flags(j, y, u);
+            b_lo |= y << j;
+            u_lo |= u << j;
+        }
+        for (int j = 32; j < jn; ++j) {
+            unsigned y, u;
+            pair_flags(j, y, u);
+            b_hi |= y << (j - 32);
+            u_hi |= u << (j - 32);
+        }
+        unsigned long long bits = ((unsigned long long)b_hi << 32) | b_lo;
+        unsigned long long undecided = ((unsigned long long)u_hi << 32) | u_lo;
+        while (undecided != 0ull) {
+            const int j = __ffsll((long long)undecided) - 1;
+            undecided &= undecided - 1ull;
+            const float xx1 = fmax_ref(ix1, cbox[wave][0][j]);
+            const float yy1 = fmax_ref(iy1, cbox[wave][1][j]);
+            const float xx2 = fmin_ref(ix2, cbox[wave][2][j]);
+            const float yy2 = fmin_ref(iy2, cbox[wave][3][j]);
+            float w = xx2 - xx1;  w = fmax0_ref(w + 1.0f);
+            float h = yy2 - yy1;  h = fmax0_ref(h + 1.0f);
+            const float inter = w * h;
+            float den = iarea + cbox[wave][4][j];
+            den = den - inter;
+            if ((double)(inter / den) >= thresh) bits |= 1ull << j;
         }
         if (cb == rb) {
             // diagonal block.  The test is symmetric in the two boxes (max/min and the area sum
