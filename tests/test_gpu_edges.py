@@ -491,3 +491,39 @@ def test_fused_batchnorm2d_channels_last_matches_stock(torch_cuda):
                               (a.running_var, b.running_var, 1e-5)):
                 assert float((u - v).abs().max()) <= tol * (1.0 + float(v.abs().max())), (shape, relu)
             assert int(a.num_batches_tracked) == 1
+
+
+def test_proposal_target_device_sampling_short_image(torch_cuda):
+    """Fewer background candidates than the quota: the image contributes fewer than
+    rois_per_image rows (the padded -1 slots of the sampler are dropped), like the reference."""
+    import torch
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.rpn_msr import proposal_target_layer_tf_bus as ptl
+    dev = torch.device("cuda", 0)
+    gt = np.zeros((2, 20, 5), np.float32)
+    gt[0, 0] = [100, 100, 300, 300, 1]
+    gt[1, 0] = [50, 60, 250, 220, 2]
+    ng = np.array([1, 1], np.int32)
+    rs = np.random.RandomState(0)
+    # image 0: 200 rois all close to its gt box (all fg, no bg); image 1: 40 fg-like + 500 far away
+    j0 = np.hstack([np.zeros((200, 1)), np.array([100, 100, 300, 300]) + rs.uniform(-6, 6, (200, 4))])
+    j1 = np.hstack([np.ones((40, 1)), np.array([50, 60, 250, 220]) + rs.uniform(-6, 6, (40, 4))])
+    far = rs.uniform(400, 900, (500, 2))
+    f1 = np.hstack([np.ones((500, 1)), far, far + rs.uniform(20, 80, (500, 2))])
+    rois = np.vstack([j0, j1, f1]).astype(np.float32)
+    old = cfg.SAMPLING_RNG
+    cfg.SAMPLING_RNG = "device"
+    try:
+        o = ptl.proposal_target_layer(torch.from_numpy(rois).to(dev), torch.from_numpy(gt).to(dev),
+                                      torch.from_numpy(ng).to(dev), 3, True, False)
+        out_rois, labels = o[0].cpu().numpy(), o[1].cpu().numpy()[:, 0]
+        fg_rpi = int(np.round(cfg.TRAIN.FG_FRACTION * cfg.TRAIN.BATCH_SIZE))
+        n0 = int(np.sum(out_rois[:, 0] == 0))
+        n1 = int(np.sum(out_rois[:, 0] == 1))
+        assert n0 == fg_rpi                      # all candidates of image 0 are fg: 32 fg, 0 bg
+        assert n1 == int(cfg.TRAIN.BATCH_SIZE)   # image 1: 32 fg + 96 bg
+        assert np.all(labels[:n0] == 1)
+        assert np.all(labels[n0:n0 + fg_rpi] == 2) and np.all(labels[n0 + fg_rpi:] == 0)
+        assert o[2].shape == (n0 + n1, 12)
+    finally:
+        cfg.SAMPLING_RNG = old
