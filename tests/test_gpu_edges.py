@@ -527,3 +527,29 @@ def test_proposal_target_device_sampling_short_image(torch_cuda):
         assert o[2].shape == (n0 + n1, 12)
     finally:
         cfg.SAMPLING_RNG = old
+
+
+def test_im2col3x3_matches_unfold(torch_cuda):
+    """csrc/plumbing/im2col.hip against the stock pad -> unfold -> permute route (exact: copies
+    forward; the adjoint adds at most 9 terms in a fixed order, compared with a tolerance)."""
+    import torch
+    import torch.nn.functional as F
+    from wssdl_bus_amd.networks import _plumbing
+    from wssdl_bus_amd.networks.backbones import _same_pad
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for (r, h, w, c, s) in ((5, 7, 7, 64, 2), (3, 4, 4, 512, 1), (2, 5, 6, 32, 1), (4, 7, 7, 16, 1), (1, 1, 1, 8, 1)):
+        x = torch.randn((r, h, w, c), device="cuda", generator=g)
+        pt, pb = _same_pad(h, 3, s)
+        pl, pr = _same_pad(w, 3, s)
+        oh, ow = -(-h // s), -(-w // s)
+        xa = x.clone().requires_grad_(True)
+        assert _plumbing.im2col_usable(xa)
+        ca = _plumbing.Im2Col3x3Fn.apply(xa, s, oh, ow, pt, pl)
+        xb = x.clone().requires_grad_(True)
+        p = F.pad(xb, (0, 0, pl, pr, pt, pb)).unfold(1, 3, s).unfold(2, 3, s)
+        cb = p.permute(0, 1, 2, 4, 5, 3).reshape(-1, 9 * c)
+        assert ca.shape == cb.shape and torch.equal(ca, cb), (r, h, w, c, s)
+        d = torch.randn(ca.shape, device="cuda", generator=g)
+        ca.backward(d)
+        cb.backward(d)
+        assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * (1.0 + float(xb.grad.abs().max()))

@@ -51,7 +51,7 @@ def build(force=False, verbose=True):
 # Second, separate library: kernels for the plumbing AROUND the hot path (fused row batch-norm
 # of the per-RoI head).  Not part of the drop-in C ABI, so it does not share its header.
 PLUMB_OUT = os.path.join(HERE, "libwssdl_plumbing_hip.so")
-PLUMB_SOURCES = [os.path.join("plumbing", "rowbn.hip")]
+PLUMB_SOURCES = [os.path.join("plumbing", "rowbn.hip"), os.path.join("plumbing", "im2col.hip")]
 PLUMB_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
                "-Wall"]
 

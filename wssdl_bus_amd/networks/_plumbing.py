@@ -38,6 +38,10 @@ def lib():
         L.wsplumb_rowbn_backward.restype = _i
         L.wsplumb_rowbn_backward.argtypes = [_vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
                                              _vp, _vp, _sz, _vp]
+        for name in ("wsplumb_im2col3x3", "wsplumb_col2im3x3"):
+            f = getattr(L, name)
+            f.restype = _i
+            f.argtypes = [_vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]
         _lib = L
     return _lib
 
@@ -107,3 +111,39 @@ def rowbn_backward(x, dy, weight, stats, relu):
     if rc:
         raise RuntimeError("wsplumb_rowbn_backward failed (%d)" % rc)
     return dx, dwb[0], dwb[1]
+
+
+def im2col_usable(x):
+    """True when the 3x3 patch kernels can take this [R, h, w, C] tensor."""
+    if os.environ.get("WSSDL_DISABLE_FUSED_IM2COL"):       # A/B switch for measurements
+        return False
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and x.shape[3] % 4 == 0 and x.shape[0] > 0 and lib() is not None)
+
+
+class Im2Col3x3Fn(torch.autograd.Function):
+    """[R, h, w, C] -> [R*oh*ow, 9*C] patches (kh, kw, c), TF 'SAME' padding given by (pt, pl)."""
+
+    @staticmethod
+    def forward(ctx, x, stride, oh, ow, pt, pl):
+        L = lib()
+        r, h, w, c = x.shape
+        cols = torch.empty((r * oh * ow, 9 * c), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = L.wsplumb_im2col3x3(_p(x), r, h, w, c, oh, ow, stride, pt, pl, _p(cols), _stream())
+        if rc:
+            raise RuntimeError("wsplumb_im2col3x3 failed (%d)" % rc)
+        ctx.geom = (r, h, w, c, oh, ow, stride, pt, pl)
+        return cols
+
+    @staticmethod
+    def backward(ctx, dcols):
+        L = lib()
+        r, h, w, c, oh, ow, stride, pt, pl = ctx.geom
+        dcols = dcols.contiguous()
+        dx = torch.empty((r, h, w, c), dtype=torch.float32, device=dcols.device)
+        with torch.cuda.device(dcols.device):
+            rc = L.wsplumb_col2im3x3(_p(dcols), r, h, w, c, oh, ow, stride, pt, pl, _p(dx), _stream())
+        if rc:
+            raise RuntimeError("wsplumb_col2im3x3 failed (%d)" % rc)
+        return dx, None, None, None, None, None

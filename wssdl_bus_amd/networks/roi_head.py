@@ -127,6 +127,11 @@ class ConvNHWC(nn.Module):
                 x = x[:, ::s, ::s, :]
             oh, ow = x.shape[1], x.shape[2]
             rows = x.reshape(-1, c)
+        elif k == 3 and _plumbing.im2col_usable(x):
+            pt, pb = _same_pad(h, k, s)
+            pl, pr = _same_pad(w, k, s)
+            oh, ow = -(-h // s), -(-w // s)
+            rows = _plumbing.Im2Col3x3Fn.apply(x, s, oh, ow, pt, pl)
         else:
             pt, pb = _same_pad(h, k, s)
             pl, pr = _same_pad(w, k, s)
