@@ -109,9 +109,9 @@ __global__ __launch_bounds__(BLOCK) void rowbn_partial_kernel(
     }
 }
 
-// Sum of the per-workgroup partials of 64 columns, in a fixed order: 16 row groups of 64 lanes
-// each add every 16th partial (in order), then lane-wise the 16 group sums are added in order.
-constexpr int FIN_COLS = 64, FIN_GROUPS = 16;
+// Sum of the per-workgroup partials of 16 columns, in a fixed order: 64 row groups of 16 lanes
+// each add every 64th partial (in order), then lane-wise the 64 group sums are added in order.
+constexpr int FIN_COLS = 16, FIN_GROUPS = 64;
 
 __device__ __forceinline__ void finish_reduce(const double *__restrict__ partial, int nblocks, int C,
                                               int c, int grp, double (*red)[FIN_COLS][2], double &s,
