@@ -6,7 +6,7 @@ python3 - <<PY
 import csv,glob
 import os; f=max(glob.glob("gpurun_out/prof_sw/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
 for r in csv.DictReader(open(f)):
-    if "nms_" in r["Name"] or "topk" in r["Name"]: print("%-44s calls=%4s avg_us=%9.2f" % (r["Name"][:44], r["Calls"], float(r["AverageNs"])/1e3))
+    if any(k in r["Name"] for k in ("nms_", "topk", "rank_")): print("%-44s calls=%4s avg_us=%9.2f" % (r["Name"][:44], r["Calls"], float(r["AverageNs"])/1e3))
 PY
 python3 tools/kernel_bench.py --config 3 --iters 10 2>&1 | grep "proposal_layer\|nms_12000"
 python3 tools/kernel_bench.py --config 5 --iters 10 2>&1 | grep "proposal_layer\|nms_"

@@ -31,8 +31,8 @@ namespace wssdl {
 // ---------------------------------------------------------------- rank/top-k ---
 // Descending order of the topn largest 64-bit keys of each image, in three steps:
 //   topk_threshold : the topn-th largest key by MSB-first radix select (one workgroup per
-//                    image, 8 histogram passes over the keys; keys are unique);
-//   topk_compact   : keys >= threshold -> dense candidate array (any order);
+//                    image; keys are unique), then keys >= threshold -> dense candidate
+//                    array (any order) by the same workgroup;
 //   rank_topk      : position of every candidate = number of greater candidates, counted over
 //                    LDS-staged tiles -- O(topn^2) instead of O(M^2) compares.
 // 64-bit keys = (order-preserving score bits << 32 | index) make the order total (ties:
@@ -42,8 +42,10 @@ constexpr int SEL_LIST = 512;
 
 __global__ __launch_bounds__(SEL_BLOCK) void topk_threshold_kernel(
     const unsigned long long *__restrict__ keys, int M, int topn,
-    unsigned long long *__restrict__ thresh, int *__restrict__ n_sorted) {
+    unsigned long long *__restrict__ thresh, int *__restrict__ n_sorted,
+    unsigned long long *__restrict__ cand) {
     __shared__ SelectScratch<SEL_LIST> sc;
+    __shared__ int s_fill;
     const int img = blockIdx.x, t = threadIdx.x;
     const unsigned long long *k = keys + (size_t)img * M;
     int valid = 0;
@@ -51,23 +53,31 @@ __global__ __launch_bounds__(SEL_BLOCK) void topk_threshold_kernel(
     const unsigned long long th = block_radix_select<SEL_BLOCK, SEL_LIST, true>(
         [k](int i, unsigned long long &v) { v = k[i]; return v != 0ull; }, M,
         [topn](int members) { return members > topn ? topn : 0; }, sc, &valid);
+    const unsigned long long cut = valid > topn ? th : 1ull;
     if (t == 0) {
         n_sorted[img] = min(valid, topn);
-        thresh[img] = valid > topn ? th : 1ull;
+        thresh[img] = cut;
+        s_fill = 0;
     }
-}
-
-__global__ __launch_bounds__(256) void topk_compact_kernel(
-    const unsigned long long *__restrict__ keys, int M, int topn,
-    const unsigned long long *__restrict__ thresh, unsigned long long *__restrict__ cand,
-    int *__restrict__ cand_fill) {
-    const int img = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    const unsigned long long v = keys[(size_t)img * M + i];
-    if (v != 0ull && v >= thresh[img]) {
-        const int pos = atomicAdd(&cand_fill[img], 1);
-        if (pos < topn) cand[(size_t)img * topn + pos] = v;
+    __syncthreads();
+    // compaction by the same workgroup: keys >= cut -> dense candidate array, any order (the
+    // ranking that follows orders them).  One LDS atomic per wave and step; a separate kernel
+    // with global atomics on one counter took 33 us for this.
+    const int lane = t & 63;
+    for (int i0 = 0; i0 < M; i0 += SEL_BLOCK) {
+        const int i = i0 + t;
+        const unsigned long long v = (i < M) ? k[i] : 0ull;
+        const bool take = v != 0ull && v >= cut;
+        const unsigned long long m = __ballot(take);
+        if (m == 0ull) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&s_fill, __popcll(m));
+        base = __builtin_amdgcn_readlane(base, leader);
+        if (take) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < topn) cand[(size_t)img * topn + pos] = v;
+        }
     }
 }
 
@@ -241,13 +251,11 @@ int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int to
                      int *sorted_index, int *n_sorted, void *scratch, size_t scratch_bytes,
                      hipStream_t st) {
     // sorted_index must be pre-filled with -1 and cand_fill with 0 by the caller
+    (void)cand_fill;
     hipLaunchKernelGGL(topk_threshold_kernel, dim3(n_images), dim3(SEL_BLOCK), 0, st, keys, M, topn,
-                       thresh, n_sorted);
+                       thresh, n_sorted, cand);
     int rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(topk_compact_kernel, dim3(cdiv(M, 256), n_images), dim3(256), 0, st, keys, M,
-                       topn, thresh, cand, cand_fill);
-    if ((rc = check_launch())) return rc;
     if (topn >= 4096 && scratch && scratch_bytes >= rank_topk_scratch_bytes(n_images, topn)) {
         unsigned long long *grouped = static_cast<unsigned long long *>(scratch);
         int *boff = reinterpret_cast<int *>(grouped + (size_t)n_images * topn);
