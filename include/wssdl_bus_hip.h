@@ -193,6 +193,14 @@ WSSDL_API int wssdl_anchor_targets(const int8_t *labels, const int32_t *argmax_g
 WSSDL_API int wssdl_roi_gt_assign(const float *rois, int R, const float *gt_boxes, int max_gt,
                         const int32_t *num_pos_boxes, int n_images, double *max_overlap,
                         int32_t *assignment, wssdl_stream_t stream);
+/* Stage 0 (device path): candidate rows = rois [R,5] followed, when append_gt, by the max_gt gt
+ *   slots of each image images[s] (:44-50); a slot's batch index is the image for its positive
+ *   boxes (the first num_pos rows) and -1 otherwise.  cand [R + n_sample_images*max_gt, 5];
+ *   num_pos_boxes [n_images] = boxes with class != 0 among the num_gt_boxes valid rows (:40-42). */
+WSSDL_API int wssdl_roi_candidates(const float *rois, int R, const float *gt_boxes, int max_gt,
+                         const int32_t *num_gt_boxes, int n_images, const int32_t *images,
+                         int n_sample_images, int append_gt, float *cand, int32_t *num_pos_boxes,
+                         wssdl_stream_t stream);
 WSSDL_API int wssdl_roi_sample_device(const float *cand, const double *max_overlap, int Rc,
                             const int32_t *images, int n_sample_images, int rois_per_image,
                             int fg_rois_per_image, double fg_thresh, double bg_thresh_hi,

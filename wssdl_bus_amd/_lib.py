@@ -43,6 +43,7 @@ SYMBOLS = {
     "wssdl_anchor_targets": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _d,
                                   _vp, _vp, _vp, _vp, _vp]),
     "wssdl_roi_gt_assign": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "wssdl_roi_candidates": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "wssdl_roi_sample_device": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _d, _d, _d, _u64, _vp, _vp, _vp, _vp]),
     "wssdl_roi_targets": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp]),

@@ -105,6 +105,38 @@ __global__ __launch_bounds__(256) void roi_targets_kernel(
     labels[p] = label;
 }
 
+// ------------------------------------------------------- candidate rows ---
+// :40-50 on the device: cand = rpn_rois followed, per supervised image, by all max_gt slots of
+// its gt array; a slot carries the image's batch index when it is one of the image's positive
+// boxes (the first num_pos rows: class != 0 among the num_gt valid rows) and -1 otherwise, so
+// that it can never be drawn.  Also emits num_pos per image.
+__global__ __launch_bounds__(256) void roi_candidates_kernel(
+    const float *__restrict__ rois, int R, const float *__restrict__ gt_boxes, int max_gt,
+    const int *__restrict__ num_gt, int n_images, const int *__restrict__ images, int S,
+    int append_gt, float *__restrict__ cand, int *__restrict__ num_pos) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    auto count_pos = [&](int img) {
+        const int ng = min(max(num_gt[img], 0), max_gt);
+        int c = 0;
+        for (int k = 0; k < ng; ++k) c += gt_boxes[((size_t)img * max_gt + k) * 5 + 4] != 0.0f ? 1 : 0;
+        return c;
+    };
+    if (row < n_images) num_pos[row] = count_pos(row);
+    const int total = R + (append_gt ? S * max_gt : 0);
+    if (row >= total) return;
+    float *o = cand + (size_t)row * 5;
+    if (row < R) {
+        const float *b = rois + (size_t)row * 5;
+        o[0] = b[0]; o[1] = b[1]; o[2] = b[2]; o[3] = b[3]; o[4] = b[4];
+        return;
+    }
+    const int s = (row - R) / max_gt, k = (row - R) % max_gt;
+    const int img = images[s];
+    const float *g = gt_boxes + ((size_t)img * max_gt + k) * 5;
+    o[0] = (k < count_pos(img)) ? (float)img : -1.0f;
+    o[1] = g[0]; o[2] = g[1]; o[3] = g[2]; o[4] = g[3];
+}
+
 // ------------------------------------------------------- device sampling ---
 constexpr int RS_BLOCK = 1024;
 
@@ -271,5 +303,21 @@ extern "C" int wssdl_roi_sample_device(const float *cand, const double *max_over
     hipLaunchKernelGGL(roi_sample_kernel, dim3(n_sample_images), dim3(RS_BLOCK), 0, as_stream(stream),
                        cand, max_overlap, Rc, images, rois_per_image, fg_rois_per_image, fg_thresh,
                        bg_thresh_hi, bg_thresh_lo, (unsigned long long)seed, keep, is_fg, counts);
+    return check_launch();
+}
+
+extern "C" int wssdl_roi_candidates(const float *rois, int R, const float *gt_boxes, int max_gt,
+                                    const int32_t *num_gt_boxes, int n_images, const int32_t *images,
+                                    int n_sample_images, int append_gt, float *cand,
+                                    int32_t *num_pos_boxes, wssdl_stream_t stream) {
+    if (R < 0 || max_gt < 1 || n_images < 1 || n_sample_images < 0) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (!gt_boxes || !num_gt_boxes || !num_pos_boxes || !cand || (R > 0 && !rois) ||
+        (n_sample_images > 0 && !images))
+        return WSSDL_ERR_INVALID_ARGUMENT;
+    const int total = R + (append_gt ? n_sample_images * max_gt : 0);
+    const int threads = total > n_images ? total : n_images;
+    hipLaunchKernelGGL(roi_candidates_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, as_stream(stream),
+                       rois, R, gt_boxes, max_gt, num_gt_boxes, n_images, images, n_sample_images,
+                       append_gt, cand, num_pos_boxes);
     return check_launch();
 }

@@ -75,22 +75,17 @@ def _supervised_device(rois, gt_dev, ng_dev, images, append_gt, num_classes):
         fg_rpi = int(np.round(cfg.TRAIN.FG_FRACTION * rpi))
         iw = np.ascontiguousarray(cfg.TRAIN.BBOX_INSIDE_WEIGHTS, dtype=np.float32)
         with torch.cuda.device(dev):
-            ar = torch.arange(max_gt, device=dev)
-            valid = ar[None, :] < ng_dev[:, None].to(torch.int64)
-            num_pos_dev = ((gt_dev[:, :, 4] != 0) & valid).sum(dim=1).to(torch.int32)
-            images_dev = torch.as_tensor(list(images), dtype=torch.int32, device=dev)
-            if append_gt and S > 0:                                    # :44-50
-                # every gt slot of the supervised images is appended; slots past the image's
-                # positives carry batch index -1 and can never be drawn
-                sel = images_dev.to(torch.int64)
-                g = gt_dev.index_select(0, sel)                         # [S, max_gt, 5]
-                pos = ar[None, :] < num_pos_dev.index_select(0, sel)[:, None].to(torch.int64)
-                b = torch.where(pos, sel[:, None].to(torch.float32).expand(S, max_gt),
-                                torch.full((), -1.0, device=dev))
-                extra = torch.cat([b[:, :, None], g[:, :, :4]], dim=2).reshape(S * max_gt, 5)
-                cand = torch.cat([rois, extra], dim=0).contiguous()
-            else:
-                cand = rois
+            images_dev = _images_tensor(images, dev)
+            R = int(rois.shape[0])
+            # every gt slot of the supervised images is appended (:44-50); slots past the image's
+            # positives carry batch index -1 and can never be drawn
+            Rc = R + (S * max_gt if append_gt else 0)
+            cand = torch.empty((Rc, 5), dtype=torch.float32, device=dev)
+            num_pos_dev = torch.empty((n_img,), dtype=torch.int32, device=dev)
+            _lib.check(L.wssdl_roi_candidates(_lib.ptr(rois), R, _lib.ptr(gt_dev), max_gt,
+                                              _lib.ptr(ng_dev), n_img, _lib.ptr(images_dev), S,
+                                              int(bool(append_gt)), _lib.ptr(cand), _lib.ptr(num_pos_dev),
+                                              _lib.stream()), "wssdl_roi_candidates")
             Rc = cand.shape[0]
             max_ov = torch.empty((Rc,), dtype=torch.float64, device=dev)
             assign = torch.empty((Rc,), dtype=torch.int32, device=dev)
@@ -107,7 +102,7 @@ def _supervised_device(rois, gt_dev, ng_dev, images, append_gt, num_classes):
                 float(cfg.TRAIN.FG_THRESH), float(cfg.TRAIN.BG_THRESH_HI),
                 float(cfg.TRAIN.BG_THRESH_LO), seed, _lib.ptr(keep), _lib.ptr(is_fg),
                 _lib.ptr(counts), _lib.stream()), "wssdl_roi_sample_device")
-            n_rows = counts.sum(dim=1).cpu().numpy()                    # the layer's one sync
+            n_rows = counts.cpu().numpy().sum(axis=1)                   # the layer's one sync
             if int(n_rows.sum()) == S * rpi:
                 keep_flat, fg_flat = keep.reshape(-1), is_fg.reshape(-1)
             else:                                                       # an image ran short of bg rows
@@ -125,6 +120,18 @@ def _supervised_device(rois, gt_dev, ng_dev, images, append_gt, num_classes):
                 _lib.ptr(out_rois), _lib.ptr(labels), _lib.ptr(tg), _lib.ptr(inw), _lib.ptr(outw),
                 _lib.stream()), "wssdl_roi_targets")
         return [out_rois, labels, tg, inw, outw]
+
+
+_images_cache = {}
+
+
+def _images_tensor(images, dev):
+    key = (tuple(images), str(dev))
+    t = _images_cache.get(key)
+    if t is None:
+        t = torch.as_tensor(list(images), dtype=torch.int32, device=dev)
+        _images_cache[key] = t
+    return t
 
 
 def _use_device_rng(rng):
