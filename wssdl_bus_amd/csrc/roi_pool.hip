@@ -335,28 +335,35 @@ __device__ __forceinline__ void visit_rows(const WalkCtx &x, __amdgpu_buffer_rsr
     }
 }
 
-template <int PWN, int TW, int CG, bool FAST, int FWR = 8>
+template <int PWN, int TW, int CG, bool FAST, int MAXB, int FWR = 8>
 __device__ __forceinline__ void visit_roi(const WalkCtx &x, __amdgpu_buffer_rsrc_t ra,
                                           __amdgpu_buffer_rsrc_t rt, int so_row, int bin_bytes,
                                           int row_bytes, unsigned long long rowmask, int phn,
                                           unsigned long long colmask) {
+    // NR bin rows per batch: at most MAXB (argmax, top_diff) load pairs in flight per wave
+    constexpr int NR = (MAXB / PWN) >= 4 ? 4 : ((MAXB / PWN) >= 3 ? 3 : 2);
     int rb = 0;
-    for (; rb + 2 <= phn; rb += 2, so_row += 2 * row_bytes)
+    for (; rb + NR <= phn; rb += NR, so_row += NR * row_bytes)
+        visit_rows<PWN, NR, TW, CG, FAST, FWR>(x, ra, rt, so_row, bin_bytes, row_bytes, rowmask, rb, colmask);
+    const int rem = phn - rb;
+    if (NR > 3 && rem == 3)
+        visit_rows<PWN, 3, TW, CG, FAST, FWR>(x, ra, rt, so_row, bin_bytes, row_bytes, rowmask, rb, colmask);
+    else if (NR > 2 && rem == 2)
         visit_rows<PWN, 2, TW, CG, FAST, FWR>(x, ra, rt, so_row, bin_bytes, row_bytes, rowmask, rb, colmask);
-    if (rb < phn)
+    else if (rem == 1)
         visit_rows<PWN, 1, TW, CG, FAST, FWR>(x, ra, rt, so_row, bin_bytes, row_bytes, rowmask, rb, colmask);
 }
 
 // FAST: C is a power of two (idx -> cell by shift) and cell / W fits a 24-bit multiply.
-template <int TH, int TW, int CG, int CHUNK, bool FAST>
-__global__ __launch_bounds__(CG) void roi_pool_bwd_kernel(
+template <int TH, int TW, int CG, int CHUNK, bool FAST, int MAXB, int MINB>
+__global__ __launch_bounds__(CG, MINB) void roi_pool_bwd_kernel(
     const float *__restrict__ top_diff, const int *__restrict__ argmax,
     const float *__restrict__ rois, int R, int N, int H, int W, int C, int PH, int PW, float scale,
     float *__restrict__ bottom_diff, int tiles_h, int tiles_w, int cgroups, int cshift,
     FastDiv divw) {
     static_assert(TH <= 8 && TW <= 8, "one mask byte per candidate bin row / column");
-    static_assert(CHUNK % CG == 0, "whole filter rounds");
-    constexpr int KPT = CHUNK / CG;        // RoIs tested per thread per filter round
+    static_assert(CHUNK % CG == 0 || CG % CHUNK == 0, "whole filter rounds");
+    constexpr int KPT = CHUNK >= CG ? CHUNK / CG : 1;   // RoIs tested per thread per filter round
     constexpr int NW = CG / WSSDL_WAVE;
     __shared__ float acc[TH * TW * CG];
     __shared__ TouchRec list[CHUNK];
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(CG) void roi_pool_bwd_kernel(
         for (int k = 0; k < KPT; ++k) {
             const int r = base + k * CG + tc;
             hit[k] = false;
-            if (r < r_end) {
+            if (r < r_end && k * CG + tc < CHUNK) {
                 gk[k] = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);
                 const RoiGeom &g = gk[k];
                 hit[k] = (g.batch == n) && g.sw <= w1 && g.ew >= w0 && g.sh <= h1 && g.eh >= h0;
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(CG) void roi_pool_bwd_kernel(
                     const_cast<float *>(top_diff + rbin0 * C), 0, roi_bytes, 0x00020000);
                 const int bin_bytes = C * 4, row_bytes = PW * C * 4;
                 const int so_row = (ph0 * PW + pw0) * bin_bytes;     // scalar byte offset of the first bin
-#define WSSDL_VISIT(K) visit_roi<K, TW, CG, FAST>(wx, ra, rt, so_row, bin_bytes, row_bytes, rowmask, phn, colmask)
+#define WSSDL_VISIT(K) visit_roi<K, TW, CG, FAST, MAXB>(wx, ra, rt, so_row, bin_bytes, row_bytes, rowmask, phn, colmask)
                 switch (pwn) {                                       // wave-uniform
                     case 1: WSSDL_VISIT(1); break;
                     case 2: WSSDL_VISIT(2); break;
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(CG) void roi_pool_bwd_kernel(
     }
 }
 
-template <int TH, int TW, int CG, int CHUNK>
+template <int TH, int TW, int CG, int CHUNK, int MAXB = 8, int MINB = 1>
 static int launch_bwd(const float *top_diff, const int *argmax, const float *rois, int R, int N,
                       int H, int W, int C, int PH, int PW, float scale, float *bottom_diff,
                       hipStream_t st) {
@@ -577,11 +584,11 @@ static int launch_bwd(const float *top_diff, const int *argmax, const float *roi
         fast = found;
     }
     if (fast)
-        hipLaunchKernelGGL((roi_pool_bwd_kernel<TH, TW, CG, CHUNK, true>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL((roi_pool_bwd_kernel<TH, TW, CG, CHUNK, true, MAXB, MINB>), dim3((unsigned)blocks),
                            dim3(CG), 0, st, top_diff, argmax, rois, R, N, H, W, C, PH, PW, scale,
                            bottom_diff, tiles_h, tiles_w, cgroups, cshift, dw);
     else
-        hipLaunchKernelGGL((roi_pool_bwd_kernel<TH, TW, CG, CHUNK, false>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL((roi_pool_bwd_kernel<TH, TW, CG, CHUNK, false, MAXB, MINB>), dim3((unsigned)blocks),
                            dim3(CG), 0, st, top_diff, argmax, rois, R, N, H, W, C, PH, PW, scale,
                            bottom_diff, tiles_h, tiles_w, cgroups, cshift, dw);
     return check_launch();
@@ -648,19 +655,23 @@ extern "C" int wssdl_roi_pool_backward(const float *top_diff, const int32_t *arg
     if (!bottom_diff || (R > 0 && (!top_diff || !argmax || !rois)))
         return WSSDL_ERR_INVALID_ARGUMENT;
     hipStream_t st = as_stream(stream);
-    // 4x8-cell tiles: 32 KiB of LDS per 256-channel workgroup -> 16 waves per CU (8x8 tiles
-    // re-read 14 % less but halve the occupancy: 2.9 ms vs 2.1 ms at R = 16000, C = 1024).
+    // Tile size: the kernel is bound by the serial latency of a wave's walk (load batch -> wait ->
+    // dependent LDS read-modify-writes), hidden only by waves per CU, not by HBM bandwidth:
+    // 4x4-cell tiles (16 KiB of LDS per 256-channel workgroup, 63 VGPRs -> 28 waves per CU)
+    // re-read MORE bytes than 4x8 tiles (32 KiB, 16 waves per CU) and are 5-9 % faster; 8x8
+    // tiles (8 waves per CU) re-read 18 % less and are 50-70 % slower whatever the depth of
+    // their load batches.
     // Channels per workgroup: 256 when that still yields enough workgroups to fill the chip,
     // fewer otherwise (small batches / narrow feature maps).
     int cg = C > 128 ? 256 : (C > 64 ? 128 : 64);
-    const long long tiles = (long long)cdiv(H, 4) * cdiv(W, 8);
+    const long long tiles = (long long)cdiv(H, 4) * cdiv(W, 8);       // counted in 4x8 tiles
     while (cg > 64 && (long long)N * cdiv(C, cg) * tiles < BWD_MIN_WORKGROUPS) cg >>= 1;
     if (const char *e = getenv("WSSDL_ROI_BWD_CG")) {       // tuning override
         const int v = atoi(e);
         if (v == 64 || v == 128 || v == 256) cg = v;
     }
     if (cg == 256)
-        return launch_bwd<4, 8, 256, 256>(top_diff, argmax, rois, R, N, H, W, C, pooled_h, pooled_w,
+        return launch_bwd<4, 4, 256, 256>(top_diff, argmax, rois, R, N, H, W, C, pooled_h, pooled_w,
                                           spatial_scale, bottom_diff, st);
     if (cg == 128)
         return launch_bwd<4, 8, 128, 256>(top_diff, argmax, rois, R, N, H, W, C, pooled_h, pooled_w,
