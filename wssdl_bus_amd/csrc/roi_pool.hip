@@ -229,19 +229,20 @@ __device__ __forceinline__ void cand_range(int d, float bin, int P, int &s, int 
     e = min(max(e, 0), P);
 }
 
-// One (RoI, tile) intersection, produced by the filter phase (24 B in LDS).
-//   geo     = ph0 | pw0 << 8 | phn << 16 | pwn << 24: the candidate bins of the tile's cells are
-//             [ph0, ph0+phn) x [pw0, pw0+pwn)  (phstart/phend are monotone in h, so the union
-//             over the tile's rows is one interval; same for columns)
-//   rowmask : bit 8*k + j  <=>  tile row h0+j lies in the RoI (in_roi) and bin row ph0+k is one of
-//             its candidate rows; colmask likewise for columns.  phn or pwn > 8 (possible only
-//             for pooled sizes > 8): GENERIC, the masks are unused.
+// One (RoI, tile) intersection, produced by the filter phase (16 B in LDS).
+//   geo     = ph0 | pw0 << 8 | phn << 16 | pwn << 20 | (r - chunk base) << 24: the candidate bins of
+//             the tile's cells are [ph0, ph0+phn) x [pw0, pw0+pwn)  (phstart/phend are monotone in
+//             h, so the union over the tile's rows is one interval; same for columns)
+//   rowmask : bit 4*k + j  <=>  tile row h0+j lies in the RoI (in_roi) and bin row ph0+k is one of
+//             its candidate rows (tiles are at most 4 rows high); colmask: bit 8*k + j likewise
+//             for columns.  phn or pwn > 8 (possible only for pooled sizes > 8): GENERIC
+//             (phn = pwn = 15), the masks are unused.
 struct TouchRec {
-    int r;
     unsigned geo;
-    unsigned long long rowmask, colmask;
+    unsigned rowmask;
+    unsigned long long colmask;
 };
-constexpr unsigned TOUCH_GENERIC = 0xffu;
+constexpr unsigned TOUCH_GENERIC = 0xfu;
 constexpr long long BWD_MIN_WORKGROUPS = 1024;   // one per workgroup slot of the chip (256 CUs x 4)
 
 template <int TN, int FW = 8>
@@ -361,8 +362,9 @@ __global__ __launch_bounds__(CG, MINB) void roi_pool_bwd_kernel(
     const float *__restrict__ rois, int R, int N, int H, int W, int C, int PH, int PW, float scale,
     float *__restrict__ bottom_diff, int tiles_h, int tiles_w, int cgroups, int cshift,
     FastDiv divw) {
-    static_assert(TH <= 8 && TW <= 8, "one mask byte per candidate bin row / column");
-    static_assert(CHUNK % CG == 0 || CG % CHUNK == 0, "whole filter rounds");
+    static_assert(TH <= 4 && TW <= 8, "4 mask bits per candidate bin row, 8 per column");
+    static_assert(CHUNK <= 256, "8-bit RoI index inside a filter round");
+    static_assert(CHUNK % CG == 0 || CHUNK < CG, "whole filter rounds");
     constexpr int KPT = CHUNK >= CG ? CHUNK / CG : 1;   // RoIs tested per thread per filter round
     constexpr int NW = CG / WSSDL_WAVE;
     __shared__ float acc[TH * TW * CG];
@@ -443,14 +445,8 @@ __global__ __launch_bounds__(CG, MINB) void roi_pool_bwd_kernel(
                 const int wc = wave_cnt[k][w];
                 before += (w < wave) ? wc : 0;
             }
-            if (hit[k]) {
-                // stage the geometry in the record's fields; finished below
-                TouchRec &q = list[cnt + before + __popcll(m & ((1ull << lane) - 1ull))];
-                q.r = base + k * CG + tc;
-                q.geo = 0;
-                q.rowmask = ((unsigned long long)(unsigned)gk[k].sh << 32) | (unsigned)gk[k].eh;
-                q.colmask = ((unsigned long long)(unsigned)gk[k].sw << 32) | (unsigned)gk[k].ew;
-            }
+            if (hit[k])   // only the RoI's index for now; finished below
+                list[cnt + before + __popcll(m & ((1ull << lane) - 1ull))].geo = (unsigned)(k * CG + tc);
 #pragma unroll
             for (int w = 0; w < NW; ++w) cnt += wave_cnt[k][w];
         }
@@ -458,17 +454,18 @@ __global__ __launch_bounds__(CG, MINB) void roi_pool_bwd_kernel(
         // finish the records with the hits packed into the first threads (no divergence
         // between hit and non-hit lanes): candidate ranges of the tile's rows / columns
         for (int t = tc; t < cnt; t += CG) {
-            TouchRec q = list[t];
-            const int sh = (int)(unsigned)(q.rowmask >> 32), eh = (int)(unsigned)q.rowmask;
-            const int sw = (int)(unsigned)(q.colmask >> 32), ew = (int)(unsigned)q.colmask;
-            const float bin_h = (float)max(eh - sh + 1, 1) / (float)PH;     // as roi_geometry
-            const float bin_w = (float)max(ew - sw + 1, 1) / (float)PW;
+            TouchRec q;
+            const unsigned rel = list[t].geo;
+            const RoiGeom g = roi_geometry(rois + (size_t)(base + (int)rel) * 5, scale, PH, PW);
             int ph0, phn, pw0, pwn;
-            touch_axis<TH>(h0, h1, sh, eh, bin_h, PH, ph0, phn, q.rowmask);
-            touch_axis<TW>(w0, w1, sw, ew, bin_w, PW, pw0, pwn, q.colmask);
+            unsigned long long rm;
+            touch_axis<TH, 4>(h0, h1, g.sh, g.eh, g.bin_h, PH, ph0, phn, rm);
+            touch_axis<TW, 8>(w0, w1, g.sw, g.ew, g.bin_w, PW, pw0, pwn, q.colmask);
             if (phn <= 0 || pwn <= 0) phn = pwn = 0;                          // nothing to visit
             else if (phn > 8 || pwn > 8) phn = pwn = (int)TOUCH_GENERIC;
-            q.geo = (unsigned)ph0 | ((unsigned)pw0 << 8) | ((unsigned)phn << 16) | ((unsigned)pwn << 24);
+            q.rowmask = (unsigned)rm;
+            q.geo = (unsigned)ph0 | ((unsigned)pw0 << 8) | ((unsigned)phn << 16) | ((unsigned)pwn << 20) |
+                    (rel << 24);
             list[t] = q;
         }
         __syncthreads();
@@ -478,15 +475,14 @@ __global__ __launch_bounds__(CG, MINB) void roi_pool_bwd_kernel(
         // wave-uniform (scalar registers); bins are visited BB at a time: 2*BB loads from a
         // scalar base + lane offset are issued back to back, then accumulated in order.
         for (int i = 0; i < cnt; ++i) {
-            const int r = __builtin_amdgcn_readfirstlane(list[i].r);
             const unsigned geo = (unsigned)__builtin_amdgcn_readfirstlane((int)list[i].geo);
+            const int r = base + (int)(geo >> 24);
             const int ph0 = geo & 0xff, pw0 = (geo >> 8) & 0xff;
-            const int phn = (geo >> 16) & 0xff, pwn = geo >> 24;
+            const int phn = (geo >> 16) & 0xf, pwn = (geo >> 20) & 0xf;
             const size_t rbin0 = (size_t)r * PH * PW;
             if (phn == 0) continue;
             if (phn != (int)TOUCH_GENERIC) {
                 const unsigned long long rowmask =
-                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(list[i].rowmask >> 32)) << 32) |
                     (unsigned)__builtin_amdgcn_readfirstlane((int)list[i].rowmask);
                 const unsigned long long colmask =
                     ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(list[i].colmask >> 32)) << 32) |
@@ -497,7 +493,7 @@ __global__ __launch_bounds__(CG, MINB) void roi_pool_bwd_kernel(
                     const_cast<float *>(top_diff + rbin0 * C), 0, roi_bytes, 0x00020000);
                 const int bin_bytes = C * 4, row_bytes = PW * C * 4;
                 const int so_row = (ph0 * PW + pw0) * bin_bytes;     // scalar byte offset of the first bin
-#define WSSDL_VISIT(K) visit_roi<K, TW, CG, FAST, MAXB>(wx, ra, rt, so_row, bin_bytes, row_bytes, rowmask, phn, colmask)
+#define WSSDL_VISIT(K) visit_roi<K, TW, CG, FAST, MAXB, 4>(wx, ra, rt, so_row, bin_bytes, row_bytes, rowmask, phn, colmask)
                 switch (pwn) {                                       // wave-uniform
                     case 1: WSSDL_VISIT(1); break;
                     case 2: WSSDL_VISIT(2); break;
@@ -671,8 +667,8 @@ extern "C" int wssdl_roi_pool_backward(const float *top_diff, const int32_t *arg
         if (v == 64 || v == 128 || v == 256) cg = v;
     }
     if (cg == 256)
-        return launch_bwd<4, 4, 256, 256>(top_diff, argmax, rois, R, N, H, W, C, pooled_h, pooled_w,
-                                          spatial_scale, bottom_diff, st);
+        return launch_bwd<4, 4, 256, 254, 8, 8>(top_diff, argmax, rois, R, N, H, W, C, pooled_h, pooled_w,
+                                                spatial_scale, bottom_diff, st);
     if (cg == 128)
         return launch_bwd<4, 8, 128, 256>(top_diff, argmax, rois, R, N, H, W, C, pooled_h, pooled_w,
                                           spatial_scale, bottom_diff, st);
