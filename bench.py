@@ -183,6 +183,7 @@ def main():
     cfg.SAMPLING_RNG = args.sampling_rng
     cfg.FUSED_RPN_SOFTMAX = bool(args.fused_rpn_softmax)
     seed = ctx.seed(cfg.RNG_SEED)
+    cfg.DEVICE_RNG_SEED = seed              # the device samplers draw a different stream on every rank
     np.random.seed(seed)
     torch.manual_seed(seed)
 

@@ -58,9 +58,18 @@ def _worker(rank, world, port, q):
     out["overlap"] = [p.grad.clone() for p in p2]
     for p in p2:
         p.grad = None
+    # Adam with existing moments on every parameter (one earlier step with all gradients)
+    opt = torch.optim.Adam(p2, lr=0.1, eps=0.1)
+    for p in p2:
+        p.grad = torch.ones_like(p)
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    before = [p.detach().clone() for p in p2]
     (net2[3](torch.full((2, 8), float(rank + 1))).sum()).backward()      # only the last layer
     ov.finish()
-    out["overlap2"] = [p.grad.clone() for p in p2]
+    out["overlap2"] = [None if p.grad is None else p.grad.clone() for p in p2]
+    opt.step()
+    out["adam_moved"] = [bool((p.detach() != b).any()) for p, b in zip(p2, before)]
     ov.remove()
     out["tmax"] = ctx.max_over_ranks(1.0 + rank)
     out["tsum"] = ctx.sum_over_ranks(1.0 + rank)
@@ -101,9 +110,12 @@ def test_data_parallel_gloo_world2():
     for k in range(len(res[0]["reduced"])):
         for r in range(world):
             assert torch.allclose(res[r]["overlap"][k], res[r]["reduced"][k], rtol=1e-6, atol=1e-7)
-    # second step: first three parameter tensors get zeros, the last layer the mean over ranks
+    # second step: the parameters without a gradient on ANY rank end with grad None again (so
+    # Adam, which holds moments for them, leaves them alone -- the single-GPU / reference
+    # behaviour), the last layer gets the mean over ranks
     for r in range(world):
-        assert all(float(g.abs().sum()) == 0.0 for g in res[r]["overlap2"][:4])
+        assert all(g is None for g in res[r]["overlap2"][:4])
+        assert res[r]["adam_moved"] == [False] * 4 + [True, True]
         assert torch.allclose(res[r]["overlap2"][4], torch.full((3, 8), 2 * 1.5))      # mean of 2*1 and 2*2
         assert torch.allclose(res[r]["overlap2"][5], torch.full((3,), 2.0))
     assert res[0]["tmax"] == res[1]["tmax"] == 2.0

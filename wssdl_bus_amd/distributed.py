@@ -51,34 +51,61 @@ class DistContext(object):
     def allreduce_gradients(self, params):
         """In-place mean of .grad across ranks, bucketed.  Parameters whose grad is None on
         this rank (e.g. RPN weights in a MIL-only step) contribute zeros, so every rank issues
-        the same collectives."""
+        the same collectives; a parameter that had no gradient on ANY rank gets its grad set
+        back to None afterwards, so the optimiser skips it exactly as on one GPU (and as the
+        reference's apply_gradients skips a None gradient, train_bus.py:297-301)."""
         if not self.enabled:
             return
         bucket, size = [], 0
         handles = []
         for p in params:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
             bucket.append(p)
-            size += p.grad.numel() * p.grad.element_size()
+            size += p.numel() * p.element_size()
             if size >= self.bucket_bytes:
                 handles.append(self._launch(bucket))
                 bucket, size = [], 0
         if bucket:
             handles.append(self._launch(bucket))
-        for flat, work, ps in handles:
-            work.wait()
-            flat.div_(self.world_size)
-            off = 0
-            for p in ps:
-                n = p.grad.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                off += n
+        for h in handles:
+            self._write_back(*h)
+
+    _flag_cache = {}
+
+    def _flags(self, had, like):
+        """[len(had)] tensor of 1.0 / 0.0 on like's device (cached per pattern: no H2D per step)."""
+        key = (tuple(had), str(like.device), like.dtype)
+        t = DistContext._flag_cache.get(key)
+        if t is None:
+            t = torch.tensor([1.0 if h else 0.0 for h in had], dtype=like.dtype, device=like.device)
+            DistContext._flag_cache[key] = t
+        return t
 
     def _launch(self, ps):
-        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        """One flat bucket = the gradients followed by one has-grad flag per parameter."""
+        had = [p.grad is not None for p in ps]
+        parts = [p.grad.reshape(-1) if h else torch.zeros(p.numel(), dtype=p.dtype, device=p.device)
+                 for p, h in zip(ps, had)]
+        parts.append(self._flags(had, ps[0]))
+        flat = torch.cat(parts)
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
         return flat, work, list(ps)
+
+    def _write_back(self, flat, work, ps):
+        work.wait()
+        any_grad = flat[flat.numel() - len(ps):].cpu().tolist()    # tiny; after the wait anyway
+        flat.div_(self.world_size)
+        off = 0
+        for p, a in zip(ps, any_grad):
+            n = p.numel()
+            if a > 0:
+                g = flat[off:off + n].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+            else:
+                p.grad = None
+            off += n
 
     def overlap(self, params):
         """Bucketed all-reduce overlapped with backward: see GradOverlap."""
@@ -119,7 +146,9 @@ class GradOverlap(object):
     RCCL's stream while backward keeps running.  ``finish()`` (called before the optimiser step)
     launches whatever is left -- buckets holding parameters that received no gradient in this
     backward, e.g. the RPN weights in a MIL-only step, are completed with zeros so that every
-    rank issues the same collectives in the same order -- waits, and writes the means back."""
+    rank issues the same collectives in the same order -- waits, and writes the means back.
+    Every bucket carries one has-grad flag per parameter: a parameter without a gradient on
+    every rank ends with ``grad = None`` again, so Adam skips it as it does on one GPU."""
 
     def __init__(self, ctx, params):
         self.ctx = ctx
@@ -157,12 +186,7 @@ class GradOverlap(object):
             self.next_to_launch += 1
 
     def _launch(self, b):
-        ps = self.buckets[b]
-        for p in ps:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-        flat = torch.cat([p.grad.reshape(-1) for p in ps])
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        flat, work, _ = self.ctx._launch(self.buckets[b])
         self.launched[b] = (flat, work)
 
     def finish(self):
@@ -173,13 +197,7 @@ class GradOverlap(object):
             self._launch(b)
         for b, ps in enumerate(self.buckets):
             flat, work = self.launched[b]
-            work.wait()
-            flat.div_(self.ctx.world_size)
-            off = 0
-            for p in ps:
-                n = p.grad.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                off += n
+            self.ctx._write_back(flat, work, ps)
         self._reset()
 
     def remove(self):

@@ -58,15 +58,18 @@ def mil_loss(cls_score_ws, batch_inds, mil_label, n_bags, global_step, funcs, co
     [0, WS_MAL_PCT, 1-WS_MAL_PCT] and by 1 - 0.99*0.9^floor(step/2000) (or a constant).
     On the GPU the bag selection is the HIP op (no host round trip); on CPU tensors (tests) the
     host-side restatement of mil/core.py runs."""
+    valid = None
     if cls_score_ws.is_cuda:
-        bag_logits, _ = mil_core.get_bag_logit_device(cls_score_ws, batch_inds, 0.0, mil_label,
-                                                      n_bags, funcs)
+        bag_logits, _, valid = mil_core.get_bag_logit_device(cls_score_ws, batch_inds, 0.0, mil_label,
+                                                             n_bags, funcs, return_valid=True)
     else:
         bag_logits, _ = mil_core.get_bag_logit(cls_score_ws, batch_inds, 3, mil_label, n_bags,
                                                funcs, counts_host)
     label = mil_label.reshape(-1).to(torch.int64)
     w = torch.tensor([0.0, cfg.TRAIN.WS_MAL_PCT, 1 - cfg.TRAIN.WS_MAL_PCT],
                      dtype=bag_logits.dtype, device=bag_logits.device)[label]
+    if valid is not None:                          # an empty bag (no proposals) carries no loss
+        w = w * valid.to(w.dtype)
     ce = F.cross_entropy(bag_logits, label, reduction='none')
     if cfg.TRAIN.WS_LOSS_USE_ADAPTIVE_SCALE_FACTOR:
         scale = 1.0 - 0.99 * (0.9 ** (int(global_step) // 2000))      # exponential_decay, staircase
@@ -106,20 +109,28 @@ class SolverWrapper(object):
         self.net = network
         self.lr = cfg.TRAIN.get('LEARNING_RATE', 0.0005) if lr is None else lr
         self.params = [p for p in network.parameters() if p.requires_grad]
+        # combined mode: ONE Adam applies the summed gradients and counts the global step
+        # (:694-705).  Alternating mode: the supervised op is Adam.minimize(loss) WITHOUT a
+        # global step, the weak op a SECOND Adam whose apply_gradients counts it (:286-301);
+        # the two keep their own moments and bias-correction powers.
         self.optimizer = torch.optim.Adam(self.params, lr=self.lr, eps=0.1)
+        self.optimizer_ws = None                  # created by the first alternating iteration
         self.global_step = 0
         self.dist = dist_ctx
+        if dist_ctx is not None:                 # seed per rank = RNG_SEED + rank,
+            cfg.DEVICE_RNG_SEED = dist_ctx.seed(cfg.RNG_SEED)   # for the device samplers too
         # data parallel: bucketed gradient all-reduce overlapped with backward
         self.overlap = dist_ctx.overlap(self.params) if (dist_ctx is not None and dist_ctx.enabled) else None
 
-    def _apply(self):
+    def _apply(self, optimizer=None, count_step=True):
         if self.overlap is not None:
             self.overlap.finish()
         elif self.dist is not None:
             self.dist.allreduce_gradients(self.params)
-        self.optimizer.step()
-        self.optimizer.zero_grad(set_to_none=True)
-        self.global_step += 1
+        (optimizer or self.optimizer).step()      # parameters whose grad is None are skipped,
+        self.optimizer.zero_grad(set_to_none=True)  # like apply_gradients with a None gradient
+        if count_step:
+            self.global_step += 1
 
     def train_step_joint(self, blobs):
         """One combined mini-batch (train_bus.py:732-764): supervised images first, weak images
@@ -148,7 +159,7 @@ class SolverWrapper(object):
                           blobs_s['num_gt_boxes'], is_training=True, is_ws=False)
         losses = supervised_loss(layers, self.net.weight_decay_params())
         losses['loss'].backward()
-        self._apply()
+        self._apply(self.optimizer, count_step=False)              # train_op_s: no global_step
         layers = self.net(blobs_ws['data'], blobs_ws['im_info'], blobs_ws['gt_boxes'],
                           blobs_ws['num_gt_boxes'], is_training=True, is_ws=True)
         batch_inds = layers['roi-data'][0][:, 0]                      # :239
@@ -157,5 +168,7 @@ class SolverWrapper(object):
         losses['mil_cross_entropy'] = mil_loss(layers['cls_score'], batch_inds, mil_label,
                                                blobs_ws['data'].shape[0], self.global_step, funcs)
         losses['mil_cross_entropy'].backward()
-        self._apply()
+        if self.optimizer_ws is None:
+            self.optimizer_ws = torch.optim.Adam(self.params, lr=self.lr, eps=0.1)
+        self._apply(self.optimizer_ws, count_step=True)            # train_op_ws counts the step
         return losses

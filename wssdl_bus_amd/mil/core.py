@@ -56,15 +56,24 @@ def get_bag_logit(instance_logits, batch_inds, num_classes, bag_labels, batch_si
 _SELECTORS = {get_mal_max_logit: 0, get_ben_max_logit: 1, get_mass_max_logit: 2}
 
 
-def get_bag_logit_device(instance_logits, bag_column, bag_offset, bag_labels, batch_size, funcs):
+def get_bag_logit_device(instance_logits, bag_column, bag_offset, bag_labels, batch_size, funcs,
+                         return_valid=False):
     """get_bag_logit as ONE kernel launch + one gather, with no host round trip: the HIP op
     ``wssdl_mil_select`` picks each bag's instance row, ``index_select`` (differentiable) gathers
     the logit rows.  `bag_column` is the column holding each instance's bag index plus
     `bag_offset` (a strided view such as ``rois[n_valid:, 0]`` is fine).  Returns
-    (bag_logits [batch_size, K], scale_factors [batch_size]) like get_bag_logit."""
+    (bag_logits [batch_size, K], scale_factors [batch_size]) like get_bag_logit.
+
+    A bag without instances (a weak image whose proposals were all filtered out) makes the
+    reference's tf.arg_max fail on the host.  Here the op reports row -1 for it; the gather then
+    uses row 0 and the bag's logits are zeroed, and with `return_valid` the [batch_size] bool
+    mask of the non-empty bags is returned as a third value so that the loss can give such a
+    bag zero weight -- all without a device->host copy.  No instances at all raises ValueError."""
     from .. import _lib
     logits = instance_logits.contiguous()
     R, K = logits.shape
+    if R == 0 and batch_size > 0:
+        raise ValueError("get_bag_logit: no instances for %d bag(s)" % batch_size)
     col = bag_column if bag_column.dtype == torch.float32 else bag_column.to(torch.float32)
     stride = col.stride(0) if col.dim() == 1 and R > 1 else 1
     if col.dim() != 1 or (R > 1 and stride < 1):
@@ -77,6 +86,10 @@ def get_bag_logit_device(instance_logits, bag_column, bag_offset, bag_labels, ba
             _lib.ptr(logits), R, K, _lib.ptr(col), int(stride), float(bag_offset), _lib.ptr(labels),
             int(batch_size), _SELECTORS[funcs[0]], _SELECTORS[funcs[1]], _lib.ptr(rows), None,
             _lib.stream()), "wssdl_mil_select")
-    bag_logits = instance_logits.index_select(0, rows.to(torch.int64))
+    valid = rows >= 0
+    bag_logits = instance_logits.index_select(0, rows.clamp_min(0).to(torch.int64))
+    bag_logits = bag_logits * valid.unsqueeze(1).to(bag_logits.dtype)
     scale = torch.softmax(bag_logits, dim=1).gather(1, labels.to(torch.int64).unsqueeze(1)).squeeze(1)
+    if return_valid:
+        return bag_logits, scale, valid
     return bag_logits, scale
