@@ -132,10 +132,11 @@ class SolverWrapper(object):
         if count_step:
             self.global_step += 1
 
-    def train_step_joint(self, blobs):
-        """One combined mini-batch (train_bus.py:732-764): supervised images first, weak images
-        after; the supervised and MIL gradients are summed per variable (:701-705), which is
-        the gradient of (loss + mil_cross_entropy)."""
+    def joint_backward(self, blobs):
+        """Forward + backward of one combined mini-batch (train_bus.py:732-764): supervised images
+        first, weak images after; the supervised and MIL gradients are summed per variable
+        (:701-705), which is the gradient of (loss + mil_cross_entropy).  Gradients are left in
+        .grad (and, under data parallelism, their all-reduce is in flight)."""
         n_s = int(cfg.TRAIN.IMS_PER_BATCH)
         n_ws = int(cfg.TRAIN.WS_IMS_PER_BATCH)
         layers = self.net(blobs['data'], blobs['im_info'], blobs['gt_boxes'], blobs['num_gt_boxes'],
@@ -149,25 +150,40 @@ class SolverWrapper(object):
         losses['mil_cross_entropy'] = mil_loss(cls_ws, batch_inds, mil_label, n_ws,
                                                self.global_step, funcs)
         (losses['loss'] + losses['mil_cross_entropy']).backward()
+        return losses
+
+    def train_step_joint(self, blobs):
+        """One combined optimiser step: joint_backward, then Adam on the (averaged) gradients."""
+        losses = self.joint_backward(blobs)
         self._apply()
         return losses
 
-    def train_step_alter(self, blobs_s, blobs_ws):
-        """One alternating iteration (train_bus.py:334-394): a supervised step on `loss`, then
-        a weak step on the MIL loss alone with is_ws=True."""
+    def supervised_backward(self, blobs_s):
+        """The supervised half of an alternating iteration (train_bus.py:334-360)."""
         layers = self.net(blobs_s['data'], blobs_s['im_info'], blobs_s['gt_boxes'],
                           blobs_s['num_gt_boxes'], is_training=True, is_ws=False)
         losses = supervised_loss(layers, self.net.weight_decay_params())
         losses['loss'].backward()
-        self._apply(self.optimizer, count_step=False)              # train_op_s: no global_step
+        return losses
+
+    def weak_backward(self, blobs_ws):
+        """The weak half (train_bus.py:362-394): the MIL loss alone, with is_ws=True."""
         layers = self.net(blobs_ws['data'], blobs_ws['im_info'], blobs_ws['gt_boxes'],
                           blobs_ws['num_gt_boxes'], is_training=True, is_ws=True)
         batch_inds = layers['roi-data'][0][:, 0]                      # :239
         mil_label = blobs_ws['im_info'][:, 3].to(torch.int32)         # :240
         funcs = [mil_core.get_mass_max_logit, mil_core.get_mal_max_logit]    # :241
-        losses['mil_cross_entropy'] = mil_loss(layers['cls_score'], batch_inds, mil_label,
-                                               blobs_ws['data'].shape[0], self.global_step, funcs)
-        losses['mil_cross_entropy'].backward()
+        mil = mil_loss(layers['cls_score'], batch_inds, mil_label, blobs_ws['data'].shape[0],
+                       self.global_step, funcs)
+        mil.backward()
+        return mil
+
+    def train_step_alter(self, blobs_s, blobs_ws):
+        """One alternating iteration (train_bus.py:334-394): a supervised step on `loss`, then
+        a weak step on the MIL loss alone with is_ws=True."""
+        losses = self.supervised_backward(blobs_s)
+        self._apply(self.optimizer, count_step=False)              # train_op_s: no global_step
+        losses['mil_cross_entropy'] = self.weak_backward(blobs_ws)
         if self.optimizer_ws is None:
             self.optimizer_ws = torch.optim.Adam(self.params, lr=self.lr, eps=0.1)
         self._apply(self.optimizer_ws, count_step=True)            # train_op_ws counts the step
