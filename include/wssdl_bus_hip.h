@@ -228,6 +228,34 @@ WSSDL_API int wssdl_roi_pool_backward(const float *top_diff, const int32_t *argm
                             int R, int N, int H, int W, int C, int pooled_h, int pooled_w,
                             float spatial_scale, float *bottom_diff, wssdl_stream_t stream);
 
+/* ------------------------------------------------- a11, a12: training path ---
+ * The same pair with a ONE-BYTE arg-max.  In the reference the arg-max tensor never leaves the
+ * op pair: networks/network.py:206-210 keeps only top_data and the registered gradient
+ * (roi_pooling_op_grad.py:24-44) hands argmax straight to RoiPoolGrad, so its encoding is an
+ * internal contract.  Both kernels are HBM-bound on top + argmax, and 4 + 1 bytes per element
+ * instead of 4 + 4 is a 37 % cut of that traffic (re-reads of the backward included).
+ *   code = (h - hstart) << 4 | (w - wstart)   within the bin's clipped window
+ *          (roi_pooling_op_gpu.cu.cc:51-64 / roi_pooling_op.cc:167-176); 0xff = empty bin (-1).
+ * Supported (wssdl_roi_pool_compact_supported == 1) when C % 32 == 0 and every window of a RoI
+ * inside the map fits 15 x 16 cells: ceil((H+1)/pooled_h)+1 <= 15, ceil((W+1)/pooled_w)+1 <= 16
+ * (7x7 bins: maps up to 97 x 104 cells).  A RoI reaching far outside the map can exceed that:
+ * the forward then sets *overflow (optional device int32, OR-ed, never cleared) and that RoI's
+ * codes are invalid -- callers feeding unclipped RoIs use the i32 pair above.
+ * top / bottom_diff are bit-identical to the i32 pair; wssdl_roi_argmax_expand rebuilds the
+ * reference's i32 argmax from the codes. */
+WSSDL_API int wssdl_roi_pool_compact_supported(int H, int W, int C, int pooled_h, int pooled_w);
+WSSDL_API int wssdl_roi_pool_forward_compact(const float *bottom, int N, int H, int W, int C,
+                           const float *rois, int R, int pooled_h, int pooled_w, float spatial_scale,
+                           int rounding, float *top, uint8_t *argmax8, int32_t *overflow,
+                           wssdl_stream_t stream);
+WSSDL_API int wssdl_roi_pool_backward_compact(const float *top_diff, const uint8_t *argmax8,
+                            const float *rois, int R, int N, int H, int W, int C, int pooled_h,
+                            int pooled_w, float spatial_scale, int rounding, float *bottom_diff,
+                            wssdl_stream_t stream);
+WSSDL_API int wssdl_roi_argmax_expand(const uint8_t *argmax8, const float *rois, int R, int H, int W,
+                            int C, int pooled_h, int pooled_w, float spatial_scale, int rounding,
+                            int32_t *argmax, wssdl_stream_t stream);
+
 /* ---------------------------------------------------------------------- f1 ---
  * MIL bag-instance selection: mil/core.py:11-46 (get_bag_logit) with the selectors
  * get_mal_max_logit :60-69, get_ben_max_logit :49-57, get_mass_max_logit :88-96.

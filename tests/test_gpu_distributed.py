@@ -168,6 +168,10 @@ def _worker_two_ranks(rank, world, port, q):
         plain = SolverWrapper(net)
         exp_state, _ = expected_step(net, state0, plain.joint_backward, blobs, [50, 51], plain.lr)
         expect = _flat(torch, [exp_state[k] for k, _ in net.named_parameters()]).clone()
+        # the same expectation once more: what the non-deterministic convolution gradients alone
+        # move (the yardstick for the comparison below)
+        exp_again, _ = expected_step(net, state0, plain.joint_backward, blobs, [50, 51], plain.lr)
+        out["joint_noise"] = float((expect - _flat(torch, [exp_again[k] for k, _ in net.named_parameters()])).abs().max())
         _load(net, state0)
         solver = SolverWrapper(net, dist_ctx=ctx)
         np.random.seed(50 + rank)
@@ -194,6 +198,9 @@ def _worker_two_ranks(rank, world, port, q):
         # parameters without a weak gradient must come out of the weak step untouched
         out["weak_nograd_static"] = all(bool(torch.equal(s1[n], s2[n])) for n, h in zip(names, had) if not h)
         expect2 = _flat(torch, [s2[k] for k in names]).clone()
+        s1b, _ = expected_step(net2, s0, plain2.supervised_backward, blobs_s, [60, 61], plain2.lr)
+        s2b, _ = expected_step(net2, s1b, plain2.weak_backward, blobs_w, [70, 71], plain2.lr)
+        out["alter_noise"] = float((expect2 - _flat(torch, [s2b[k] for k in names])).abs().max())
         _load(net2, s0)
         solver2 = SolverWrapper(net2, dist_ctx=ctx)
         orig_apply = solver2._apply
@@ -242,8 +249,12 @@ def test_two_ranks_on_one_gpu_real_steps_match_mean_gradient_update():
         o = res[r]
         assert o["joint_identical"] and o["alter_identical"], o
         assert o["joint_moved"] > 1e-5
-        # Adam(eps=0.1, lr=5e-4) on the mean gradient; f32 all-reduce + non-deterministic conv
-        # weight gradients leave ~1e-8 differences
-        assert o["joint_err"] <= 2e-6 and o["alter_err"] <= 2e-6, o
+        # Adam(eps=0.1, lr=5e-4) on the mean gradient: the data-parallel result may differ from
+        # the serial expectation by no more than a few times what a REPEAT of the serial
+        # computation differs from itself (MIOpen's weight gradients are not deterministic),
+        # and in any case by less than 2 % of the largest possible Adam step (lr)
+        assert o["joint_err"] <= 4 * o["joint_noise"] + 1e-7, o
+        assert o["alter_err"] <= 4 * o["alter_noise"] + 1e-7, o
+        assert o["joint_err"] <= 1e-5 and o["alter_err"] <= 1e-5, o
         assert o["alter_step"] == 1 and o["alter_calls"] == [False, True]
         assert o["weak_nograd_params"] > 0 and o["weak_nograd_static"]

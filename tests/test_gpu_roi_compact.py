@@ -1,0 +1,180 @@
+"""-m gpu: the training-path RoI pool pair with a 1-byte arg-max (wssdl_roi_pool_forward_compact /
+_backward_compact) against the C oracle: top bit-equal, the codes expanded to the reference's i32
+argmax bit-equal, bottom_diff bit-equal (same f32 summation order), for both bin roundings, at
+every config's feature-map shape and for every tile variant the backward can be built with."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from test_gpu_parity import _random_rois
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    from wssdl_bus_amd import _lib
+    _lib.lib()
+    return torch
+
+
+def _rois_for(rs, R, N, H, W):
+    im_h, im_w = 16 * H - 8, 16 * W - 8
+    rois = _random_rois(rs, R, N, im_h, im_w)
+    k = min(10, R // 4)
+    rois[:k, 3:] = rois[:k, 1:3] + rs.uniform(0, 60, (k, 2))               # smaller than 7x7 cells
+    rois[k] = [0, 0, 0, im_w - 1, im_h - 1]                                 # the whole image
+    rois[k + 1] = [N - 1, im_w - 17, im_h - 17, im_w - 1, im_h - 1]         # bottom-right corner
+    rois[k + 2] = [0, 8, 8, 24, 24]                                         # .5 cell coordinates
+    rois[k + 3] = [N - 1, 200, 100, 100, 50]                                # malformed (end < start)
+    return np.ascontiguousarray(rois[rs.permutation(R)])                    # NOT grouped by image
+
+
+@pytest.mark.parametrize("shape", [(2, 38, 63, 256), (3, 38, 63, 1024), (1, 63, 100, 1024), (1, 37, 62, 512),
+                                   (2, 38, 63, 96), (5, 20, 30, 64)])
+@pytest.mark.parametrize("mode", ["cuda", "cpu"])
+def test_compact_pair_vs_oracle(torch_cuda, shape, mode):
+    torch = torch_cuda
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    N, H, W, C = shape
+    assert op.compact_supported(H, W, C, 7, 7)
+    rs = np.random.RandomState(H * 1000 + C)
+    f = np.maximum(rs.normal(size=shape), 0).astype(np.float32)             # ReLU plateaus: ties at 0
+    R = 300 if C >= 512 else 500
+    rois = _rois_for(rs, R, N, H, W)
+    et, ea = c_oracle.roi_pool_forward(f, rois, 7, 7, 1.0 / 16, mode, threads=16)
+    ft, rt = torch.from_numpy(f).cuda(), torch.from_numpy(rois).cuda()
+    top, arg8 = op.roi_pool_compact(ft, rt, 7, 7, 1.0 / 16, rounding=mode)
+    assert arg8.dtype == torch.uint8 and tuple(arg8.shape) == (R, 7, 7, C)
+    assert np.array_equal(top.cpu().numpy(), et)
+    arg = op.expand_argmax(arg8, rt, shape, 7, 7, 1.0 / 16, rounding=mode)
+    assert np.array_equal(arg.cpu().numpy(), ea)
+    # the i32 pair of the reference contract gives the same tensors
+    top_i, arg_i = op.roi_pool(ft, rt, 7, 7, 1.0 / 16, rounding=mode)
+    assert torch.equal(top_i, top) and torch.equal(arg_i, arg)
+    diff = rs.normal(size=et.shape).astype(np.float32)
+    want = c_oracle.roi_pool_backward(diff, ea, rois, f.shape, 7, 7, 1.0 / 16)
+    dt = torch.from_numpy(diff).cuda()
+    old = os.environ.get("WSSDL_ROI_BWDC_VARIANT")
+    try:
+        for variant in ("0", "1", "2", "3", "4"):
+            os.environ["WSSDL_ROI_BWDC_VARIANT"] = variant
+            got = op.roi_pool_grad_compact(shape, rt, arg8, dt, 7, 7, 1.0 / 16, rounding=mode)
+            assert np.array_equal(got.cpu().numpy(), want), (shape, mode, variant)
+    finally:
+        if old is None:
+            os.environ.pop("WSSDL_ROI_BWDC_VARIANT", None)
+        else:
+            os.environ["WSSDL_ROI_BWDC_VARIANT"] = old
+
+
+def test_compact_other_pooled_sizes_and_unsupported_shapes(torch_cuda):
+    torch = torch_cuda
+    from wssdl_bus_amd import _lib
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    L = _lib.lib()
+    assert L.wssdl_roi_pool_compact_supported(38, 63, 1024, 7, 7) == 1
+    assert L.wssdl_roi_pool_compact_supported(97, 104, 64, 7, 7) == 1
+    assert L.wssdl_roi_pool_compact_supported(98, 100, 64, 7, 7) == 0       # windows could exceed 15 rows
+    assert L.wssdl_roi_pool_compact_supported(38, 105, 64, 7, 7) == 0       # ... or 16 columns
+    assert L.wssdl_roi_pool_compact_supported(38, 63, 70, 7, 7) == 0        # C % 32 != 0
+    assert L.wssdl_roi_pool_compact_supported(38, 63, 64, 1, 1) == 0        # one bin = the whole RoI
+    rs = np.random.RandomState(2)
+    shape = (1, 20, 24, 32)
+    f = np.maximum(rs.normal(size=shape), 0).astype(np.float32)
+    x1, y1 = rs.uniform(0, 300, 40), rs.uniform(0, 250, 40)
+    rois = np.stack([np.zeros(40), x1, y1, x1 + rs.uniform(8, 80, 40), y1 + rs.uniform(8, 70, 40)], 1).astype(np.float32)
+    ft, rt = torch.from_numpy(f).cuda(), torch.from_numpy(rois).cuda()
+    for ph, pw, scale in ((6, 6, 1.0 / 3), (14, 14, 1.0 / 16), (3, 11, 1.0 / 8), (2, 2, 1.0 / 16)):
+        if not op.compact_supported(20, 24, 32, ph, pw):
+            continue
+        et, ea = c_oracle.roi_pool_forward(f, rois, ph, pw, scale, "cuda")
+        top, arg8 = op.roi_pool_compact(ft, rt, ph, pw, scale, rounding="cuda")
+        assert np.array_equal(top.cpu().numpy(), et)
+        assert np.array_equal(op.expand_argmax(arg8, rt, shape, ph, pw, scale, rounding="cuda").cpu().numpy(), ea)
+        d = rs.normal(size=et.shape).astype(np.float32)
+        want = c_oracle.roi_pool_backward(d, ea, rois, shape, ph, pw, scale)
+        got = op.roi_pool_grad_compact(shape, rt, arg8, torch.from_numpy(d).cuda(), ph, pw, scale, rounding="cuda")
+        assert np.array_equal(got.cpu().numpy(), want), (ph, pw)
+    # empty RoI list, and an all-empty gradient
+    top, arg8 = op.roi_pool_compact(ft, rt[:0], 7, 7, 1.0 / 16)
+    assert top.shape == (0, 7, 7, 32) and arg8.shape == (0, 7, 7, 32)
+    g = op.roi_pool_grad_compact(shape, rt[:0], arg8, top, 7, 7, 1.0 / 16)
+    assert tuple(g.shape) == shape and not bool(g.any())
+
+
+def test_compact_overflow_flag_for_rois_far_outside_the_map(torch_cuda):
+    torch = torch_cuda
+    from wssdl_bus_amd import _lib
+    f = torch.relu(torch.randn((1, 38, 63, 64), device="cuda"))
+    top = torch.empty((2, 7, 7, 64), device="cuda")
+    arg8 = torch.empty((2, 7, 7, 64), dtype=torch.uint8, device="cuda")
+    flag = torch.zeros((1,), dtype=torch.int32, device="cuda")
+
+    def run(rois):
+        r = torch.tensor(rois, dtype=torch.float32, device="cuda")
+        _lib.check(_lib.lib().wssdl_roi_pool_forward_compact(_lib.ptr(f), 1, 38, 63, 64, _lib.ptr(r), 2, 7, 7,
+                                                             1.0 / 16, 0, _lib.ptr(top), _lib.ptr(arg8),
+                                                             _lib.ptr(flag), _lib.stream()), "fwd compact")
+        return int(flag.item())
+    assert run([[0, 0, 0, 1007, 607], [0, -40, -40, 1100, 700]]) == 0       # inside / slightly outside: fine
+    assert run([[0, 0, 0, 1007, 607], [0, -9000, -9000, 9000, 9000]]) == 1  # one bin spans the whole map
+
+
+def test_autograd_uses_compact_path_and_matches_oracle(torch_cuda):
+    torch = torch_cuda
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    rs = np.random.RandomState(8)
+    f_np = np.maximum(rs.normal(size=(2, 38, 63, 64)), 0).astype(np.float32)
+    rois_np = _rois_for(rs, 60, 2, 38, 63)
+    want_t, want_a = c_oracle.roi_pool_forward(f_np, rois_np, 7, 7, 1.0 / 16, "cuda")
+    w_np = rs.normal(size=want_t.shape).astype(np.float32)
+    want_g = c_oracle.roi_pool_backward(w_np, want_a, rois_np, f_np.shape, 7, 7, 1.0 / 16)
+    for compact in (True, False):
+        cfg.ROI_POOL_COMPACT_ARGMAX = compact
+        try:
+            f = torch.from_numpy(f_np).cuda().requires_grad_(True)
+            top, saved = op.RoiPoolFunction.apply(f, torch.from_numpy(rois_np).cuda(), 7, 7, 1.0 / 16, None)
+            assert saved.dtype == (torch.uint8 if compact else torch.int32)
+            top2, arg = op.roi_pool_autograd(f, torch.from_numpy(rois_np).cuda(), 7, 7, 1.0 / 16)
+            assert arg.dtype == torch.int32 and np.array_equal(arg.cpu().numpy(), want_a)
+            assert np.array_equal(top2.detach().cpu().numpy(), want_t)
+            (top2 * torch.from_numpy(w_np).cuda()).sum().backward()
+            assert np.array_equal(f.grad.cpu().numpy(), want_g)
+        finally:
+            cfg.ROI_POOL_COMPACT_ARGMAX = True
+    assert not op.compact_overflowed()
+
+
+def test_compact_full_size_properties(torch_cuda):
+    """BASELINE config 3 size (R = 4*128 + 4*2000 = 8512, C = 1024, 8 images 38x63): the compact pair
+    equals the i32 pair bit for bit (which test_gpu_parity.py checks against the oracle by
+    sampling), plus a sampled oracle comparison of its own."""
+    torch = torch_cuda
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    rs = np.random.RandomState(3)
+    N, H, W, C, R = 8, 38, 63, 1024, 8512
+    f = torch.relu(torch.randn((N, H, W, C), device="cuda", generator=torch.Generator("cuda").manual_seed(3)))
+    rois_np = _random_rois(rs, R, N, 600, 1000)
+    rois_np = rois_np[np.argsort(rois_np[:, 0], kind="stable")]
+    rois = torch.from_numpy(rois_np).cuda()
+    top_i, arg_i = op.roi_pool(f, rois, 7, 7, 1.0 / 16)
+    top, arg8 = op.roi_pool_compact(f, rois, 7, 7, 1.0 / 16)
+    assert torch.equal(top, top_i)
+    assert torch.equal(op.expand_argmax(arg8, rois, (N, H, W, C), 7, 7, 1.0 / 16), arg_i)
+    d = torch.randn(top.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(4))
+    g_i = op.roi_pool_grad(f, rois, arg_i, d, 7, 7, 1.0 / 16)
+    g = op.roi_pool_grad_compact((N, H, W, C), rois, arg8, d, 7, 7, 1.0 / 16)
+    assert torch.equal(g, g_i)
+    assert torch.equal(op.roi_pool_grad_compact((N, H, W, C), rois, arg8, d, 7, 7, 1.0 / 16), g)   # deterministic
+    img0 = np.where(rois_np[:, 0] == 0)[0][:200]
+    et, ea = c_oracle.roi_pool_forward(f[:1].cpu().numpy(), rois_np[img0], 7, 7, 1.0 / 16, "cuda", threads=16)
+    want = c_oracle.roi_pool_backward(d[img0].cpu().numpy(), ea, rois_np[img0], (1, H, W, C), 7, 7, 1.0 / 16)
+    got = op.roi_pool_grad_compact((1, H, W, C), rois[img0], arg8[img0].contiguous(), d[img0].contiguous(), 7, 7, 1.0 / 16)
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert not op.compact_overflowed()

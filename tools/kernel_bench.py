@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from wssdl_bus_amd.fast_rcnn.config import cfg  # noqa: E402
-from wssdl_bus_amd.roi_pooling_layer.roi_pooling_op import roi_pool, roi_pool_grad  # noqa: E402
+from wssdl_bus_amd.roi_pooling_layer.roi_pooling_op import (roi_pool, roi_pool_grad, roi_pool_compact,  # noqa: E402
+                                                            roi_pool_grad_compact, compact_supported)
 from wssdl_bus_amd.rpn_msr.anchor_target_layer_tf_bus import anchor_target_layer  # noqa: E402
 from wssdl_bus_amd.rpn_msr.proposal_layer_tf_bus import proposal_layer_padded, compact_rois  # noqa: E402
 from wssdl_bus_amd.nms.hip_nms import hip_nms  # noqa: E402
@@ -90,6 +91,25 @@ def main():
     ms = timeit(lambda: roi_pool_grad(feat, rois, arg, diff, 7, 7, 1.0 / 16), args.iters)
     byt = R * 49 * C * 8 + N * H * W * C * 4
     out.append(dict(op="roi_pool_backward", ms=ms, R=R, C=C, alg_bytes=byt, GBps=byt / ms / 1e6))
+
+    # training path: 1-byte arg-max (same algorithmic bytes: the metric counts the reference's layout)
+    if compact_supported(H, W, C, 7, 7):
+        top_c, arg8 = roi_pool_compact(feat, rois, 7, 7, 1.0 / 16)
+        assert torch.equal(top_c, top)
+        ms = timeit(lambda: roi_pool_compact(feat, rois, 7, 7, 1.0 / 16), args.iters)
+        byt = N * H * W * C * 4 + R * 20 + R * 49 * C * 8
+        out.append(dict(op="roi_pool_forward_compact", ms=ms, R=R, C=C, alg_bytes=byt, GBps=byt / ms / 1e6,
+                        moved_bytes=N * H * W * C * 4 + R * 20 + R * 49 * C * 5))
+        ref_g = roi_pool_grad(feat, rois, arg, diff, 7, 7, 1.0 / 16)
+        for variant in os.environ.get("KB_BWDC_VARIANTS", "0").split(","):
+            os.environ["WSSDL_ROI_BWDC_VARIANT"] = variant
+            g = roi_pool_grad_compact(tuple(feat.shape), rois, arg8, diff, 7, 7, 1.0 / 16)
+            assert os.environ.get("KB_NO_CHECK") or torch.equal(g, ref_g), variant
+            ms = timeit(lambda: roi_pool_grad_compact(tuple(feat.shape), rois, arg8, diff, 7, 7, 1.0 / 16), args.iters)
+            byt = R * 49 * C * 8 + N * H * W * C * 4
+            out.append(dict(op="roi_pool_backward_compact[v%s]" % variant, ms=ms, R=R, C=C, alg_bytes=byt,
+                            GBps=byt / ms / 1e6))
+        os.environ.pop("WSSDL_ROI_BWDC_VARIANT", None)
 
     # anchor targets
     gt = torch.zeros((N, 20, 5), device="cuda")

@@ -49,6 +49,10 @@ SYMBOLS = {
                                _vp]),
     "wssdl_roi_pool_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "wssdl_roi_pool_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "wssdl_roi_pool_compact_supported": (_i, [_i, _i, _i, _i, _i]),
+    "wssdl_roi_pool_forward_compact": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "wssdl_roi_pool_backward_compact": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "wssdl_roi_argmax_expand": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "wssdl_mil_select": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
 }
 

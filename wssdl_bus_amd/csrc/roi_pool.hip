@@ -24,9 +24,8 @@
 //            channel, so per element the f32 additions happen in exactly the
 //            reference's order (roi^, ph^, pw^): bit-identical, no atomics, no
 //            pre-zeroing, every bottom_diff element written once, coalesced.
-#include "common.hip.h"
+#include "roi_pool.hip.h"
 
-#include <float.h>
 #include <stdlib.h>
 
 // cache policy of the backward's streaming loads: 0 = default.  nt (2) was measured 5 % slower:
@@ -35,49 +34,6 @@
 
 
 namespace wssdl {
-
-struct RoiGeom {
-    int batch, sw, sh, ew, eh;
-    float bin_h, bin_w;
-};
-
-// roi_pooling_op_gpu.cu.cc:36-49 == roi_pooling_op.cc:152-165
-__device__ __forceinline__ RoiGeom roi_geometry(const float *__restrict__ r, float scale, int PH,
-                                                int PW) {
-    RoiGeom g;
-    g.batch = (int)r[0];
-    g.sw = (int)roundf(r[1] * scale);
-    g.sh = (int)roundf(r[2] * scale);
-    g.ew = (int)roundf(r[3] * scale);
-    g.eh = (int)roundf(r[4] * scale);
-    int rw = max(g.ew - g.sw + 1, 1);
-    int rh = max(g.eh - g.sh + 1, 1);
-    g.bin_h = (float)rh / (float)PH;
-    g.bin_w = (float)rw / (float)PW;
-    return g;
-}
-
-__device__ __forceinline__ void bin_window(const RoiGeom &g, int ph, int pw, int H, int W,
-                                           int rounding, int &hs, int &he, int &ws, int &we) {
-    if (rounding == WSSDL_ROI_ROUND_CPU) {          // roi_pooling_op.cc:167-170
-        hs = (int)((float)ph * g.bin_h);
-        ws = (int)((float)pw * g.bin_w);
-        he = (int)((float)(ph + 1) * g.bin_h);
-        we = (int)((float)(pw + 1) * g.bin_w);
-    } else {                                        // roi_pooling_op_gpu.cu.cc:51-58
-        hs = (int)floorf((float)ph * g.bin_h);
-        ws = (int)floorf((float)pw * g.bin_w);
-        he = (int)ceilf((float)(ph + 1) * g.bin_h);
-        we = (int)ceilf((float)(pw + 1) * g.bin_w);
-    }
-    hs = min(max(hs + g.sh, 0), H);
-    he = min(max(he + g.sh, 0), H);
-    ws = min(max(ws + g.sw, 0), W);
-    we = min(max(we + g.sw, 0), W);
-}
-
-typedef float float4v __attribute__((ext_vector_type(4)));
-typedef int int4v __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ forward ---
 // VEC = 4: one lane = 4 channels (C % 4 == 0);  VEC = 1: scalar fallback.
@@ -221,14 +177,6 @@ struct FastDiv {          // n / d = (n * magic) >> shift with one full-rate v_m
     int shift;
 };
 
-// candidate pooled-bin range of one bottom row / column, roi_pooling_op_gpu.cu.cc:169-177
-__device__ __forceinline__ void cand_range(int d, float bin, int P, int &s, int &e) {
-    s = (int)floorf((float)d / bin);
-    e = (int)ceilf((float)(d + 1) / bin);
-    s = min(max(s, 0), P);
-    e = min(max(e, 0), P);
-}
-
 // One (RoI, tile) intersection, produced by the filter phase (16 B in LDS).
 //   geo     = ph0 | pw0 << 8 | phn << 16 | pwn << 20 | (r - chunk base) << 24: the candidate bins of
 //             the tile's cells are [ph0, ph0+phn) x [pw0, pw0+pwn)  (phstart/phend are monotone in
@@ -242,35 +190,6 @@ struct TouchRec {
     unsigned rowmask;
     unsigned long long colmask;
 };
-constexpr unsigned TOUCH_GENERIC = 0xfu;
-constexpr long long BWD_MIN_WORKGROUPS = 1024;   // one per workgroup slot of the chip (256 CUs x 4)
-
-template <int TN, int FW = 8>
-__device__ __forceinline__ void touch_axis(int t0, int t1, int rs, int re, float bin, int P, int &p0,
-                                           int &pn, unsigned long long &mask) {
-    // tile cells t0..t1 (inclusive, <= TN of them), RoI cells rs..re; mask bit FW*k + j
-    static_assert(TN <= FW && FW * 8 <= 64, "one FW-bit field per candidate bin");
-    const int lo = max(t0, rs), hi = min(t1, re);
-    int s[TN], e[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        s[j] = e[j] = 0;
-        if (t0 + j >= lo && t0 + j <= hi) cand_range(t0 + j - rs, bin, P, s[j], e[j]);
-    }
-    int a, z, t;
-    cand_range(lo - rs, bin, P, a, t);
-    cand_range(hi - rs, bin, P, t, z);
-    p0 = a;
-    pn = z - a;
-    mask = 0ull;
-    if (lo > hi) { pn = 0; return; }
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-            if (a + k >= s[j] && a + k < e[j]) mask |= 1ull << (FW * k + j);
-}
-
 
 // Per-wave constants of the walk (kept in registers across RoIs)
 struct WalkCtx {

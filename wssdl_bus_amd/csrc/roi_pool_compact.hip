@@ -1,0 +1,580 @@
+// RoI max-pooling, TRAINING path with a 1-byte arg-max, for gfx950 (MI355X).
+//
+// In the reference the arg-max tensor is an internal hand-off: network.py:206-210 keeps only
+// top_data ([0] of the op's outputs) and the registered gradient (roi_pooling_op_grad.py:24-44)
+// feeds argmax straight back into RoiPoolGrad.  Its i32 layout (a flat NHWC index,
+// roi_pooling_op_gpu.cu.cc:71-79) costs as many bytes as the activations, and both kernels are
+// HBM-bound on exactly those bytes.  Here the pair (forward, backward) agrees on one byte per
+// element instead:
+//
+//     code = (h - hstart) << 4 | (w - wstart)        0xff = empty bin (the reference's -1)
+//
+// where [hstart, hend) x [wstart, wend) is the bin's CLIPPED window (roi_pooling_op_gpu.cu.cc:
+// 51-64 / roi_pooling_op.cc:167-176).  Windows are at most 15 rows x 16 columns for every RoI
+// that lies inside a feature map of up to 97 x 104 cells with 7 x 7 bins (the host checks the
+// map size; a window beyond that sets *overflow).  wssdl_roi_argmax_expand turns the codes
+// back into the reference's i32 indices (tests compare those with the oracle bit for bit).
+//
+// Forward : the XCD-sliced kernel of roi_pool.hip, writing 4 + 1 instead of 4 + 4 bytes per
+//           element (the kernel is bound by its store stream).
+// Backward: the tile-owner kernel of roi_pool.hip (4x4-cell x 256-channel tiles of bottom_diff in
+//           LDS, RoIs filtered per tile in RoI order, candidate bins walked in (ph, pw) order, one
+//           lane per channel => the reference's f32 summation order, bit-identical) reading 4 + 1
+//           bytes per visited element.  Bins that straddle tile borders are read by every tile
+//           they touch, so the saving applies to the re-reads too.  The (RoI, tile) record built
+//           by the filter phase additionally carries the window start of each candidate bin row /
+//           column relative to the tile, so decoding a code is two adds and two mask look-ups
+//           (no division by W or C as with the flat index).
+#include "roi_pool.hip.h"
+
+#include <stdlib.h>
+
+namespace wssdl {
+
+// tuning builds only (-DWSSDL_BWDC_ABLATE=n via WSSDL_HIPCC_EXTRA): 1 = walk without loads,
+// 2 = loads without decode / accumulation, 3 = filter phase only, 4 = no LDS accumulation
+#ifndef WSSDL_BWDC_ABLATE
+#define WSSDL_BWDC_ABLATE 0
+#endif
+
+// tuning builds only (-DWSSDL_BWDC_TRACE=1): every workgroup of the backward records
+// (start, end) of s_memrealtime (100 MHz) and its record / bin counts into a buffer set with
+// wssdl_debug_set_trace (tools/bwd_trace.py)
+#ifndef WSSDL_BWDC_TRACE
+#define WSSDL_BWDC_TRACE 0
+#endif
+#if WSSDL_BWDC_TRACE
+static unsigned long long *g_trace = nullptr;
+extern "C" __attribute__((visibility("default"))) void wssdl_debug_set_trace(void *p) {
+    g_trace = static_cast<unsigned long long *>(p);
+}
+#define WSSDL_TRACE_PARAM , unsigned long long *__restrict__ trace
+#define WSSDL_TRACE_ARG , g_trace
+#else
+#define WSSDL_TRACE_PARAM
+#define WSSDL_TRACE_ARG
+#endif
+
+constexpr unsigned ARG8_EMPTY = 0xffu;
+constexpr int ARG8_MAX_WIN_H = 15;    // dh <= 14: the code 0xff = (15, 15) can never be produced
+constexpr int ARG8_MAX_WIN_W = 16;
+
+// clipped window start of bin p: roi_pooling_op_gpu.cu.cc:51-52,61-63 / roi_pooling_op.cc:167-168,173-175
+__device__ __forceinline__ int win_start(int p, float bin, int rs, int limit, int rounding) {
+    const float v = (float)p * bin;
+    const int s = (rounding == WSSDL_ROI_ROUND_CPU) ? (int)v : (int)floorf(v);
+    return min(max(s + rs, 0), limit);
+}
+
+__device__ __forceinline__ int win_end(int p, float bin, int rs, int limit, int rounding) {
+    const float v = (float)(p + 1) * bin;
+    const int e = (rounding == WSSDL_ROI_ROUND_CPU) ? (int)v : (int)ceilf(v);
+    return min(max(e + rs, 0), limit);
+}
+
+// ------------------------------------------------------------------ forward ---
+// Workgroup b serves channel slice b % 8 (one XCD's L2 then holds only its slice of the feature
+// map); a lane owns 4 channels of one (roi, ph) bin row and walks its PW bins.  C % 32 == 0.
+template <int BATCH>
+__global__ __launch_bounds__(256) void roi_pool_fwd_compact_kernel(
+    const float *__restrict__ bottom, int N, int H, int W, int C, const float *__restrict__ rois,
+    int R, int PH, int PW, float scale, int rounding, float *__restrict__ top,
+    unsigned *__restrict__ arg8 /* [R,PH,PW,C] bytes, written 4 at a time */,
+    int *__restrict__ overflow, int lanes_per_row /* = C/32 */, int rows_per_block) {
+    const int slice = blockIdx.x & 7;
+    const long long rows = (long long)R * PH;
+    const long long row = (long long)(blockIdx.x >> 3) * rows_per_block + threadIdx.x / lanes_per_row;
+    if (row >= rows) return;
+    const int lane_in_row = threadIdx.x % lanes_per_row;
+    const int c0 = slice * (C >> 3) + lane_in_row * 4;
+    const int r = (int)(row / PH), ph = (int)(row - (long long)r * PH);
+    const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);
+    const bool bad = g.batch < 0 || g.batch >= N;
+    const float *img = bottom + (size_t)(bad ? 0 : g.batch) * H * W * C;
+    const int hs = win_start(ph, g.bin_h, g.sh, H, rounding);
+    const int he = win_end(ph, g.bin_h, g.sh, H, rounding);
+    size_t o = ((size_t)row * PW) * C + c0;
+    for (int pw = 0; pw < PW; ++pw, o += C) {
+        const int ws = win_start(pw, g.bin_w, g.sw, W, rounding);
+        const int we = win_end(pw, g.bin_w, g.sw, W, rounding);
+        const bool empty = (he <= hs) || (we <= ws) || bad;
+        float4v mv = empty ? (float4v)(0.0f) : (float4v)(-FLT_MAX);
+        unsigned m0 = ARG8_EMPTY, m1 = ARG8_EMPTY, m2 = ARG8_EMPTY, m3 = ARG8_EMPTY;
+        if (!empty) {
+            if ((he - hs > ARG8_MAX_WIN_H || we - ws > ARG8_MAX_WIN_W) && overflow) atomicOr(overflow, 1);
+            // BATCH cells of a window row are fetched together; slots past the window's last
+            // column re-read that column: an equal value never passes the strict >, so the scan
+            // order and the first-maximum rule (roi_pooling_op_gpu.cu.cc:71-79) are untouched.
+            for (int h = hs; h < he; ++h) {
+                const int row_base = h * W * C + c0;
+                const unsigned rcode = (unsigned)(h - hs) << 4;
+                for (int w = ws; w < we; w += BATCH) {
+                    float4v v[BATCH];
+                    unsigned code[BATCH];
+#pragma unroll
+                    for (int j = 0; j < BATCH; ++j) {
+                        const int wj = min(w + j, we - 1);
+                        code[j] = rcode | (unsigned)(wj - ws);
+                        v[j] = *reinterpret_cast<const float4v *>(img + row_base + wj * C);
+                    }
+#pragma unroll
+                    for (int j = 0; j < BATCH; ++j) {
+                        if (v[j].x > mv.x) { mv.x = v[j].x; m0 = code[j]; }
+                        if (v[j].y > mv.y) { mv.y = v[j].y; m1 = code[j]; }
+                        if (v[j].z > mv.z) { mv.z = v[j].z; m2 = code[j]; }
+                        if (v[j].w > mv.w) { mv.w = v[j].w; m3 = code[j]; }
+                    }
+                }
+            }
+        }
+        __builtin_nontemporal_store(mv, reinterpret_cast<float4v *>(top + o));
+        __builtin_nontemporal_store(m0 | (m1 << 8) | (m2 << 16) | (m3 << 24), arg8 + (o >> 2));
+    }
+}
+
+// codes -> the reference's flat NHWC index (roi_pooling_op_gpu.cu.cc:71-79); one lane = 4 channels
+__global__ __launch_bounds__(256) void roi_argmax_expand_kernel(
+    const unsigned *__restrict__ arg8, const float *__restrict__ rois, long long total4, int H, int W,
+    int C, int PH, int PW, float scale, int rounding, int4v *__restrict__ out) {
+    const int C4 = C >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long bin = i / C4;
+        const int c0 = (int)(i - bin * C4) * 4;
+        const int pw = (int)(bin % PW), ph = (int)((bin / PW) % PH);
+        const int r = (int)(bin / ((long long)PW * PH));
+        const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);
+        const int hs = win_start(ph, g.bin_h, g.sh, H, rounding);
+        const int ws = win_start(pw, g.bin_w, g.sw, W, rounding);
+        const unsigned codes = arg8[i];
+        int4v o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned a = (codes >> (8 * j)) & 0xffu;
+            const int idx = ((hs + (int)(a >> 4)) * W + ws + (int)(a & 15u)) * C + c0 + j;
+            o[j] = (a == ARG8_EMPTY) ? -1 : idx;
+        }
+        out[i] = o;
+    }
+}
+
+// ----------------------------------------------------------------- backward ---
+// One (RoI, tile) intersection (32 B in LDS).  geo / rowmask / colmask as in roi_pool.hip:
+//   geo     = ph0 | pw0 << 8 | phn << 16 | pwn << 20 | (r - chunk base) << 24
+//   rowmask : bit 4*k + j <=> tile row h0+j lies in the RoI and bin row ph0+k is one of its
+//             candidate rows (roi_pooling_op_gpu.cu.cc:141-151,169-177); colmask: bit 8*k + j
+//   hs      : byte k = (clipped window start of bin row ph0+k) - h0, clamped to [-16, 15];
+//   ws      : byte k likewise for bin column pw0+k and w0.
+struct TouchRecC {
+    unsigned geo;
+    unsigned rowmask;
+    unsigned long long colmask;
+    unsigned long long hs;
+    unsigned long long ws;
+};
+
+struct WalkCtxC {
+    float *acc;            // LDS tile [TH*TW][CG]
+    int tc;
+    bool lane_ok;          // channel < C
+    int voff8, voff;       // lane's byte offset inside a bin of arg8 / top_diff
+};
+
+template <int PWN, int NROWS, int TW, int CG>
+__device__ __forceinline__ void visit_rows_c(const WalkCtxC &x, __amdgpu_buffer_rsrc_t ra,
+                                             __amdgpu_buffer_rsrc_t rt, int so8, int so, int C, int PW,
+                                             unsigned rowmask, int row0, unsigned long long colmask,
+                                             unsigned long long hs, unsigned long long ws) {
+    unsigned a[NROWS][PWN];
+    float td[NROWS][PWN];
+#pragma unroll
+    for (int q = 0; q < NROWS; ++q)
+#pragma unroll
+        for (int j = 0; j < PWN; ++j) {
+            const int bin = q * PW + j;
+#if WSSDL_BWDC_ABLATE == 1
+            a[q][j] = (unsigned)(x.tc * 7 + bin + so8) & 0x33u;
+            td[q][j] = 1.0f;
+#else
+            a[q][j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(ra, x.voff8, so8 + bin * C, 0);
+            td[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, x.voff, so + bin * C * 4, 0));
+#endif
+        }
+    // keep every loaded value live here: otherwise the compiler sinks the top_diff loads into
+    // the (rare) hit branch and serialises them
+#pragma unroll
+    for (int q = 0; q < NROWS; ++q)
+#pragma unroll
+        for (int j = 0; j < PWN; ++j) asm volatile("" : "+v"(a[q][j]), "+v"(td[q][j]));
+#if WSSDL_BWDC_ABLATE == 2
+    return;
+#endif
+#pragma unroll
+    for (int q = 0; q < NROWS; ++q) {
+        const int sh4 = 4 * (row0 + q), sh8 = 8 * (row0 + q);
+        const unsigned rm = (rowmask >> sh4) & 0xfu;
+        const int hsq = (int)(signed char)(hs >> sh8);
+#pragma unroll
+        for (int j = 0; j < PWN; ++j) {
+            const unsigned cmk = (unsigned)(colmask >> (8 * j)) & 0xffu;
+            const int wsj = (int)(signed char)(ws >> (8 * j));
+            const unsigned code = a[q][j];
+            const int th = hsq + (int)(code >> 4), tw = wsj + (int)(code & 15u);
+            // tile, in_roi and candidate-bin tests: the masks have no bits at positions a cell
+            // outside the tile would index (th, tw in [-16, 30]; shifts use the low 5 bits)
+            const unsigned bits = (rm >> (th & 31)) & (cmk >> (tw & 31)) & 1u;
+            const bool ok = (bits != 0u) & (code != ARG8_EMPTY) & x.lane_ok;
+#if WSSDL_BWDC_ABLATE == 4
+            float v = ok ? td[q][j] : 0.0f;
+            asm volatile("" :: "v"(v), "v"(th * TW + tw));
+#else
+            if (ok) {
+                float *p = &x.acc[(th * TW + tw) * CG + x.tc];
+                *p = *p + td[q][j];
+            }
+#endif
+        }
+    }
+}
+
+template <int PWN, int TW, int CG, int MAXB>
+__device__ __forceinline__ void visit_roi_c(const WalkCtxC &x, __amdgpu_buffer_rsrc_t ra,
+                                            __amdgpu_buffer_rsrc_t rt, int so8, int so, int C, int PW,
+                                            unsigned rowmask, int phn, unsigned long long colmask,
+                                            unsigned long long hs, unsigned long long ws) {
+    constexpr int NR = (MAXB / PWN) >= 4 ? 4 : ((MAXB / PWN) >= 3 ? 3 : 2);
+    int rb = 0;
+    for (; rb + NR <= phn; rb += NR, so8 += NR * PW * C, so += NR * PW * C * 4)
+        visit_rows_c<PWN, NR, TW, CG>(x, ra, rt, so8, so, C, PW, rowmask, rb, colmask, hs, ws);
+    const int rem = phn - rb;
+    if (NR > 3 && rem == 3)
+        visit_rows_c<PWN, 3, TW, CG>(x, ra, rt, so8, so, C, PW, rowmask, rb, colmask, hs, ws);
+    else if (NR > 2 && rem == 2)
+        visit_rows_c<PWN, 2, TW, CG>(x, ra, rt, so8, so, C, PW, rowmask, rb, colmask, hs, ws);
+    else if (rem == 1)
+        visit_rows_c<PWN, 1, TW, CG>(x, ra, rt, so8, so, C, PW, rowmask, rb, colmask, hs, ws);
+}
+
+template <int TH, int TW, int CG, int CHUNK, int MAXB, int MINB>
+__global__ __launch_bounds__(CG, MINB) void roi_pool_bwd_compact_kernel(
+    const float *__restrict__ top_diff, const unsigned char *__restrict__ arg8,
+    const float *__restrict__ rois, int R, int N, int H, int W, int C, int PH, int PW, float scale,
+    int rounding, float *__restrict__ bottom_diff, int tiles_h, int tiles_w, int cgroups WSSDL_TRACE_PARAM) {
+    static_assert(TH <= 4 && TW <= 8, "4 mask bits per candidate bin row, 8 per column");
+#if WSSDL_BWDC_TRACE
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long n_rec = 0, n_bins = 0;
+#endif
+    static_assert(CHUNK <= 256, "8-bit RoI index inside a filter round");
+    static_assert(CHUNK % CG == 0 || CHUNK < CG, "whole filter rounds");
+    constexpr int KPT = CHUNK >= CG ? CHUNK / CG : 1;   // RoIs tested per thread per filter round
+    constexpr int NW = CG / WSSDL_WAVE;
+    __shared__ float acc[TH * TW * CG];
+    __shared__ TouchRecC list[CHUNK];
+    __shared__ int wave_cnt[KPT][NW];
+    __shared__ int roi_span[2];
+
+    // Workgroup -> (image, channel group, tile): all tiles of one (image, channel group) pair
+    // share blockIdx % 8 (observed: one XCD), so border bins re-read by neighbouring tiles can
+    // meet in one L2.  Placement affects speed only.
+    const int pairs = N * cgroups, tiles = tiles_h * tiles_w;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = xcd + 8 * (slot / tiles);
+    if (pair >= pairs) return;
+    const int tile = slot % tiles;
+    const int cg = pair % cgroups, n = pair / cgroups;
+    const int tx = tile % tiles_w, ty = tile / tiles_w;
+    const int tc = threadIdx.x;
+    const int c = cg * CG + tc;
+    const bool c_ok = c < C;
+    const int h0 = ty * TH, w0 = tx * TW;
+    const int h1 = min(h0 + TH, H) - 1, w1 = min(w0 + TW, W) - 1;   // inclusive
+    const int lane = tc & (WSSDL_WAVE - 1), wave = tc / WSSDL_WAVE;
+    const int cl = c_ok ? c : C - 1;       // lanes past C read channel C-1 and never accumulate
+    const int roi_elems = PH * PW * C;
+    WalkCtxC wx;
+    wx.acc = acc;  wx.tc = tc;  wx.lane_ok = c_ok;  wx.voff8 = cl;  wx.voff = cl * 4;
+
+#pragma unroll
+    for (int i = 0; i < TH * TW; ++i) acc[i * CG + tc] = 0.0f;
+
+    // ---- the span of RoI indices that belong to image n (RoIs normally arrive grouped by image;
+    // any order stays correct)
+    if (tc == 0) { roi_span[0] = R; roi_span[1] = -1; }
+    __syncthreads();
+    {
+        int lo = R, hi = -1;
+        for (int r = tc; r < R; r += CG)
+            if ((int)rois[(size_t)r * 5] == n) { lo = min(lo, r); hi = r; }
+        if (hi >= 0) { atomicMin(&roi_span[0], lo); atomicMax(&roi_span[1], hi); }
+    }
+    __syncthreads();
+    const int r_begin = roi_span[0], r_end = roi_span[1] + 1;
+
+    for (int base = r_begin; base < r_end; base += CHUNK) {
+        // ---- filter: RoIs of image n whose rounded box touches the tile, in RoI order
+        bool hit[KPT];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int r = base + k * CG + tc;
+            hit[k] = false;
+            if (r < r_end && k * CG + tc < CHUNK) {
+                const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);
+                hit[k] = (g.batch == n) && g.sw <= w1 && g.ew >= w0 && g.sh <= h1 && g.eh >= h0;
+            }
+            const unsigned long long m = __ballot(hit[k]);
+            if (lane == 0) wave_cnt[k][wave] = __popcll(m);
+        }
+        __syncthreads();
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const unsigned long long m = __ballot(hit[k]);
+            int before = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int wc = wave_cnt[k][w];
+                before += (w < wave) ? wc : 0;
+            }
+            if (hit[k])   // only the RoI's index for now; finished below
+                list[cnt + before + __popcll(m & ((1ull << lane) - 1ull))].geo = (unsigned)(k * CG + tc);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) cnt += wave_cnt[k][w];
+        }
+        __syncthreads();
+        // finish the records with the hits packed into the first threads: candidate ranges of the
+        // tile's rows / columns (the reference's backward tests) and the forward's window starts
+        for (int t = tc; t < cnt; t += CG) {
+            TouchRecC q;
+            const unsigned rel = list[t].geo;
+            const RoiGeom g = roi_geometry(rois + (size_t)(base + (int)rel) * 5, scale, PH, PW);
+            int ph0, phn, pw0, pwn;
+            unsigned long long rm;
+            touch_axis<TH, 4>(h0, h1, g.sh, g.eh, g.bin_h, PH, ph0, phn, rm);
+            touch_axis<TW, 8>(w0, w1, g.sw, g.ew, g.bin_w, PW, pw0, pwn, q.colmask);
+            q.hs = q.ws = 0ull;
+            if (phn <= 0 || pwn <= 0) phn = pwn = 0;                          // nothing to visit
+            else if (phn > 8 || pwn > 8) phn = pwn = (int)TOUCH_GENERIC;
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int a = min(max(win_start(ph0 + k, g.bin_h, g.sh, H, rounding) - h0, -16), 15);
+                    const int b = min(max(win_start(pw0 + k, g.bin_w, g.sw, W, rounding) - w0, -16), 15);
+                    q.hs |= (unsigned long long)((unsigned)a & 0xffu) << (8 * k);
+                    q.ws |= (unsigned long long)((unsigned)b & 0xffu) << (8 * k);
+                }
+            }
+            q.rowmask = (unsigned)rm;
+            q.geo = (unsigned)ph0 | ((unsigned)pw0 << 8) | ((unsigned)phn << 16) | ((unsigned)pwn << 20) |
+                    (rel << 24);
+            list[t] = q;
+        }
+        __syncthreads();
+
+        // ---- walk the touching RoIs in order; every lane = one channel, so per element the f32
+        // additions happen in the reference's order (roi^, ph^, pw^).  The record is wave-uniform.
+#if WSSDL_BWDC_ABLATE == 3
+        cnt = 0;
+#endif
+        for (int i = 0; i < cnt; ++i) {
+            const unsigned geo = (unsigned)__builtin_amdgcn_readfirstlane((int)list[i].geo);
+            const int r = base + (int)(geo >> 24);
+            const int ph0 = geo & 0xff, pw0 = (geo >> 8) & 0xff;
+            const int phn = (geo >> 16) & 0xf, pwn = (geo >> 20) & 0xf;
+            const size_t rbin0 = (size_t)r * PH * PW;
+            if (phn == 0) continue;
+#if WSSDL_BWDC_TRACE
+            n_rec += 1;
+            n_bins += (unsigned)(phn * pwn);
+#endif
+            if (phn != (int)TOUCH_GENERIC) {
+#define WSSDL_RFL64(v) (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((v) >> 32)) << 32) | \
+                        (unsigned)__builtin_amdgcn_readfirstlane((int)(v)))
+                const unsigned rowmask = (unsigned)__builtin_amdgcn_readfirstlane((int)list[i].rowmask);
+                const unsigned long long colmask = WSSDL_RFL64(list[i].colmask);
+                const unsigned long long hs = WSSDL_RFL64(list[i].hs);
+                const unsigned long long ws = WSSDL_RFL64(list[i].ws);
+#undef WSSDL_RFL64
+                const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<unsigned char *>(arg8 + rbin0 * C), 0, roi_elems, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(top_diff + rbin0 * C), 0, roi_elems * 4, 0x00020000);
+                const int so8 = (ph0 * PW + pw0) * C;      // scalar byte offset of the first bin
+#define WSSDL_VISIT(K) visit_roi_c<K, TW, CG, MAXB>(wx, ra, rt, so8, so8 * 4, C, PW, rowmask, phn, colmask, hs, ws)
+                switch (pwn) {                                       // wave-uniform
+                    case 1: WSSDL_VISIT(1); break;
+                    case 2: WSSDL_VISIT(2); break;
+                    case 3: WSSDL_VISIT(3); break;
+                    case 4: WSSDL_VISIT(4); break;
+                    case 5: WSSDL_VISIT(5); break;
+                    case 6: WSSDL_VISIT(6); break;
+                    case 7: WSSDL_VISIT(7); break;
+                    default: WSSDL_VISIT(8); break;
+                }
+#undef WSSDL_VISIT
+            } else {
+                // pooled sizes with more than 8 candidate bin rows / columns per tile: one bin at a
+                // time, the reference's tests evaluated per lane
+                const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);
+                const int hlo = max(h0, g.sh), hhi = min(h1, g.eh);
+                const int wlo = max(w0, g.sw), whi = min(w1, g.ew);
+                int pa, pz, qa, qz, t;
+                cand_range(hlo - g.sh, g.bin_h, PH, pa, t);
+                cand_range(hhi - g.sh, g.bin_h, PH, t, pz);
+                cand_range(wlo - g.sw, g.bin_w, PW, qa, t);
+                cand_range(whi - g.sw, g.bin_w, PW, t, qz);
+                for (int ph = pa; ph < pz; ++ph) {
+                    const int bhs = win_start(ph, g.bin_h, g.sh, H, rounding);
+                    for (int pw = qa; pw < qz; ++pw) {
+                        const size_t bo = (rbin0 + (size_t)(ph * PW + pw)) * C;
+                        const unsigned code = (arg8 + bo)[cl];
+                        const float tv = (top_diff + bo)[cl];
+                        if (code == ARG8_EMPTY || !c_ok) continue;
+                        const int h = bhs + (int)(code >> 4);
+                        const int w = win_start(pw, g.bin_w, g.sw, W, rounding) + (int)(code & 15u);
+                        if (h < hlo || h > hhi || w < wlo || w > whi) continue;
+                        int rs, re, cs, ce;
+                        cand_range(h - g.sh, g.bin_h, PH, rs, re);
+                        cand_range(w - g.sw, g.bin_w, PW, cs, ce);
+                        if (ph >= rs && ph < re && pw >= cs && pw < ce) {
+                            float *a = &acc[((h - h0) * TW + (w - w0)) * CG + tc];
+                            *a = *a + tv;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (c_ok) {
+        float *img = bottom_diff + (size_t)n * H * W * C;
+#pragma unroll
+        for (int i = 0; i < TH * TW; ++i) {
+            const int h = h0 + i / TW, w = w0 + i % TW;
+            if (h < H && w < W) img[((size_t)h * W + w) * C + c] = acc[i * CG + tc];
+        }
+    }
+#if WSSDL_BWDC_TRACE
+    if (trace && tc == 0) {
+        unsigned long long *t = trace + (size_t)blockIdx.x * 4;
+        t[0] = t_start;  t[1] = __builtin_amdgcn_s_memrealtime();  t[2] = n_rec;  t[3] = n_bins;
+    }
+#endif
+}
+
+template <int TH, int TW, int CG, int CHUNK, int MAXB = 8, int MINB = 1>
+static int launch_bwd_c(const float *top_diff, const unsigned char *arg8, const float *rois, int R, int N,
+                        int H, int W, int C, int PH, int PW, float scale, int rounding,
+                        float *bottom_diff, hipStream_t st) {
+    int tiles_h = cdiv(H, TH), tiles_w = cdiv(W, TW), cgroups = cdiv(C, CG);
+    // 8 interleaved queues (one per blockIdx % 8) of ceil(pairs / 8) * tiles workgroups each
+    long long blocks = 8LL * cdiv((long long)N * cgroups, 8) * tiles_h * tiles_w;
+    if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL((roi_pool_bwd_compact_kernel<TH, TW, CG, CHUNK, MAXB, MINB>), dim3((unsigned)blocks),
+                       dim3(CG), 0, st, top_diff, arg8, rois, R, N, H, W, C, PH, PW, scale, rounding,
+                       bottom_diff, tiles_h, tiles_w, cgroups WSSDL_TRACE_ARG);
+    return check_launch();
+}
+
+static bool compact_supported(int H, int W, int C, int PH, int PW) {
+    if (H < 1 || W < 1 || C < 32 || (C % 32) != 0 || C / 32 > 256 || PH < 1 || PW < 1) return false;
+    if (PH > 255 || PW > 255) return false;
+    // a RoI inside the map spans at most H+1 (W+1) cells after rounding: windows of at most
+    // ceil((H+1)/PH) + 1 rows, ceil((W+1)/PW) + 1 columns
+    return cdiv(H + 1, PH) + 1 <= ARG8_MAX_WIN_H && cdiv(W + 1, PW) + 1 <= ARG8_MAX_WIN_W;
+}
+
+}  // namespace wssdl
+
+using namespace wssdl;
+
+extern "C" int wssdl_roi_pool_compact_supported(int H, int W, int C, int pooled_h, int pooled_w) {
+    return compact_supported(H, W, C, pooled_h, pooled_w) ? 1 : 0;
+}
+
+extern "C" int wssdl_roi_pool_forward_compact(const float *bottom, int N, int H, int W, int C,
+                                              const float *rois, int R, int pooled_h, int pooled_w,
+                                              float spatial_scale, int rounding, float *top,
+                                              uint8_t *argmax8, int32_t *overflow,
+                                              wssdl_stream_t stream) {
+    if (N < 0 || R < 0 || !compact_supported(H, W, C, pooled_h, pooled_w)) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (rounding != WSSDL_ROI_ROUND_CUDA && rounding != WSSDL_ROI_ROUND_CPU)
+        return WSSDL_ERR_INVALID_ARGUMENT;
+    if (R == 0) return WSSDL_OK;
+    if (!bottom || !rois || !top || !argmax8 || N < 1) return WSSDL_ERR_INVALID_ARGUMENT;
+    if ((reinterpret_cast<uintptr_t>(bottom) & 15) || (reinterpret_cast<uintptr_t>(top) & 15) ||
+        (reinterpret_cast<uintptr_t>(argmax8) & 3))
+        return WSSDL_ERR_INVALID_ARGUMENT;
+    hipStream_t st = as_stream(stream);
+    const int lanes_per_row = C / 32;
+    const int rows_per_block = 256 / lanes_per_row;
+    const long long row_blocks = ((long long)R * pooled_h + rows_per_block - 1) / rows_per_block;
+    if (row_blocks * 8 > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
+    unsigned *a8 = reinterpret_cast<unsigned *>(argmax8);
+    if (row_blocks * 8 <= 4096)      // less than ~4 workgroups per CU: latency-bound, fetch 2 cells at a time
+        hipLaunchKernelGGL(roi_pool_fwd_compact_kernel<2>, dim3((unsigned)(row_blocks * 8)), dim3(256), 0, st,
+                           bottom, N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top, a8,
+                           overflow, lanes_per_row, rows_per_block);
+    else
+        hipLaunchKernelGGL(roi_pool_fwd_compact_kernel<1>, dim3((unsigned)(row_blocks * 8)), dim3(256), 0, st,
+                           bottom, N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top, a8,
+                           overflow, lanes_per_row, rows_per_block);
+    return check_launch();
+}
+
+extern "C" int wssdl_roi_argmax_expand(const uint8_t *argmax8, const float *rois, int R, int H, int W,
+                                       int C, int pooled_h, int pooled_w, float spatial_scale,
+                                       int rounding, int32_t *argmax, wssdl_stream_t stream) {
+    if (R < 0 || !compact_supported(H, W, C, pooled_h, pooled_w)) return WSSDL_ERR_INVALID_ARGUMENT;
+    if ((long long)H * W * C > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (R == 0) return WSSDL_OK;
+    if (!argmax8 || !rois || !argmax) return WSSDL_ERR_INVALID_ARGUMENT;
+    if ((reinterpret_cast<uintptr_t>(argmax8) & 3) || (reinterpret_cast<uintptr_t>(argmax) & 15))
+        return WSSDL_ERR_INVALID_ARGUMENT;
+    const long long total4 = (long long)R * pooled_h * pooled_w * (C / 4);
+    long long blocks = (total4 + 255) / 256;
+    if (blocks > (1LL << 20)) blocks = 1LL << 20;
+    hipLaunchKernelGGL(roi_argmax_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const unsigned *>(argmax8), rois, total4, H, W, C, pooled_h, pooled_w,
+                       spatial_scale, rounding, reinterpret_cast<int4v *>(argmax));
+    return check_launch();
+}
+
+extern "C" int wssdl_roi_pool_backward_compact(const float *top_diff, const uint8_t *argmax8,
+                                               const float *rois, int R, int N, int H, int W, int C,
+                                               int pooled_h, int pooled_w, float spatial_scale,
+                                               int rounding, float *bottom_diff,
+                                               wssdl_stream_t stream) {
+    if (N < 0 || R < 0 || !compact_supported(H, W, C, pooled_h, pooled_w)) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (rounding != WSSDL_ROI_ROUND_CUDA && rounding != WSSDL_ROI_ROUND_CPU)
+        return WSSDL_ERR_INVALID_ARGUMENT;
+    if (N == 0) return WSSDL_OK;
+    if (!bottom_diff || (R > 0 && (!top_diff || !argmax8 || !rois))) return WSSDL_ERR_INVALID_ARGUMENT;
+    hipStream_t st = as_stream(stream);
+    // channels per workgroup: 256 when that still yields enough workgroups to fill the chip
+    int cg = C > 128 ? 256 : (C > 64 ? 128 : 64);
+    const long long tiles = (long long)cdiv(H, 4) * cdiv(W, 8);       // counted in 4x8 tiles
+    while (cg > 64 && (long long)N * cdiv(C, cg) * tiles < BWD_MIN_WORKGROUPS) cg >>= 1;
+    int variant = 0;
+    if (const char *e = getenv("WSSDL_ROI_BWD_CG")) {       // tuning overrides
+        const int v = atoi(e);
+        if (v == 64 || v == 128 || v == 256) cg = v;
+    }
+    if (const char *e = getenv("WSSDL_ROI_BWDC_VARIANT")) variant = atoi(e);
+#define WSSDL_BWDC(TH, TW, CGV, CHUNK, MAXB, MINB) \
+    launch_bwd_c<TH, TW, CGV, CHUNK, MAXB, MINB>(top_diff, argmax8, rois, R, N, H, W, C, pooled_h, pooled_w, \
+                                                 spatial_scale, rounding, bottom_diff, st)
+    if (cg == 256) {
+        switch (variant) {
+            case 1: return WSSDL_BWDC(4, 4, 256, 218, 8, 7);     // 7 workgroups / CU, longer filter rounds
+            case 2: return WSSDL_BWDC(4, 8, 256, 240, 8, 4);     // 4x8 tiles: fewer border re-reads, 4-5 wg / CU
+            case 3: return WSSDL_BWDC(4, 8, 256, 240, 16, 4);
+            case 4: return WSSDL_BWDC(4, 4, 256, 126, 12, 6);
+            default: return WSSDL_BWDC(4, 4, 256, 126, 8, 8);    // 8 workgroups / CU (20 KiB of LDS each)
+        }
+    }
+    if (cg == 128) return WSSDL_BWDC(4, 8, 128, 128, 8, 1);
+    return WSSDL_BWDC(4, 8, 64, 64, 8, 1);
+#undef WSSDL_BWDC
+}

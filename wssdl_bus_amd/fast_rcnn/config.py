@@ -79,6 +79,9 @@ __C.FUSED_RPN_SOFTMAX = False
 # RoI-pool bin rounding: 'cuda' (canonical, roi_pooling_op_gpu.cu.cc:51-58) or
 # 'cpu' (roi_pooling_op.cc:167-170)
 __C.ROI_POOL_ROUNDING = "cuda"
+# training path: the autograd pair hands a 1-byte arg-max from RoiPool to RoiPoolGrad when the
+# library supports the shape (include/wssdl_bus_hip.h); False = the reference's i32 layout
+__C.ROI_POOL_COMPACT_ARGMAX = True
 
 
 def cfg_from_list(cfg_list):

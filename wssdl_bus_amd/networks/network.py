@@ -83,7 +83,7 @@ class Network(object):
         differentiable w.r.t. the feature map."""
         data, rois = _first(input[0]), _first(input[1])
         return roi_pool_op.roi_pool_autograd(data, rois, pooled_height, pooled_width,
-                                             spatial_scale)[0]
+                                             spatial_scale, return_argmax=False)[0]
 
     @layer
     def proposal_layer(self, input, _feat_stride, anchor_scales, is_training, is_ws, name):

@@ -75,33 +75,129 @@ def roi_pool_grad(bottom_data, bottom_rois, argmax, grad, pooled_height, pooled_
     return out.cpu().numpy() if as_np else out
 
 
+# ----------------------------------------------------- training path: 1-byte arg-max ---
+# The arg-max tensor is an internal hand-off between the op and its gradient
+# (network.py:206-210 keeps top_data only; roi_pooling_op_grad.py:24-44 feeds argmax back), so the
+# autograd pair below agrees on one byte per element instead of four whenever the library
+# supports the shape (include/wssdl_bus_hip.h, "training path").  top_data and the gradient are
+# bit-identical to the i32 pair; `expand_argmax` rebuilds the reference's i32 indices.
+
+_overflow_flags = {}
+
+
+def compact_supported(H, W, C, pooled_height, pooled_width):
+    return bool(cfg.ROI_POOL_COMPACT_ARGMAX) and bool(
+        _lib.lib().wssdl_roi_pool_compact_supported(int(H), int(W), int(C), int(pooled_height),
+                                                    int(pooled_width)))
+
+
+def _overflow_flag(dev):
+    f = _overflow_flags.get(dev)
+    if f is None:
+        f = torch.zeros((1,), dtype=torch.int32, device=dev)
+        _overflow_flags[dev] = f
+    return f
+
+
+def compact_overflowed(device=None):
+    """True when any compact forward on `device` met a window larger than 15 x 16 cells (a RoI
+    reaching far outside the feature map).  Synchronises; for tests / debugging."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    f = _overflow_flags.get(dev)
+    return bool(f is not None and int(f.item()) != 0)
+
+
+def roi_pool_compact(data, rois, pooled_height, pooled_width, spatial_scale, rounding=None):
+    """GPU tensors in, ``(top_data f32, argmax8 u8)`` out."""
+    _check_inputs(data, rois)
+    N, H, W, C = data.shape
+    R = rois.shape[0]
+    mode = _ROUNDING[cfg.ROI_POOL_ROUNDING if rounding is None else rounding]
+    top = torch.empty((R, pooled_height, pooled_width, C), dtype=torch.float32, device=data.device)
+    arg8 = torch.empty((R, pooled_height, pooled_width, C), dtype=torch.uint8, device=data.device)
+    with torch.cuda.device(data.device), \
+            _lib.timed("roi_pool_forward", dict(N=N, H=H, W=W, C=C, R=R, argmax_bytes=1)):
+        _lib.check(_lib.lib().wssdl_roi_pool_forward_compact(
+            _lib.ptr(data), N, H, W, C, _lib.ptr(rois), R, int(pooled_height), int(pooled_width),
+            float(spatial_scale), mode, _lib.ptr(top), _lib.ptr(arg8), _lib.ptr(_overflow_flag(data.device)),
+            _lib.stream()), "wssdl_roi_pool_forward_compact")
+    return top, arg8
+
+
+def roi_pool_grad_compact(shape, rois, arg8, grad, pooled_height, pooled_width, spatial_scale,
+                          rounding=None):
+    N, H, W, C = shape
+    mode = _ROUNDING[cfg.ROI_POOL_ROUNDING if rounding is None else rounding]
+    out = torch.empty(shape, dtype=torch.float32, device=grad.device)
+    with torch.cuda.device(grad.device), \
+            _lib.timed("roi_pool_backward", dict(N=N, H=H, W=W, C=C, R=rois.shape[0], argmax_bytes=1)):
+        _lib.check(_lib.lib().wssdl_roi_pool_backward_compact(
+            _lib.ptr(grad), _lib.ptr(arg8), _lib.ptr(rois), rois.shape[0], N, H, W, C,
+            int(pooled_height), int(pooled_width), float(spatial_scale), mode, _lib.ptr(out),
+            _lib.stream()), "wssdl_roi_pool_backward_compact")
+    return out
+
+
+def expand_argmax(arg8, rois, shape, pooled_height, pooled_width, spatial_scale, rounding=None):
+    """1-byte codes -> the reference's i32 argmax (flat NHWC index inside the image, -1 empty)."""
+    N, H, W, C = shape
+    mode = _ROUNDING[cfg.ROI_POOL_ROUNDING if rounding is None else rounding]
+    out = torch.empty(tuple(arg8.shape), dtype=torch.int32, device=arg8.device)
+    with torch.cuda.device(arg8.device):
+        _lib.check(_lib.lib().wssdl_roi_argmax_expand(
+            _lib.ptr(arg8), _lib.ptr(rois), rois.shape[0], H, W, C, int(pooled_height),
+            int(pooled_width), float(spatial_scale), mode, _lib.ptr(out), _lib.stream()),
+            "wssdl_roi_argmax_expand")
+    return out
+
+
 class RoiPoolFunction(torch.autograd.Function):
     """autograd wiring of the pair above (roi_pooling_op_grad.py:24-44): the
-    gradient flows to the feature map only; rois get None."""
+    gradient flows to the feature map only; rois get None.  The second output is the arg-max
+    the backward will read: u8 codes on the compact path, the reference's i32 otherwise."""
 
     @staticmethod
     def forward(ctx, bottom_data, bottom_rois, pooled_height, pooled_width, spatial_scale,
                 rounding):
         data = bottom_data.contiguous()
         rois = bottom_rois.contiguous()
-        top, arg = roi_pool(data, rois, pooled_height, pooled_width, spatial_scale,
-                            rounding=rounding)
+        _check_inputs(data, rois)
+        rounding = cfg.ROI_POOL_ROUNDING if rounding is None else rounding     # fixed for the pair
+        ctx.compact = data.is_cuda and data.dtype == torch.float32 and rois.dtype == torch.float32 and \
+            compact_supported(data.shape[1], data.shape[2], data.shape[3], pooled_height, pooled_width)
+        if ctx.compact:
+            top, arg = roi_pool_compact(data, rois, pooled_height, pooled_width, spatial_scale, rounding)
+        else:
+            top, arg = roi_pool(data, rois, pooled_height, pooled_width, spatial_scale,
+                                rounding=rounding)
         ctx.save_for_backward(rois, arg)
-        ctx.geom = (tuple(data.shape), pooled_height, pooled_width, spatial_scale)
+        ctx.geom = (tuple(data.shape), pooled_height, pooled_width, spatial_scale, rounding)
         ctx.mark_non_differentiable(arg)
         return top, arg
 
     @staticmethod
     def backward(ctx, grad_top, _grad_arg):
         rois, arg = ctx.saved_tensors
-        shape, ph, pw, scale = ctx.geom
-        bottom_diff = roi_pool_grad(torch.empty(shape, device="meta"), rois, arg,
-                                    grad_top.contiguous(), ph, pw, scale)
+        shape, ph, pw, scale, rounding = ctx.geom
+        if ctx.compact:
+            bottom_diff = roi_pool_grad_compact(shape, rois, arg, grad_top.contiguous(), ph, pw, scale,
+                                                rounding)
+        else:
+            bottom_diff = roi_pool_grad(torch.empty(shape, device="meta"), rois, arg,
+                                        grad_top.contiguous(), ph, pw, scale)
         return bottom_diff, None, None, None, None, None
 
 
 def roi_pool_autograd(bottom_data, bottom_rois, pooled_height, pooled_width, spatial_scale,
-                      rounding=None):
-    """Differentiable roi_pool: ``(top_data, argmax)``."""
-    return RoiPoolFunction.apply(bottom_data, bottom_rois, pooled_height, pooled_width,
-                                 spatial_scale, rounding)
+                      rounding=None, return_argmax=True):
+    """Differentiable roi_pool: ``(top_data, argmax)``.  `argmax` is the reference's i32 tensor
+    (expanded from the 1-byte codes when the compact path ran); pass return_argmax=False -- as the
+    network layer does, which like network.py:206-210 keeps top_data only -- to skip that."""
+    top, arg = RoiPoolFunction.apply(bottom_data, bottom_rois, pooled_height, pooled_width,
+                                     spatial_scale, rounding)
+    if not return_argmax:
+        return top, None
+    if arg.dtype == torch.uint8:
+        arg = expand_argmax(arg, bottom_rois.contiguous(), tuple(bottom_data.shape), pooled_height,
+                            pooled_width, spatial_scale, rounding)
+    return top, arg
