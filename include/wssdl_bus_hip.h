@@ -248,10 +248,26 @@ WSSDL_API int wssdl_roi_pool_forward_compact(const float *bottom, int N, int H, 
                            const float *rois, int R, int pooled_h, int pooled_w, float spatial_scale,
                            int rounding, float *top, uint8_t *argmax8, int32_t *overflow,
                            wssdl_stream_t stream);
+/* Backward in two calls.  The lists that drive it depend on the RoIs and the shapes only, so
+ * wssdl_roi_pool_backward_prepare can run as soon as the RoIs exist (e.g. right behind the
+ * forward): per (image, tile) it builds the stream of candidate bins in the reference's
+ * summation order (roi, ph, pw) with the reference's in_roi / candidate-bin tests
+ * (roi_pooling_op_gpu.cu.cc:141-151,169-177) evaluated once, and sorts the tiles by work.
+ * It writes the plan it chose to *plan_host (a HOST int; -1 = not supported or no workspace:
+ * the backward then runs a kernel that filters the RoIs itself).  wssdl_roi_pool_backward_compact
+ * with that plan and the same workspace is then ONE kernel: one wave per (image, tile, 128
+ * channels), heaviest tiles first.  workspace_bytes = 0 when the pooled size is not supported.
+ * bottom_diff is bit-identical on every path. */
+WSSDL_API size_t wssdl_roi_pool_backward_workspace_bytes(int R, int N, int H, int W, int pooled_h,
+                            int pooled_w);
+WSSDL_API int wssdl_roi_pool_backward_prepare(const float *rois, int R, int N, int H, int W, int C,
+                            int pooled_h, int pooled_w, float spatial_scale, int rounding,
+                            void *workspace, size_t workspace_bytes, int32_t *plan_host,
+                            wssdl_stream_t stream);
 WSSDL_API int wssdl_roi_pool_backward_compact(const float *top_diff, const uint8_t *argmax8,
                             const float *rois, int R, int N, int H, int W, int C, int pooled_h,
                             int pooled_w, float spatial_scale, int rounding, float *bottom_diff,
-                            wssdl_stream_t stream);
+                            void *workspace, size_t workspace_bytes, int plan, wssdl_stream_t stream);
 WSSDL_API int wssdl_roi_argmax_expand(const uint8_t *argmax8, const float *rois, int R, int H, int W,
                             int C, int pooled_h, int pooled_w, float spatial_scale, int rounding,
                             int32_t *argmax, wssdl_stream_t stream);

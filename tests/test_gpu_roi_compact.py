@@ -59,17 +59,29 @@ def test_compact_pair_vs_oracle(torch_cuda, shape, mode):
     diff = rs.normal(size=et.shape).astype(np.float32)
     want = c_oracle.roi_pool_backward(diff, ea, rois, f.shape, 7, 7, 1.0 / 16)
     dt = torch.from_numpy(diff).cuda()
-    old = os.environ.get("WSSDL_ROI_BWDC_VARIANT")
+    old = {k: os.environ.get(k) for k in ("WSSDL_ROI_BWDC_VARIANT", "WSSDL_ROI_BWD_PLAN")}
     try:
-        for variant in ("0", "1", "2", "3", "4"):
+        # every plan of the list-driven walk (tile shape x records in flight) ...
+        for plan_id in range(6):
+            os.environ["WSSDL_ROI_BWD_PLAN"] = str(plan_id)
+            plan = op.roi_pool_grad_prepare(shape, rt, 7, 7, 1.0 / 16, rounding=mode)
+            assert plan.plan == plan_id
+            got = op.roi_pool_grad_compact(shape, rt, arg8, dt, 7, 7, 1.0 / 16, rounding=mode, plan=plan)
+            assert np.array_equal(got.cpu().numpy(), want), (shape, mode, "plan", plan_id)
+            got = op.roi_pool_grad_compact(shape, rt, arg8, 2 * dt, 7, 7, 1.0 / 16, rounding=mode, plan=plan)
+            assert np.array_equal(got.cpu().numpy(), 2 * want)            # a plan serves many backward calls
+        os.environ.pop("WSSDL_ROI_BWD_PLAN")
+        # ... and every shape of the fallback kernel that filters the RoIs itself (no workspace)
+        for variant in ("0", "1", "2", "3", "4", "5"):
             os.environ["WSSDL_ROI_BWDC_VARIANT"] = variant
-            got = op.roi_pool_grad_compact(shape, rt, arg8, dt, 7, 7, 1.0 / 16, rounding=mode)
-            assert np.array_equal(got.cpu().numpy(), want), (shape, mode, variant)
+            got = op.roi_pool_grad_compact(shape, rt, arg8, dt, 7, 7, 1.0 / 16, rounding=mode, use_workspace=False)
+            assert np.array_equal(got.cpu().numpy(), want), (shape, mode, "fallback", variant)
     finally:
-        if old is None:
-            os.environ.pop("WSSDL_ROI_BWDC_VARIANT", None)
-        else:
-            os.environ["WSSDL_ROI_BWDC_VARIANT"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def test_compact_other_pooled_sizes_and_unsupported_shapes(torch_cuda):

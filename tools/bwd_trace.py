@@ -34,7 +34,7 @@ def main():
     top, arg8 = roi_pool_compact(feat, rois, 7, 7, 1.0 / 16)
     diff = torch.randn_like(top)
     L = _lib.lib()
-    nblk = 1 << 16
+    nblk = 1 << 18
     trace = torch.zeros((nblk, 4), dtype=torch.int64, device="cuda")
     L.wssdl_debug_set_trace.argtypes = [ctypes.c_void_p]
     for _ in range(3):

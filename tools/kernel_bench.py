@@ -101,15 +101,23 @@ def main():
         out.append(dict(op="roi_pool_forward_compact", ms=ms, R=R, C=C, alg_bytes=byt, GBps=byt / ms / 1e6,
                         moved_bytes=N * H * W * C * 4 + R * 20 + R * 49 * C * 5))
         ref_g = roi_pool_grad(feat, rois, arg, diff, 7, 7, 1.0 / 16)
-        for variant in os.environ.get("KB_BWDC_VARIANTS", "0").split(","):
-            os.environ["WSSDL_ROI_BWDC_VARIANT"] = variant
-            g = roi_pool_grad_compact(tuple(feat.shape), rois, arg8, diff, 7, 7, 1.0 / 16)
-            assert os.environ.get("KB_NO_CHECK") or torch.equal(g, ref_g), variant
-            ms = timeit(lambda: roi_pool_grad_compact(tuple(feat.shape), rois, arg8, diff, 7, 7, 1.0 / 16), args.iters)
+        from wssdl_bus_amd.roi_pooling_layer.roi_pooling_op import roi_pool_grad_prepare
+        shape = tuple(feat.shape)
+        for plan_id in os.environ.get("KB_BWD_PLANS", "1").split(","):
+            os.environ["WSSDL_ROI_BWD_PLAN"] = plan_id
+            plan = roi_pool_grad_prepare(shape, rois, 7, 7, 1.0 / 16)
+            g = roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan)
+            assert os.environ.get("KB_NO_CHECK") or torch.equal(g, ref_g), plan_id
+            ms_p = timeit(lambda: roi_pool_grad_prepare(shape, rois, 7, 7, 1.0 / 16), args.iters, warmup=5)
+            ms = timeit(lambda: roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan), args.iters,
+                        warmup=5)
             byt = R * 49 * C * 8 + N * H * W * C * 4
-            out.append(dict(op="roi_pool_backward_compact[v%s]" % variant, ms=ms, R=R, C=C, alg_bytes=byt,
-                            GBps=byt / ms / 1e6))
-        os.environ.pop("WSSDL_ROI_BWDC_VARIANT", None)
+            out.append(dict(op="roi_pool_backward_compact[plan %s]" % plan_id, ms=ms, prepare_ms=ms_p, R=R, C=C,
+                            alg_bytes=byt, GBps=byt / ms / 1e6, GBps_with_prepare=byt / (ms + ms_p) / 1e6))
+        os.environ.pop("WSSDL_ROI_BWD_PLAN", None)
+        ms = timeit(lambda: roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, use_workspace=False),
+                    args.iters, warmup=5)
+        out.append(dict(op="roi_pool_backward_compact[no lists]", ms=ms, R=R, C=C, alg_bytes=byt, GBps=byt / ms / 1e6))
 
     # anchor targets
     gt = torch.zeros((N, 20, 5), device="cuda")

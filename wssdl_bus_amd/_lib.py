@@ -51,7 +51,10 @@ SYMBOLS = {
     "wssdl_roi_pool_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "wssdl_roi_pool_compact_supported": (_i, [_i, _i, _i, _i, _i]),
     "wssdl_roi_pool_forward_compact": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
-    "wssdl_roi_pool_backward_compact": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "wssdl_roi_pool_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "wssdl_roi_pool_backward_prepare": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp]),
+    "wssdl_roi_pool_backward_compact": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _i,
+                                             _vp]),
     "wssdl_roi_argmax_expand": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "wssdl_mil_select": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
 }

@@ -92,4 +92,12 @@ __device__ __forceinline__ void touch_axis(int t0, int t1, int rs, int re, float
 }
 
 
+// list-driven backward of the training path (roi_pool_walk.hip)
+bool walk_supported(int R, int N, int H, int W, int C, int PH, int PW);
+size_t walk_workspace_bytes(int R, int N, int H, int W, int PH, int PW);
+int walk_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, int PW, float scale, int rounding,
+                 void *workspace, size_t workspace_bytes, int *plan_out, hipStream_t st);
+int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH,
+                int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, hipStream_t st);
+
 }  // namespace wssdl

@@ -44,9 +44,11 @@ namespace wssdl {
 #define WSSDL_BWDC_TRACE 0
 #endif
 #if WSSDL_BWDC_TRACE
+extern unsigned long long *g_walk_trace;
 static unsigned long long *g_trace = nullptr;
 extern "C" __attribute__((visibility("default"))) void wssdl_debug_set_trace(void *p) {
     g_trace = static_cast<unsigned long long *>(p);
+    g_walk_trace = g_trace;
 }
 #define WSSDL_TRACE_PARAM , unsigned long long *__restrict__ trace
 #define WSSDL_TRACE_ARG , g_trace
@@ -541,27 +543,57 @@ extern "C" int wssdl_roi_argmax_expand(const uint8_t *argmax8, const float *rois
     return check_launch();
 }
 
+extern "C" size_t wssdl_roi_pool_backward_workspace_bytes(int R, int N, int H, int W, int pooled_h,
+                                                          int pooled_w) {
+    if (R < 0 || N < 1 || H < 1 || W < 1 || pooled_h < 1 || pooled_w < 1 || pooled_h > 8 || pooled_w > 8) return 0;
+    return walk_workspace_bytes(R, N, H, W, pooled_h, pooled_w);
+}
+
+extern "C" int wssdl_roi_pool_backward_prepare(const float *rois, int R, int N, int H, int W, int C,
+                                               int pooled_h, int pooled_w, float spatial_scale,
+                                               int rounding, void *workspace, size_t workspace_bytes,
+                                               int32_t *plan_host, wssdl_stream_t stream) {
+    if (!plan_host) return WSSDL_ERR_INVALID_ARGUMENT;
+    *plan_host = -1;
+    if (N < 1 || R < 0 || !compact_supported(H, W, C, pooled_h, pooled_w)) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (rounding != WSSDL_ROI_ROUND_CUDA && rounding != WSSDL_ROI_ROUND_CPU)
+        return WSSDL_ERR_INVALID_ARGUMENT;
+    if (!workspace || !walk_supported(R, N, H, W, C, pooled_h, pooled_w)) return WSSDL_OK;   // plan -1: fallback kernel
+    if (R > 0 && !rois) return WSSDL_ERR_INVALID_ARGUMENT;
+    int plan = -1;
+    const int rc = walk_prepare(rois, R, N, H, W, C, pooled_h, pooled_w, spatial_scale, rounding, workspace,
+                                workspace_bytes, &plan, as_stream(stream));
+    if (rc == WSSDL_OK) *plan_host = plan;
+    return rc;
+}
+
 extern "C" int wssdl_roi_pool_backward_compact(const float *top_diff, const uint8_t *argmax8,
                                                const float *rois, int R, int N, int H, int W, int C,
                                                int pooled_h, int pooled_w, float spatial_scale,
-                                               int rounding, float *bottom_diff,
-                                               wssdl_stream_t stream) {
+                                               int rounding, float *bottom_diff, void *workspace,
+                                               size_t workspace_bytes, int plan, wssdl_stream_t stream) {
     if (N < 0 || R < 0 || !compact_supported(H, W, C, pooled_h, pooled_w)) return WSSDL_ERR_INVALID_ARGUMENT;
     if (rounding != WSSDL_ROI_ROUND_CUDA && rounding != WSSDL_ROI_ROUND_CPU)
         return WSSDL_ERR_INVALID_ARGUMENT;
     if (N == 0) return WSSDL_OK;
     if (!bottom_diff || (R > 0 && (!top_diff || !argmax8 || !rois))) return WSSDL_ERR_INVALID_ARGUMENT;
     hipStream_t st = as_stream(stream);
+    if (plan >= 0) {          // lists prepared by wssdl_roi_pool_backward_prepare: the walk kernel alone
+        if (!workspace || !walk_supported(R, N, H, W, C, pooled_h, pooled_w)) return WSSDL_ERR_INVALID_ARGUMENT;
+        return launch_walk(top_diff, argmax8, R, N, H, W, C, pooled_h, pooled_w, bottom_diff, workspace,
+                           workspace_bytes, plan, st);
+    }
+    int variant = 0;
+    if (const char *e = getenv("WSSDL_ROI_BWDC_VARIANT")) variant = atoi(e);      // tuning: fallback kernel shapes
+    // fallback: tile-owner kernel with the RoI filter inside (no workspace; any pooled size)
     // channels per workgroup: 256 when that still yields enough workgroups to fill the chip
     int cg = C > 128 ? 256 : (C > 64 ? 128 : 64);
     const long long tiles = (long long)cdiv(H, 4) * cdiv(W, 8);       // counted in 4x8 tiles
     while (cg > 64 && (long long)N * cdiv(C, cg) * tiles < BWD_MIN_WORKGROUPS) cg >>= 1;
-    int variant = 0;
     if (const char *e = getenv("WSSDL_ROI_BWD_CG")) {       // tuning overrides
         const int v = atoi(e);
         if (v == 64 || v == 128 || v == 256) cg = v;
     }
-    if (const char *e = getenv("WSSDL_ROI_BWDC_VARIANT")) variant = atoi(e);
 #define WSSDL_BWDC(TH, TW, CGV, CHUNK, MAXB, MINB) \
     launch_bwd_c<TH, TW, CGV, CHUNK, MAXB, MINB>(top_diff, argmax8, rois, R, N, H, W, C, pooled_h, pooled_w, \
                                                  spatial_scale, rounding, bottom_diff, st)
@@ -571,7 +603,8 @@ extern "C" int wssdl_roi_pool_backward_compact(const float *top_diff, const uint
             case 2: return WSSDL_BWDC(4, 8, 256, 240, 8, 4);     // 4x8 tiles: fewer border re-reads, 4-5 wg / CU
             case 3: return WSSDL_BWDC(4, 8, 256, 240, 16, 4);
             case 4: return WSSDL_BWDC(4, 4, 256, 126, 12, 6);
-            default: return WSSDL_BWDC(4, 4, 256, 126, 8, 8);    // 8 workgroups / CU (20 KiB of LDS each)
+            case 5: return WSSDL_BWDC(4, 4, 256, 126, 8, 8);     // 8 workgroups / CU (20 KiB of LDS each)
+            default: return WSSDL_BWDC(4, 4, 256, 218, 8, 7);
         }
     }
     if (cg == 128) return WSSDL_BWDC(4, 8, 128, 128, 8, 1);

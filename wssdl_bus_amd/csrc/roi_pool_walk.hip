@@ -1,0 +1,539 @@
+// RoI-pool backward, training path (1-byte arg-max), list-driven: gfx950 (MI355X).
+//
+// Reference semantics: roi_pooling_op_gpu.cu.cc:114-190 == roi_pooling_op.cc:383-458 (per bottom
+// element, over the RoIs of its image that contain it and over its candidate bins, add top_diff
+// where the arg-max matches -- f32, in the order roi, ph, pw).  Results are bit-identical to that.
+//
+// What measurement of the tile-owner kernel (roi_pool_compact.hip, kept as the fallback) showed:
+//   * it is not bandwidth-bound: the walk without any load takes 0.5 ms, the loads without the
+//     walk 0.6 ms, the RoI filter every workgroup repeats 0.15 ms (R = 8512, C = 1024);
+//   * the busiest tiles (image centre of the 2000-RoI weak images) are serial chains of ~320
+//     (RoI, tile) records at ~3 us each -- load, wait for HBM, accumulate -- and take 80 % of the
+//     kernel's span, while half of the chip idles behind them.
+// So the structure here is:
+//   1. span     first / last RoI index of every image (one atomic pair per wave and image)
+//   2. fill     one workgroup per (image, tile): counts the tile's candidate bins, claims a
+//               region of the workspace (one atomic on a cursor) and writes the tile's SLOT
+//               STREAM in the reference's order (roi^, ph^, pw^): 8 bytes per candidate bin =
+//               element offset of the bin in top_diff / arg8 + the masks and window offsets that
+//               decode a code for this tile (the reference's in_roi / candidate-bin tests,
+//               evaluated once here)
+//   3. order    one workgroup: the tiles sorted by work, heaviest first
+//   4. walk     one WAVE per (image, tile, 128 channels), launched heaviest tiles first: a
+//               record = 8 slots (64 B) is fetched by 16 lanes and broadcast to scalar registers;
+//               the data of the next DEPTH-1 records is in flight while a record is accumulated
+//               (straight-line code: 8 slots, no per-slot branches, out-of-range offsets for the
+//               padding slots of a tile's last record); a lane owns TWO channels (one 2-byte +
+//               one 8-byte load per slot and lane); accumulators live in LDS (8.5 KiB per wave for
+//               4x4-cell tiles), branch-free (misses add 0.0 to a spare cell).  A lane is the
+//               only writer of its channels: the f32 additions run in exactly the reference's order.
+// The lists are shared by all channel groups, the walk needs no barrier at all, and no workgroup
+// repeats the RoI filter.
+#include "roi_pool.hip.h"
+
+#include <stdlib.h>
+
+namespace wssdl {
+
+#ifndef WSSDL_BWDC_TRACE
+#define WSSDL_BWDC_TRACE 0
+#endif
+
+constexpr unsigned ARG8_EMPTY_W = 0xffu;
+constexpr int WALK_SLOTS = 8;            // slots per record (64 B)
+constexpr int WALK_CH = 128;             // channels per wave (2 per lane)
+
+__device__ __forceinline__ int win_start_w(int p, float bin, int rs, int limit, int rounding) {
+    const float v = (float)p * bin;
+    const int s = (rounding == WSSDL_ROI_ROUND_CPU) ? (int)v : (int)floorf(v);
+    return min(max(s + rs, 0), limit);
+}
+
+struct WalkWs {
+    int *tile_slots;    // [items] candidate bins of each (image, tile)
+    int *tile_off;      // [items] first record of the tile's stream
+    int *order;         // [items] items sorted by tile_slots, heaviest first
+    int *img_span;      // [N][2]  (R - first RoI index, one-past-last RoI index) of each image (zeroed per call)
+    int *total;         // [4]     record cursor, error flags                                   (zeroed per call)
+    unsigned long long *slots;   // [cap_records * 8]
+};
+
+static size_t carve_walk(void *ws, int N, int tiles, long long cap_records, WalkWs *out) {
+    Carver c(ws);
+    WalkWs w;
+    const size_t items = (size_t)N * tiles;
+    w.img_span = c.take<int>((size_t)N * 2);
+    w.total = c.take<int>(4);
+    w.tile_slots = c.take<int>(items);
+    w.tile_off = c.take<int>(items);
+    w.order = c.take<int>(items);
+    w.slots = c.take<unsigned long long>((size_t)cap_records * WALK_SLOTS);
+    if (out) *out = w;
+    return c.off;
+}
+
+// upper bound of the records a call can need (every bin counted in every tile its window can reach)
+static long long walk_record_bound(int R, int N, int H, int W, int PH, int PW, int TH, int TW) {
+    const int win_h = cdiv(H + 1, PH) + 1, win_w = cdiv(W + 1, PW) + 1;
+    const long long per_bin = (long long)cdiv(win_h + TH - 1, TH) * cdiv(win_w + TW - 1, TW);
+    const long long slots = (long long)R * PH * PW * per_bin;
+    const long long tiles = (long long)N * cdiv(H, TH) * cdiv(W, TW);
+    return slots / WALK_SLOTS + tiles + 8;        // + one partly filled record per tile
+}
+
+// ---- 1. span: first / last RoI of every image ---------------------------------------------------
+__global__ __launch_bounds__(256) void walk_span_kernel(const float *__restrict__ rois, int R, int N,
+                                                        int *__restrict__ img_span) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int n = -1;
+    if (r < R) {
+        n = (int)rois[(size_t)r * 5];
+        if (n < 0 || n >= N) n = -1;
+    }
+    // RoIs arrive grouped by image almost always: one atomic pair per wave and image
+    unsigned long long todo = __ballot(n >= 0);
+    while (todo != 0ull) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int n0 = __builtin_amdgcn_readlane(n, leader);
+        const unsigned long long same = __ballot(n == n0);
+        if (lane == leader) {
+            const int r0 = r - lane;
+            atomicMax(&img_span[n0 * 2], R - (r0 + __ffsll((long long)same) - 1));
+            atomicMax(&img_span[n0 * 2 + 1], r0 + 64 - __clzll((long long)same));
+        }
+        todo &= ~same;
+    }
+}
+
+// block-wide exclusive scan of one int per thread (BLOCK threads); returns the block total via *total
+template <int BLOCK>
+__device__ __forceinline__ int block_exclusive_scan(int v, int *wave_sums /* [BLOCK/64] LDS */, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    __syncthreads();                       // wave_sums may still be read from the previous call
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+        const int s = wave_sums[w];
+        before += (w < wave) ? s : 0;
+        all += s;
+    }
+    *total = all;
+    return before + incl - v;
+}
+
+// ---- 2. fill: the slot stream of one (image, tile), in (roi, ph, pw) order ---------------------
+//   slot = w0 | w1 << 32:  w0 = element offset of the bin (r * PH*PW*C + bin * C),
+//   w1 = rm | cm << 8 | (hs & 31) << 16 | (ws & 31) << 21 where, for this tile,
+//     rm : 8 bits, bit j <=> tile row h0+j lies in the RoI and the bin's row is one of its candidate
+//          rows (roi_pooling_op_gpu.cu.cc:141-151,169-177); cm: 8 bits likewise for columns;
+//     hs : (clipped window start of the bin's row) - h0, clamped to [-16, 15]; ws likewise.
+//   Padding slots of the last record: w0 = total elements (out of range: loads return 0), w1 = 0.
+template <int TH, int TW>
+struct TileTouch {
+    int nb, ph0, phn, pw0, pwn;
+    unsigned long long rm, cm;
+    RoiGeom g;
+};
+
+template <int TH, int TW>
+__device__ __forceinline__ TileTouch<TH, TW> touch_tile(const float *__restrict__ rois, int r, bool in_range, int n,
+                                                       int h0, int h1, int w0, int w1, int PH, int PW, float scale) {
+    TileTouch<TH, TW> t;
+    t.nb = 0;  t.ph0 = t.phn = t.pw0 = t.pwn = 0;  t.rm = t.cm = 0ull;
+    if (in_range) {
+        t.g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);
+        if (t.g.batch == n && t.g.sw <= w1 && t.g.ew >= w0 && t.g.sh <= h1 && t.g.eh >= h0) {
+            touch_axis<TH, 8>(h0, h1, t.g.sh, t.g.eh, t.g.bin_h, PH, t.ph0, t.phn, t.rm);
+            touch_axis<TW, 8>(w0, w1, t.g.sw, t.g.ew, t.g.bin_w, PW, t.pw0, t.pwn, t.cm);
+            if (t.phn > 0 && t.pwn > 0) t.nb = t.phn * t.pwn;
+        }
+    }
+    return t;
+}
+
+constexpr int FILL_BLOCK = 1024;
+
+template <int TH, int TW>
+__global__ __launch_bounds__(FILL_BLOCK) void walk_fill_kernel(
+    const float *__restrict__ rois, int N, int H, int W, int C, int PH, int PW, float scale, int rounding,
+    int R, int tiles_h, int tiles_w, const int *__restrict__ img_span, int *__restrict__ tile_off,
+    int *__restrict__ tile_slots, unsigned long long *__restrict__ slots, long long cap_records,
+    unsigned total_elems, int *__restrict__ total) {
+    __shared__ int wave_sums[FILL_BLOCK / 64];
+    __shared__ int s_first;
+    const int tiles = tiles_h * tiles_w;
+    const int item = blockIdx.x;
+    const int n = item / tiles, tile = item - n * tiles;
+    const int ty = tile / tiles_w, tx = tile - ty * tiles_w;
+    const int h0 = ty * TH, w0 = tx * TW;
+    const int h1 = min(h0 + TH, H) - 1, w1 = min(w0 + TW, W) - 1;
+    const int lo = R - img_span[n * 2], hi = img_span[n * 2 + 1];       // (R, 0) when the image has no RoI
+    // pass 1: how many candidate bins -> claim a region of the slot array
+    int mine = 0;
+    for (int base = lo; base < hi; base += FILL_BLOCK) {
+        const int r = base + (int)threadIdx.x;
+        mine += touch_tile<TH, TW>(rois, r, r < hi, n, h0, h1, w0, w1, PH, PW, scale).nb;
+    }
+    int nslots;
+    block_exclusive_scan<FILL_BLOCK>(mine, wave_sums, &nslots);
+    const int nrec = (nslots + WALK_SLOTS - 1) / WALK_SLOTS;
+    if (threadIdx.x == 0) {
+        const int first_rec = atomicAdd(&total[0], nrec);
+        s_first = first_rec;
+        tile_off[item] = first_rec;
+        tile_slots[item] = nslots;
+        if ((long long)first_rec + nrec > cap_records) atomicOr(&total[1], 1);   // cannot happen: cap is a bound
+    }
+    __syncthreads();
+    const long long first = (long long)s_first * WALK_SLOTS;
+    const long long cap = cap_records * WALK_SLOTS;
+    // pass 2: write the stream
+    int run = 0;
+    for (int base = lo; base < hi; base += FILL_BLOCK) {
+        const int r = base + (int)threadIdx.x;
+        const TileTouch<TH, TW> t = touch_tile<TH, TW>(rois, r, r < hi, n, h0, h1, w0, w1, PH, PW, scale);
+        int tot;
+        const int ex = block_exclusive_scan<FILL_BLOCK>(t.nb, wave_sums, &tot);
+        if (t.nb > 0) {
+            long long pos = first + run + ex;
+            const unsigned ebase = (unsigned)r * (unsigned)(PH * PW * C);
+            for (int q = 0; q < t.phn; ++q) {
+                const unsigned rmq = (unsigned)(t.rm >> (8 * q)) & 0xffu;
+                const int hs = min(max(win_start_w(t.ph0 + q, t.g.bin_h, t.g.sh, H, rounding) - h0, -16), 15);
+                for (int j = 0; j < t.pwn; ++j, ++pos) {
+                    const unsigned cmj = (unsigned)(t.cm >> (8 * j)) & 0xffu;
+                    const int ws = min(max(win_start_w(t.pw0 + j, t.g.bin_w, t.g.sw, W, rounding) - w0, -16), 15);
+                    const unsigned wlo = ebase + (unsigned)(((t.ph0 + q) * PW + t.pw0 + j) * C);
+                    const unsigned whi = rmq | (cmj << 8) | (((unsigned)hs & 31u) << 16) | (((unsigned)ws & 31u) << 21);
+                    if (pos < cap) slots[pos] = (unsigned long long)wlo | ((unsigned long long)whi << 32);
+                }
+            }
+        }
+        run += tot;
+    }
+    for (int i = nslots + (int)threadIdx.x; i < nrec * WALK_SLOTS; i += FILL_BLOCK)      // pad the last record
+        if (first + i < cap) slots[first + i] = (unsigned long long)total_elems;
+}
+
+// ---- 3. launch order: tiles sorted by work, heaviest first ---------------------------------------
+__global__ __launch_bounds__(1024) void walk_order_kernel(const int *__restrict__ tile_slots, int items,
+                                                          int *__restrict__ order) {
+    __shared__ int wave_sums[16];
+    __shared__ int hist[1024];
+    __shared__ int s_max;
+    const int t = threadIdx.x;
+    if (t == 0) s_max = 0;
+    hist[t] = 0;
+    __syncthreads();
+    int mx = 0;
+    for (int i = t; i < items; i += 1024) mx = max(mx, tile_slots[i]);
+    atomicMax(&s_max, mx);
+    __syncthreads();
+    // bucket sort (the order only decides when a tile is launched)
+    const long long top = max(s_max, 1);
+    for (int i = t; i < items; i += 1024)
+        atomicAdd(&hist[1023 - (int)((long long)tile_slots[i] * 1023 / top)], 1);
+    __syncthreads();
+    {
+        const int v = hist[t];
+        int tot;
+        const int ex = block_exclusive_scan<1024>(v, wave_sums, &tot);
+        __syncthreads();
+        hist[t] = ex;
+    }
+    __syncthreads();
+    for (int i = t; i < items; i += 1024) {
+        const int pos = atomicAdd(&hist[1023 - (int)((long long)tile_slots[i] * 1023 / top)], 1);
+        order[pos] = i;
+    }
+}
+
+// ---- 4. walk ----------------------------------------------------------------------------------
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+struct SlotRec {                 // one record = 8 slots, wave-uniform (scalar registers)
+    unsigned lo[WALK_SLOTS];     // element offset of the bin
+    unsigned hi[WALK_SLOTS];     // masks and window offsets
+};
+
+struct SlotData {                // what a lane holds of one record
+    unsigned a[WALK_SLOTS];      // two 1-byte codes
+    float2v td[WALK_SLOTS];      // two top_diff values
+};
+
+// a record is fetched by lanes 0..15 (one dword each) and broadcast with v_readlane: that keeps the
+// fetch in the vector-memory queue, where the compiler can count it (a scalar load would be waited
+// for at the next LDS access, i.e. immediately)
+__device__ __forceinline__ unsigned fetch_rec(const unsigned *__restrict__ recs, int i, int nrec, int lane) {
+    const int k = min(i, max(nrec - 1, 0));
+    return recs[(size_t)k * 16 + (lane & 15)];
+}
+
+__device__ __forceinline__ SlotRec spread_rec(unsigned v, bool valid, unsigned total_elems) {
+    SlotRec r;
+#pragma unroll
+    for (int s = 0; s < WALK_SLOTS; ++s) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)v, 2 * s);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)v, 2 * s + 1);
+        r.lo[s] = valid ? lo : total_elems;
+        r.hi[s] = valid ? hi : 0u;
+    }
+    return r;
+}
+
+__device__ __forceinline__ void issue_rec(SlotData &d, const SlotRec &r, __amdgpu_buffer_rsrc_t ra,
+                                          __amdgpu_buffer_rsrc_t rt, int voff8, int voff) {
+#pragma unroll
+    for (int s = 0; s < WALK_SLOTS; ++s) {
+        d.a[s] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(ra, voff8, (int)r.lo[s], 0);
+        d.td[s] = __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(rt, voff, (int)(r.lo[s] << 2), 0));
+    }
+}
+
+template <int TH, int TW>
+__device__ __forceinline__ void process_rec(const SlotData &d, const SlotRec &r, float *acc, int lane, bool lane_ok) {
+    constexpr int DUMMY = TH * TW;
+#pragma unroll
+    for (int s = 0; s < WALK_SLOTS; ++s) {
+        const unsigned w = r.hi[s];
+        const unsigned rm = w & 0xffu, cm = (w >> 8) & 0xffu;
+        const int hs = ((int)(w << 11)) >> 27, ws = ((int)(w << 6)) >> 27;     // sign-extended 5-bit fields
+        const unsigned a = d.a[s];
+        int idx[2];
+        float val[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const unsigned code = (a >> (8 * p)) & 0xffu;
+            const int th = hs + (int)(code >> 4), tw = ws + (int)(code & 15u);
+            // tile, in_roi and candidate-bin tests: the masks have no bits where a cell outside the
+            // tile would index (th, tw in [-16, 30]; shifts use the low 5 bits)
+            const unsigned bits = (rm >> (th & 31)) & (cm >> (tw & 31)) & 1u;
+            const bool ok = (bits != 0u) & (code != ARG8_EMPTY_W) & lane_ok;
+            const int cell = ok ? th * TW + tw : DUMMY;
+            idx[p] = (cell * 2 + p) * 64 + lane;
+            val[p] = ok ? d.td[s][p] : 0.0f;
+        }
+        const float v0 = acc[idx[0]], v1 = acc[idx[1]];
+        acc[idx[0]] = v0 + val[0];
+        acc[idx[1]] = v1 + val[1];
+    }
+}
+
+#if WSSDL_BWDC_TRACE
+unsigned long long *g_walk_trace = nullptr;
+#define WSSDL_WALK_TRACE_PARAM , unsigned long long *__restrict__ trace
+#define WSSDL_WALK_TRACE_ARG , g_walk_trace
+#else
+#define WSSDL_WALK_TRACE_PARAM
+#define WSSDL_WALK_TRACE_ARG
+#endif
+
+template <int TH, int TW, int DEPTH, int MINW>
+__global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
+    const float *__restrict__ top_diff, const unsigned char *__restrict__ arg8,
+    const unsigned *__restrict__ slots, const int *__restrict__ tile_off, const int *__restrict__ tile_slots,
+    const int *__restrict__ order, int items, int tiles_w, int tiles, int G, int H, int W, int C,
+    unsigned total_elems, float *__restrict__ bottom_diff WSSDL_WALK_TRACE_PARAM) {
+    static_assert(TH <= 8 && TW <= 8 && DEPTH >= 2 && DEPTH <= 4, "8-bit masks; 2..4 records in flight");
+    __shared__ float acc[(TH * TW + 1) * 2 * 64];
+#if WSSDL_BWDC_TRACE
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
+    // blockIdx -> (position k in the launch order, channel group g).  Workgroups are dealt
+    // round-robin over the 8 XCDs (blockIdx % 8; observed, speed only): with 8 or more channel
+    // groups every XCD serves its own groups for all tiles, so the border bins neighbouring tiles
+    // re-read meet in one L2.
+    const int b = blockIdx.x;
+    int k, g;
+    if ((G & 7) == 0) {
+        const int per = G >> 3, q = b >> 3;
+        g = (b & 7) + 8 * (q % per);
+        k = q / per;
+    } else if (G < 8 && (8 % G) == 0) {
+        const int share = 8 / G, x = b & 7;
+        g = x % G;
+        k = (b >> 3) * share + x / G;
+    } else {
+        g = b % G;
+        k = b / G;
+    }
+    if (k >= items) return;
+    const int item = order[k];
+    const int n = item / tiles, tile = item - n * tiles;
+    const int ty = tile / tiles_w, tx = tile - ty * tiles_w;
+    const int h0 = ty * TH, w0 = tx * TW;
+    const int lane = threadIdx.x;
+    const int c0 = g * WALK_CH + 2 * lane;
+    const bool lane_ok = c0 < C;
+    const int cl = lane_ok ? c0 : 0;
+
+#pragma unroll
+    for (int i = 0; i < (TH * TW + 1) * 2; ++i) acc[i * 64 + lane] = 0.0f;
+
+    const int nrec = (tile_slots[item] + WALK_SLOTS - 1) / WALK_SLOTS;
+    const unsigned *rp = slots + (size_t)tile_off[item] * 16;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(arg8), 0, (int)total_elems, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(top_diff), 0, (int)(total_elems << 2), 0x00020000);
+    const int voff8 = cl, voff = cl * 4;
+
+    // DEPTH records in flight: while record i is accumulated the data of records i+1 .. i+DEPTH-1
+    // and the descriptor of record i+DEPTH travel.  r[j] describes the data in d[j].
+    SlotRec r[DEPTH];
+    SlotData d[DEPTH];
+#pragma unroll
+    for (int j = 0; j < DEPTH - 1; ++j) {
+        r[j] = spread_rec(fetch_rec(rp, j, nrec, lane), j < nrec, total_elems);
+        issue_rec(d[j], r[j], ra, rt, voff8, voff);
+    }
+    unsigned pending = fetch_rec(rp, DEPTH - 1, nrec, lane);
+    for (int i = 0; i < nrec; i += DEPTH) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            constexpr int dummy = 0;  (void)dummy;
+            const int x = (j + DEPTH - 1) % DEPTH;
+            const unsigned next = fetch_rec(rp, i + j + DEPTH, nrec, lane);
+            r[x] = spread_rec(pending, i + j + DEPTH - 1 < nrec, total_elems);
+            issue_rec(d[x], r[x], ra, rt, voff8, voff);
+            process_rec<TH, TW>(d[j], r[j], acc, lane, lane_ok);
+            pending = next;
+        }
+    }
+
+    if (lane_ok) {
+        float *img = bottom_diff + (size_t)n * H * W * C;
+#pragma unroll
+        for (int i = 0; i < TH * TW; ++i) {
+            const int h = h0 + i / TW, w = w0 + i % TW;
+            if (h < H && w < W) {
+                float2v o;
+                o.x = acc[(i * 2) * 64 + lane];
+                o.y = acc[(i * 2 + 1) * 64 + lane];
+                *reinterpret_cast<float2v *>(img + ((size_t)h * W + w) * C + c0) = o;
+            }
+        }
+    }
+#if WSSDL_BWDC_TRACE
+    if (trace && lane == 0) {
+        unsigned long long *t = trace + (size_t)blockIdx.x * 4;
+        t[0] = t_start;  t[1] = __builtin_amdgcn_s_memrealtime();  t[2] = (unsigned long long)nrec;
+        t[3] = (unsigned long long)tile_slots[item];
+    }
+#endif
+}
+
+// A plan = tile shape, records in flight and the waves per SIMD the launch bounds ask for.
+// WSSDL_ROI_BWD_PLAN (tuning) overrides the default.
+constexpr int WALK_PLANS = 6;
+constexpr int WALK_DEFAULT_PLAN = 1;
+
+static int walk_plan_from_env() {
+    if (const char *e = getenv("WSSDL_ROI_BWD_PLAN")) {
+        const int v = atoi(e);
+        if (v >= 0 && v < WALK_PLANS) return v;
+    }
+    return WALK_DEFAULT_PLAN;
+}
+
+static void plan_shape(int plan, int *th, int *tw) {
+    static const int shapes[WALK_PLANS][2] = {{4, 4}, {4, 8}, {8, 8}, {4, 8}, {8, 8}, {4, 4}};
+    *th = shapes[plan][0];
+    *tw = shapes[plan][1];
+}
+
+bool walk_supported(int R, int N, int H, int W, int C, int PH, int PW) {
+    if (PH > 8 || PW > 8 || (C & 1)) return false;
+    const long long elems = (long long)R * PH * PW * C;
+    return elems * 4 < 0xffffffffLL && (long long)N * H * W * C < 0x7fffffffLL;
+}
+
+size_t walk_workspace_bytes(int R, int N, int H, int W, int PH, int PW) {
+    // sized for the smallest tiles (most records), so that every plan fits
+    const int tiles = cdiv(H, 4) * cdiv(W, 4);
+    return carve_walk(nullptr, N, tiles, walk_record_bound(R, N, H, W, PH, PW, 4, 4), nullptr);
+}
+
+template <int TH, int TW>
+static int prepare_t(const float *rois, int R, int N, int H, int W, int C, int PH, int PW, float scale,
+                     int rounding, void *workspace, size_t workspace_bytes, hipStream_t st) {
+    const int tiles_h = cdiv(H, TH), tiles_w = cdiv(W, TW), tiles = tiles_h * tiles_w;
+    const int items = N * tiles;
+    const long long cap = walk_record_bound(R, N, H, W, PH, PW, TH, TW);
+    WalkWs ws;
+    if (carve_walk(workspace, N, tiles, cap, &ws) > workspace_bytes) return WSSDL_ERR_WORKSPACE;
+    const unsigned total_elems = (unsigned)((long long)R * PH * PW * C);
+    // img_span, total = 0: one contiguous region at the head of the workspace
+    hipError_t e = hipMemsetAsync(ws.img_span, 0, (char *)ws.tile_slots - (char *)ws.img_span, st);
+    if (e != hipSuccess) { set_last_error(e);  return WSSDL_ERR_LAUNCH; }
+    if (R > 0)
+        hipLaunchKernelGGL(walk_span_kernel, dim3(cdiv(R, 256)), dim3(256), 0, st, rois, R, N, ws.img_span);
+    hipLaunchKernelGGL((walk_fill_kernel<TH, TW>), dim3(items), dim3(FILL_BLOCK), 0, st, rois, N, H, W, C, PH, PW,
+                       scale, rounding, R, tiles_h, tiles_w, ws.img_span, ws.tile_off, ws.tile_slots, ws.slots, cap,
+                       total_elems, ws.total);
+    hipLaunchKernelGGL(walk_order_kernel, dim3(1), dim3(1024), 0, st, ws.tile_slots, items, ws.order);
+    return check_launch();
+}
+
+int walk_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, int PW, float scale, int rounding,
+                 void *workspace, size_t workspace_bytes, int *plan_out, hipStream_t st) {
+    const int plan = walk_plan_from_env();
+    int th, tw;
+    plan_shape(plan, &th, &tw);
+    int rc;
+    if (th == 4 && tw == 4) rc = prepare_t<4, 4>(rois, R, N, H, W, C, PH, PW, scale, rounding, workspace, workspace_bytes, st);
+    else if (th == 4) rc = prepare_t<4, 8>(rois, R, N, H, W, C, PH, PW, scale, rounding, workspace, workspace_bytes, st);
+    else rc = prepare_t<8, 8>(rois, R, N, H, W, C, PH, PW, scale, rounding, workspace, workspace_bytes, st);
+    if (rc == WSSDL_OK && plan_out) *plan_out = plan;
+    return rc;
+}
+
+template <int TH, int TW, int DEPTH, int MINW>
+static int launch_walk_t(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C,
+                         int PH, int PW, float *bottom_diff, void *workspace, size_t workspace_bytes,
+                         hipStream_t st) {
+    const int tiles_h = cdiv(H, TH), tiles_w = cdiv(W, TW), tiles = tiles_h * tiles_w;
+    const int items = N * tiles;
+    WalkWs ws;
+    if (carve_walk(workspace, N, tiles, walk_record_bound(R, N, H, W, PH, PW, TH, TW), &ws) > workspace_bytes)
+        return WSSDL_ERR_WORKSPACE;
+    const unsigned total_elems = (unsigned)((long long)R * PH * PW * C);
+    const int G = cdiv(C, WALK_CH);
+    long long blocks;
+    if ((G & 7) == 0) blocks = (long long)items * G;
+    else if (G < 8 && (8 % G) == 0) blocks = 8LL * cdiv(items, 8 / G);
+    else blocks = (long long)items * G;
+    if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<TH, TW, DEPTH, MINW>), dim3((unsigned)blocks), dim3(64), 0, st,
+                       top_diff, arg8, reinterpret_cast<const unsigned *>(ws.slots), ws.tile_off, ws.tile_slots,
+                       ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff WSSDL_WALK_TRACE_ARG);
+    return check_launch();
+}
+
+int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH,
+                int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, hipStream_t st) {
+#define WSSDL_WALK(TH, TW, DEPTH, MINW) \
+    launch_walk_t<TH, TW, DEPTH, MINW>(top_diff, arg8, R, N, H, W, C, PH, PW, bottom_diff, workspace, \
+                                       workspace_bytes, st)
+    switch (plan) {
+        case 0: return WSSDL_WALK(4, 4, 2, 5);
+        case 1: return WSSDL_WALK(4, 8, 2, 2);
+        case 2: return WSSDL_WALK(8, 8, 3, 1);
+        case 3: return WSSDL_WALK(4, 8, 3, 2);
+        case 4: return WSSDL_WALK(8, 8, 4, 1);
+        case 5: return WSSDL_WALK(4, 4, 3, 4);
+        default: return WSSDL_ERR_INVALID_ARGUMENT;
+    }
+#undef WSSDL_WALK
+}
+
+}  // namespace wssdl

@@ -9,6 +9,8 @@ roi_pooling_op_grad.py:24-44 (gradient w.r.t. the feature map only).
 Layouts are the op's: bottom_data [N,H,W,C] f32 (NHWC), bottom_rois [R,5] f32,
 top_data / argmax [R,PH,PW,C].
 """
+import ctypes
+
 import torch
 
 from .. import _lib
@@ -124,17 +126,53 @@ def roi_pool_compact(data, rois, pooled_height, pooled_width, spatial_scale, rou
     return top, arg8
 
 
+class BackwardPlan(object):
+    """What wssdl_roi_pool_backward_prepare left behind: the workspace holding the per-tile lists
+    and the plan id the walk kernel must be launched with (-1: no lists, the backward filters
+    the RoIs itself)."""
+
+    def __init__(self, workspace, nbytes, plan):
+        self.workspace, self.nbytes, self.plan = workspace, nbytes, plan
+
+
+def roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scale, rounding=None):
+    """Build the lists that drive the compact backward.  They depend on the RoIs and the shapes
+    only, so the autograd pair does this right behind the forward (off the backward's path)."""
+    N, H, W, C = shape
+    mode = _ROUNDING[cfg.ROI_POOL_ROUNDING if rounding is None else rounding]
+    L = _lib.lib()
+    R = rois.shape[0]
+    plan = ctypes.c_int32(-1)
+    with torch.cuda.device(rois.device):
+        nws = L.wssdl_roi_pool_backward_workspace_bytes(R, N, H, W, int(pooled_height), int(pooled_width))
+        ws = torch.empty((nws,), dtype=torch.uint8, device=rois.device) if nws else None
+        with _lib.timed("roi_pool_backward_prepare", dict(N=N, H=H, W=W, C=C, R=R)):
+            _lib.check(L.wssdl_roi_pool_backward_prepare(
+                _lib.ptr(rois), R, N, H, W, C, int(pooled_height), int(pooled_width), float(spatial_scale),
+                mode, _lib.ptr(ws), nws, ctypes.byref(plan), _lib.stream()), "wssdl_roi_pool_backward_prepare")
+    return BackwardPlan(ws, nws, int(plan.value))
+
+
 def roi_pool_grad_compact(shape, rois, arg8, grad, pooled_height, pooled_width, spatial_scale,
-                          rounding=None):
+                          rounding=None, use_workspace=True, plan=None):
+    """bottom_diff from the 1-byte arg-max.  `plan` = what roi_pool_grad_prepare returned for these
+    RoIs (prepared here when None and use_workspace)."""
     N, H, W, C = shape
     mode = _ROUNDING[cfg.ROI_POOL_ROUNDING if rounding is None else rounding]
     out = torch.empty(shape, dtype=torch.float32, device=grad.device)
-    with torch.cuda.device(grad.device), \
-            _lib.timed("roi_pool_backward", dict(N=N, H=H, W=W, C=C, R=rois.shape[0], argmax_bytes=1)):
-        _lib.check(_lib.lib().wssdl_roi_pool_backward_compact(
-            _lib.ptr(grad), _lib.ptr(arg8), _lib.ptr(rois), rois.shape[0], N, H, W, C,
-            int(pooled_height), int(pooled_width), float(spatial_scale), mode, _lib.ptr(out),
-            _lib.stream()), "wssdl_roi_pool_backward_compact")
+    L = _lib.lib()
+    R = rois.shape[0]
+    if plan is None and use_workspace:
+        plan = roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scale, rounding)
+    if plan is None or plan.plan < 0:
+        plan = BackwardPlan(None, 0, -1)
+    with torch.cuda.device(grad.device):
+        with _lib.timed("roi_pool_backward", dict(N=N, H=H, W=W, C=C, R=R, argmax_bytes=1, plan=plan.plan)):
+            _lib.check(L.wssdl_roi_pool_backward_compact(
+                _lib.ptr(grad), _lib.ptr(arg8), _lib.ptr(rois), R, N, H, W, C,
+                int(pooled_height), int(pooled_width), float(spatial_scale), mode, _lib.ptr(out),
+                _lib.ptr(plan.workspace), plan.nbytes, plan.plan, _lib.stream()),
+                "wssdl_roi_pool_backward_compact")
     return out
 
 
@@ -165,8 +203,13 @@ class RoiPoolFunction(torch.autograd.Function):
         rounding = cfg.ROI_POOL_ROUNDING if rounding is None else rounding     # fixed for the pair
         ctx.compact = data.is_cuda and data.dtype == torch.float32 and rois.dtype == torch.float32 and \
             compact_supported(data.shape[1], data.shape[2], data.shape[3], pooled_height, pooled_width)
+        ctx.plan = None
         if ctx.compact:
             top, arg = roi_pool_compact(data, rois, pooled_height, pooled_width, spatial_scale, rounding)
+            if data.requires_grad or bottom_data.requires_grad:
+                # the backward's lists depend on the RoIs only: build them now, behind the forward
+                ctx.plan = roi_pool_grad_prepare(tuple(data.shape), rois, pooled_height, pooled_width,
+                                                 spatial_scale, rounding)
         else:
             top, arg = roi_pool(data, rois, pooled_height, pooled_width, spatial_scale,
                                 rounding=rounding)
@@ -181,7 +224,7 @@ class RoiPoolFunction(torch.autograd.Function):
         shape, ph, pw, scale, rounding = ctx.geom
         if ctx.compact:
             bottom_diff = roi_pool_grad_compact(shape, rois, arg, grad_top.contiguous(), ph, pw, scale,
-                                                rounding)
+                                                rounding, plan=ctx.plan)
         else:
             bottom_diff = roi_pool_grad(torch.empty(shape, device="meta"), rois, arg,
                                         grad_top.contiguous(), ph, pw, scale)
