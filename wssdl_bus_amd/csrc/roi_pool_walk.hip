@@ -12,13 +12,15 @@
 //     kernel's span, while half of the chip idles behind them.
 // So the structure here is:
 //   1. span     first / last RoI index of every image (one atomic pair per wave and image)
-//   2. fill     one workgroup per (image, tile): counts the tile's candidate bins, claims a
-//               region of the workspace (one atomic on a cursor) and writes the tile's SLOT
-//               STREAM in the reference's order (roi^, ph^, pw^): 8 bytes per candidate bin =
-//               element offset of the bin in top_diff / arg8 + the masks and window offsets that
-//               decode a code for this tile (the reference's in_roi / candidate-bin tests,
-//               evaluated once here)
-//   3. order    one workgroup: the tiles sorted by work, heaviest first
+//   2. axes     one lane per (RoI, tile row) / (RoI, tile column): the reference's in_roi and
+//               candidate-bin tests and the forward's window starts, as 16-byte table entries
+//      count    one workgroup per (image, tile): its candidate bins
+//      order    one workgroup: offsets (prefix sum) and the tiles sorted by work, heaviest first
+//               (a single cursor claimed with one atomic per tile serialised: 65 us for 1280 tiles)
+//   3. fill     one workgroup per (image, tile): the tile's SLOT STREAM in the reference's order
+//               (roi^, ph^, pw^): 8 bytes per candidate bin = element offset of the bin in
+//               top_diff / arg8 + the masks and window offsets that decode a code for this tile
+//               (the reference's in_roi / candidate-bin tests, evaluated once here)
 //   4. walk     one WAVE per (image, tile, 128 channels), launched heaviest tiles first: a
 //               record = 8 slots (64 B) is fetched by 16 lanes and broadcast to scalar registers;
 //               the data of the next DEPTH-1 records is in flight while a record is accumulated
@@ -54,19 +56,24 @@ struct WalkWs {
     int *tile_off;      // [items] first record of the tile's stream
     int *order;         // [items] items sorted by tile_slots, heaviest first
     int *img_span;      // [N][2]  (R - first RoI index, one-past-last RoI index) of each image (zeroed per call)
-    int *total;         // [4]     record cursor, error flags                                   (zeroed per call)
+    int *total;         // [4]     records in use, error flags                                  (zeroed per call)
+    unsigned long long *rowtab;  // [R][tiles_h][2]  AxisEntry of every (RoI, tile row)
+    unsigned long long *coltab;  // [R][tiles_w][2]  ... (RoI, tile column)
     unsigned long long *slots;   // [cap_records * 8]
 };
 
-static size_t carve_walk(void *ws, int N, int tiles, long long cap_records, WalkWs *out) {
+static size_t carve_walk(void *ws, int R, int N, int tiles_h, int tiles_w, long long cap_records, WalkWs *out) {
     Carver c(ws);
     WalkWs w;
+    const int tiles = tiles_h * tiles_w;
     const size_t items = (size_t)N * tiles;
     w.img_span = c.take<int>((size_t)N * 2);
     w.total = c.take<int>(4);
     w.tile_slots = c.take<int>(items);
     w.tile_off = c.take<int>(items);
     w.order = c.take<int>(items);
+    w.rowtab = c.take<unsigned long long>((size_t)R * tiles_h * 2);
+    w.coltab = c.take<unsigned long long>((size_t)R * tiles_w * 2);
     w.slots = c.take<unsigned long long>((size_t)cap_records * WALK_SLOTS);
     if (out) *out = w;
     return c.off;
@@ -80,6 +87,8 @@ static long long walk_record_bound(int R, int N, int H, int W, int PH, int PW, i
     const long long tiles = (long long)N * cdiv(H, TH) * cdiv(W, TW);
     return slots / WALK_SLOTS + tiles + 8;        // + one partly filled record per tile
 }
+
+constexpr int FILL_BLOCK = 1024;
 
 // ---- 1. span: first / last RoI of every image ---------------------------------------------------
 __global__ __launch_bounds__(256) void walk_span_kernel(const float *__restrict__ rois, int R, int N,
@@ -137,83 +146,130 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *wave_sums /* [BL
 //          rows (roi_pooling_op_gpu.cu.cc:141-151,169-177); cm: 8 bits likewise for columns;
 //     hs : (clipped window start of the bin's row) - h0, clamped to [-16, 15]; ws likewise.
 //   Padding slots of the last record: w0 = total elements (out of range: loads return 0), w1 = 0.
-template <int TH, int TW>
-struct TileTouch {
-    int nb, ph0, phn, pw0, pwn;
-    unsigned long long rm, cm;
-    RoiGeom g;
+// One (RoI, tile row) or (RoI, tile column): 16 bytes.
+//   mask  : bit 8*k + j <=> tile line t0+j lies in the RoI and bin p0+k is one of its candidates
+//           (the reference's in_roi and candidate tests, roi_pooling_op_gpu.cu.cc:141-151,169-177)
+//   info  : bits 5k..5k+4 = (clipped window start of bin p0+k) - t0, clamped to [-16, 15], k < 8;
+//           bits 40..47 = p0, bits 48..51 = pn (0: the RoI does not touch this line of tiles)
+struct AxisEntry {
+    unsigned long long mask, info;
 };
 
-template <int TH, int TW>
-__device__ __forceinline__ TileTouch<TH, TW> touch_tile(const float *__restrict__ rois, int r, bool in_range, int n,
-                                                       int h0, int h1, int w0, int w1, int PH, int PW, float scale) {
-    TileTouch<TH, TW> t;
-    t.nb = 0;  t.ph0 = t.phn = t.pw0 = t.pwn = 0;  t.rm = t.cm = 0ull;
-    if (in_range) {
-        t.g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);
-        if (t.g.batch == n && t.g.sw <= w1 && t.g.ew >= w0 && t.g.sh <= h1 && t.g.eh >= h0) {
-            touch_axis<TH, 8>(h0, h1, t.g.sh, t.g.eh, t.g.bin_h, PH, t.ph0, t.phn, t.rm);
-            touch_axis<TW, 8>(w0, w1, t.g.sw, t.g.ew, t.g.bin_w, PW, t.pw0, t.pwn, t.cm);
-            if (t.phn > 0 && t.pwn > 0) t.nb = t.phn * t.pwn;
-        }
+template <int TN>
+__device__ __forceinline__ AxisEntry axis_entry(int t0, int limit, int rs, int re, float bin, int P, int rounding) {
+    AxisEntry e;
+    int p0, pn;
+    const int t1 = min(t0 + TN, limit) - 1;
+    touch_axis<TN, 8>(t0, t1, rs, re, bin, P, p0, pn, e.mask);
+    e.info = 0ull;
+    if (pn <= 0 || re < rs) { e.mask = 0ull;  return e; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int a = min(max(win_start_w(p0 + k, bin, rs, limit, rounding) - t0, -16), 15);
+        e.info |= (unsigned long long)((unsigned)a & 31u) << (5 * k);
     }
-    return t;
+    e.info |= ((unsigned long long)(unsigned)p0 << 40) | ((unsigned long long)(unsigned)pn << 48);
+    return e;
 }
 
-constexpr int FILL_BLOCK = 1024;
-
+// one lane per (RoI, tile row) and per (RoI, tile column): the reference's tests are evaluated
+// tiles_h + tiles_w times per RoI instead of once per (RoI, tile) and axis
 template <int TH, int TW>
-__global__ __launch_bounds__(FILL_BLOCK) void walk_fill_kernel(
-    const float *__restrict__ rois, int N, int H, int W, int C, int PH, int PW, float scale, int rounding,
-    int R, int tiles_h, int tiles_w, const int *__restrict__ img_span, int *__restrict__ tile_off,
-    int *__restrict__ tile_slots, unsigned long long *__restrict__ slots, long long cap_records,
-    unsigned total_elems, int *__restrict__ total) {
+__global__ __launch_bounds__(256) void walk_axes_kernel(
+    const float *__restrict__ rois, int R, int N, int H, int W, int PH, int PW, float scale, int rounding,
+    int tiles_h, int tiles_w, unsigned long long *__restrict__ rowtab, unsigned long long *__restrict__ coltab) {
+    const int per = tiles_h + tiles_w;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)R * per) return;
+    const int r = (int)(i / per), a = (int)(i - (long long)r * per);
+    const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);
+    const bool bad = g.batch < 0 || g.batch >= N;
+    AxisEntry e;
+    if (a < tiles_h) {
+        e = axis_entry<TH>(a * TH, H, g.sh, g.eh, g.bin_h, PH, rounding);
+        if (bad) e.mask = e.info = 0ull;
+        rowtab[((size_t)r * tiles_h + a) * 2] = e.mask;
+        rowtab[((size_t)r * tiles_h + a) * 2 + 1] = e.info;
+    } else {
+        const int tx = a - tiles_h;
+        e = axis_entry<TW>(tx * TW, W, g.sw, g.ew, g.bin_w, PW, rounding);
+        if (bad) e.mask = e.info = 0ull;
+        coltab[((size_t)r * tiles_w + tx) * 2] = e.mask;
+        coltab[((size_t)r * tiles_w + tx) * 2 + 1] = e.info;
+    }
+}
+
+__device__ __forceinline__ int axis_pn(unsigned long long info) { return (int)(info >> 48) & 15; }
+__device__ __forceinline__ int axis_p0(unsigned long long info) { return (int)(info >> 40) & 255; }
+
+// pass 1: the number of candidate bins of one (image, tile)
+__global__ __launch_bounds__(FILL_BLOCK) void walk_count_kernel(
+    const float *__restrict__ rois, int R, int tiles_h, int tiles_w, const int *__restrict__ img_span,
+    const unsigned long long *__restrict__ rowtab, const unsigned long long *__restrict__ coltab,
+    int *__restrict__ tile_slots) {
     __shared__ int wave_sums[FILL_BLOCK / 64];
-    __shared__ int s_first;
     const int tiles = tiles_h * tiles_w;
     const int item = blockIdx.x;
     const int n = item / tiles, tile = item - n * tiles;
     const int ty = tile / tiles_w, tx = tile - ty * tiles_w;
-    const int h0 = ty * TH, w0 = tx * TW;
-    const int h1 = min(h0 + TH, H) - 1, w1 = min(w0 + TW, W) - 1;
     const int lo = R - img_span[n * 2], hi = img_span[n * 2 + 1];       // (R, 0) when the image has no RoI
-    // pass 1: how many candidate bins -> claim a region of the slot array
     int mine = 0;
-    for (int base = lo; base < hi; base += FILL_BLOCK) {
-        const int r = base + (int)threadIdx.x;
-        mine += touch_tile<TH, TW>(rois, r, r < hi, n, h0, h1, w0, w1, PH, PW, scale).nb;
+    for (int r = lo + (int)threadIdx.x; r < hi; r += FILL_BLOCK) {
+        if ((int)rois[(size_t)r * 5] != n) continue;
+        mine += axis_pn(rowtab[((size_t)r * tiles_h + ty) * 2 + 1]) * axis_pn(coltab[((size_t)r * tiles_w + tx) * 2 + 1]);
     }
     int nslots;
     block_exclusive_scan<FILL_BLOCK>(mine, wave_sums, &nslots);
+    if (threadIdx.x == 0) tile_slots[item] = nslots;
+}
+
+// pass 2 (after the offsets are known): the slot stream of one (image, tile), in (roi, ph, pw) order
+//   slot = w0 | w1 << 32:  w0 = element offset of the bin (r * PH*PW*C + bin * C),
+//   w1 = rm | cm << 8 | (hs & 31) << 16 | (ws & 31) << 21: the 8 mask bits of the bin's row /
+//   column for this tile's rows / columns and the window starts relative to the tile.
+//   Padding slots of the last record: w0 = total elements (out of range: loads return 0), w1 = 0.
+__global__ __launch_bounds__(FILL_BLOCK) void walk_fill_kernel(
+    const float *__restrict__ rois, int C, int PW, int PHPW, int R, int tiles_h, int tiles_w,
+    const int *__restrict__ img_span, const unsigned long long *__restrict__ rowtab,
+    const unsigned long long *__restrict__ coltab, const int *__restrict__ tile_off,
+    const int *__restrict__ tile_slots, unsigned long long *__restrict__ slots, long long cap_records,
+    unsigned total_elems, int *__restrict__ total) {
+    __shared__ int wave_sums[FILL_BLOCK / 64];
+    const int tiles = tiles_h * tiles_w;
+    const int item = blockIdx.x;
+    const int n = item / tiles, tile = item - n * tiles;
+    const int ty = tile / tiles_w, tx = tile - ty * tiles_w;
+    const int lo = R - img_span[n * 2], hi = img_span[n * 2 + 1];
+    const int nslots = tile_slots[item];
     const int nrec = (nslots + WALK_SLOTS - 1) / WALK_SLOTS;
-    if (threadIdx.x == 0) {
-        const int first_rec = atomicAdd(&total[0], nrec);
-        s_first = first_rec;
-        tile_off[item] = first_rec;
-        tile_slots[item] = nslots;
-        if ((long long)first_rec + nrec > cap_records) atomicOr(&total[1], 1);   // cannot happen: cap is a bound
-    }
-    __syncthreads();
-    const long long first = (long long)s_first * WALK_SLOTS;
+    const long long first = (long long)tile_off[item] * WALK_SLOTS;
     const long long cap = cap_records * WALK_SLOTS;
-    // pass 2: write the stream
     int run = 0;
     for (int base = lo; base < hi; base += FILL_BLOCK) {
         const int r = base + (int)threadIdx.x;
-        const TileTouch<TH, TW> t = touch_tile<TH, TW>(rois, r, r < hi, n, h0, h1, w0, w1, PH, PW, scale);
+        unsigned long long rmask = 0, rinfo = 0, cmask = 0, cinfo = 0;
+        int nb = 0;
+        if (r < hi && (int)rois[(size_t)r * 5] == n) {
+            rinfo = rowtab[((size_t)r * tiles_h + ty) * 2 + 1];
+            cinfo = coltab[((size_t)r * tiles_w + tx) * 2 + 1];
+            nb = axis_pn(rinfo) * axis_pn(cinfo);
+            if (nb > 0) {
+                rmask = rowtab[((size_t)r * tiles_h + ty) * 2];
+                cmask = coltab[((size_t)r * tiles_w + tx) * 2];
+            }
+        }
         int tot;
-        const int ex = block_exclusive_scan<FILL_BLOCK>(t.nb, wave_sums, &tot);
-        if (t.nb > 0) {
+        const int ex = block_exclusive_scan<FILL_BLOCK>(nb, wave_sums, &tot);
+        if (nb > 0) {
             long long pos = first + run + ex;
-            const unsigned ebase = (unsigned)r * (unsigned)(PH * PW * C);
-            for (int q = 0; q < t.phn; ++q) {
-                const unsigned rmq = (unsigned)(t.rm >> (8 * q)) & 0xffu;
-                const int hs = min(max(win_start_w(t.ph0 + q, t.g.bin_h, t.g.sh, H, rounding) - h0, -16), 15);
-                for (int j = 0; j < t.pwn; ++j, ++pos) {
-                    const unsigned cmj = (unsigned)(t.cm >> (8 * j)) & 0xffu;
-                    const int ws = min(max(win_start_w(t.pw0 + j, t.g.bin_w, t.g.sw, W, rounding) - w0, -16), 15);
-                    const unsigned wlo = ebase + (unsigned)(((t.ph0 + q) * PW + t.pw0 + j) * C);
-                    const unsigned whi = rmq | (cmj << 8) | (((unsigned)hs & 31u) << 16) | (((unsigned)ws & 31u) << 21);
+            const int phn = axis_pn(rinfo), pwn = axis_pn(cinfo);
+            const unsigned e0 = (unsigned)r * (unsigned)(PHPW * C) + (unsigned)((axis_p0(rinfo) * PW + axis_p0(cinfo)) * C);
+            for (int q = 0; q < phn; ++q) {
+                const unsigned hq = ((unsigned)(rmask >> (8 * q)) & 0xffu) | (((unsigned)(rinfo >> (5 * q)) & 31u) << 16);
+                for (int j = 0; j < pwn; ++j, ++pos) {
+                    const unsigned whi = hq | (((unsigned)(cmask >> (8 * j)) & 0xffu) << 8) |
+                                         (((unsigned)(cinfo >> (5 * j)) & 31u) << 21);
+                    const unsigned wlo = e0 + (unsigned)((q * PW + j) * C);
                     if (pos < cap) slots[pos] = (unsigned long long)wlo | ((unsigned long long)whi << 32);
                 }
             }
@@ -222,11 +278,13 @@ __global__ __launch_bounds__(FILL_BLOCK) void walk_fill_kernel(
     }
     for (int i = nslots + (int)threadIdx.x; i < nrec * WALK_SLOTS; i += FILL_BLOCK)      // pad the last record
         if (first + i < cap) slots[first + i] = (unsigned long long)total_elems;
+    if (threadIdx.x == 0 && (run != nslots || first + (long long)nrec * WALK_SLOTS > cap)) atomicOr(&total[1], 1);
 }
 
 // ---- 3. launch order: tiles sorted by work, heaviest first ---------------------------------------
 __global__ __launch_bounds__(1024) void walk_order_kernel(const int *__restrict__ tile_slots, int items,
-                                                          int *__restrict__ order) {
+                                                          int *__restrict__ tile_off, int *__restrict__ order,
+                                                          int *__restrict__ total) {
     __shared__ int wave_sums[16];
     __shared__ int hist[1024];
     __shared__ int s_max;
@@ -234,10 +292,20 @@ __global__ __launch_bounds__(1024) void walk_order_kernel(const int *__restrict_
     if (t == 0) s_max = 0;
     hist[t] = 0;
     __syncthreads();
-    int mx = 0;
-    for (int i = t; i < items; i += 1024) mx = max(mx, tile_slots[i]);
+    // offsets: exclusive prefix sum of the records per tile
+    int run = 0, mx = 0;
+    for (int base = 0; base < items; base += 1024) {
+        const int i = base + t;
+        const int v = i < items ? tile_slots[i] : 0;
+        int tot;
+        const int ex = block_exclusive_scan<1024>((v + WALK_SLOTS - 1) / WALK_SLOTS, wave_sums, &tot);
+        if (i < items) tile_off[i] = run + ex;
+        run += tot;
+        mx = max(mx, v);
+    }
     atomicMax(&s_max, mx);
     __syncthreads();
+    if (t == 0) total[0] = run;
     // bucket sort (the order only decides when a tile is launched)
     const long long top = max(s_max, 1);
     for (int i = t; i < items; i += 1024)
@@ -459,8 +527,7 @@ bool walk_supported(int R, int N, int H, int W, int C, int PH, int PW) {
 
 size_t walk_workspace_bytes(int R, int N, int H, int W, int PH, int PW) {
     // sized for the smallest tiles (most records), so that every plan fits
-    const int tiles = cdiv(H, 4) * cdiv(W, 4);
-    return carve_walk(nullptr, N, tiles, walk_record_bound(R, N, H, W, PH, PW, 4, 4), nullptr);
+    return carve_walk(nullptr, R, N, cdiv(H, 4), cdiv(W, 4), walk_record_bound(R, N, H, W, PH, PW, 4, 4), nullptr);
 }
 
 template <int TH, int TW>
@@ -470,17 +537,23 @@ static int prepare_t(const float *rois, int R, int N, int H, int W, int C, int P
     const int items = N * tiles;
     const long long cap = walk_record_bound(R, N, H, W, PH, PW, TH, TW);
     WalkWs ws;
-    if (carve_walk(workspace, N, tiles, cap, &ws) > workspace_bytes) return WSSDL_ERR_WORKSPACE;
+    if (carve_walk(workspace, R, N, tiles_h, tiles_w, cap, &ws) > workspace_bytes) return WSSDL_ERR_WORKSPACE;
     const unsigned total_elems = (unsigned)((long long)R * PH * PW * C);
     // img_span, total = 0: one contiguous region at the head of the workspace
     hipError_t e = hipMemsetAsync(ws.img_span, 0, (char *)ws.tile_slots - (char *)ws.img_span, st);
     if (e != hipSuccess) { set_last_error(e);  return WSSDL_ERR_LAUNCH; }
-    if (R > 0)
+    if (R > 0) {
         hipLaunchKernelGGL(walk_span_kernel, dim3(cdiv(R, 256)), dim3(256), 0, st, rois, R, N, ws.img_span);
-    hipLaunchKernelGGL((walk_fill_kernel<TH, TW>), dim3(items), dim3(FILL_BLOCK), 0, st, rois, N, H, W, C, PH, PW,
-                       scale, rounding, R, tiles_h, tiles_w, ws.img_span, ws.tile_off, ws.tile_slots, ws.slots, cap,
+        hipLaunchKernelGGL((walk_axes_kernel<TH, TW>), dim3(cdiv((long long)R * (tiles_h + tiles_w), 256)), dim3(256), 0,
+                           st, rois, R, N, H, W, PH, PW, scale, rounding, tiles_h, tiles_w, ws.rowtab, ws.coltab);
+    }
+    hipLaunchKernelGGL(walk_count_kernel, dim3(items), dim3(FILL_BLOCK), 0, st, rois, R, tiles_h, tiles_w,
+                       ws.img_span, ws.rowtab, ws.coltab, ws.tile_slots);
+    hipLaunchKernelGGL(walk_order_kernel, dim3(1), dim3(1024), 0, st, ws.tile_slots, items, ws.tile_off, ws.order,
+                       ws.total);
+    hipLaunchKernelGGL(walk_fill_kernel, dim3(items), dim3(FILL_BLOCK), 0, st, rois, C, PW, PH * PW, R, tiles_h,
+                       tiles_w, ws.img_span, ws.rowtab, ws.coltab, ws.tile_off, ws.tile_slots, ws.slots, cap,
                        total_elems, ws.total);
-    hipLaunchKernelGGL(walk_order_kernel, dim3(1), dim3(1024), 0, st, ws.tile_slots, items, ws.order);
     return check_launch();
 }
 
@@ -504,7 +577,7 @@ static int launch_walk_t(const float *top_diff, const unsigned char *arg8, int R
     const int tiles_h = cdiv(H, TH), tiles_w = cdiv(W, TW), tiles = tiles_h * tiles_w;
     const int items = N * tiles;
     WalkWs ws;
-    if (carve_walk(workspace, N, tiles, walk_record_bound(R, N, H, W, PH, PW, TH, TW), &ws) > workspace_bytes)
+    if (carve_walk(workspace, R, N, tiles_h, tiles_w, walk_record_bound(R, N, H, W, PH, PW, TH, TW), &ws) > workspace_bytes)
         return WSSDL_ERR_WORKSPACE;
     const unsigned total_elems = (unsigned)((long long)R * PH * PW * C);
     const int G = cdiv(C, WALK_CH);
