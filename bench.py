@@ -11,6 +11,10 @@ rank runs the same per-GPU batch; gradients are averaged with one RCCL all-reduc
 untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; the time is
 the max over ranks; rank 0 prints ONE JSON line.
 
+`roofline` is measured on a FIXED RoI set (tools/roofline_leg.py: exactly n_sup*128 + n_ws*2000 =
+8512 rows for the default workload, profiles/roofline_rois_r8512.npy) right after the timed steps,
+with HIP events on the launch stream around each C-ABI call; `cpu_baseline` pools the same RoI set.
+
 Workloads (BASELINE.json `configs`):
   resnet50_joint_b8   configs[2] -- ResNet-50, combined mini-batch (train.py), 4 supervised +
                       4 weak images per GPU: R = 4*128 + 4*2000 RoIs through RoI pool (default:
@@ -39,7 +43,7 @@ HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300
 
 WORKLOADS = {
     "resnet50_joint_b8": dict(net="Resnet_train", depth=50, mode="joint", n_sup=4, n_ws=4,
-                              im=(600, 1000), baseline_config=2),
+                              im=(600, 1000), baseline_config=2, fixed_rois=True),
     "resnet18_sup_b2": dict(net="Resnet_train_alter", depth=18, mode="sup", n_sup=2, n_ws=0,
                             im=(600, 1000), baseline_config=1),
     "resnet50_alter": dict(net="Resnet_train_alter", depth=50, mode="alter", n_sup=1, n_ws=2,
@@ -66,11 +70,17 @@ def alg_bytes(name, m):
     return 0
 
 
-def cpu_baseline(wl, seed=3):
+def cpu_baseline(wl, fixed_rois=None, seed=3):
     """The oracle (a port of the reference's CPU path; its NMS/IoU inner kernels are the
-    reference's own Cython when oracle/_ref is present) timed on this host over the whole per-GPU
-    mini-batch of the workload (every image with its own synthetic inputs), repeated until about
-    10 s of CPU work have been measured."""
+    reference's own Cython when oracle/_ref is present) timed on this host:
+      layers   anchor targets + proposal layer + proposal targets of every image of the per-GPU
+               mini-batch (each with its own synthetic RPN maps), single-threaded like the reference
+               (py_func under the GIL);
+      RoI pool forward + backward on the SAME fixed RoI set the GPU roofline leg uses, on all host
+               cores (forward sharded over RoIs like the reference's Shard(), roi_pooling_op.cc:198-203;
+               backward sharded over channels: the reference shards the flat bottom range,
+               :460-465).
+    One pass is 10-30 s of CPU work; repeated (at most 3 passes) until 10 s have been measured."""
     import numpy as np
     from oracle import c_oracle, np_oracle as O, ref_kernels
     H = -(-wl["im"][0] // 16)
@@ -90,8 +100,7 @@ def cpu_baseline(wl, seed=3):
         p = (e / e.sum(-1, keepdims=True)).astype(np.float32)
         prob = np.concatenate((p[..., 0], p[..., 1]), axis=-1)
         pred = rs.normal(0, 0.2, size=(1, H, W, 36)).astype(np.float32)
-        feat = np.maximum(rs.normal(size=(1, H, W, C)), 0).astype(np.float32)
-        return prob, pred, feat
+        return prob, pred
 
     use_ref = ref_kernels.available()
     if use_ref:                       # the reference's own Cython kernels (PyObject-compare NMS)
@@ -104,30 +113,36 @@ def cpu_baseline(wl, seed=3):
     cores = os.cpu_count() or 1
     n_img = wl["n_sup"] + wl["n_ws"]
     t_layers = t_pool = 0.0
-    n_rois = passes = 0
+    passes = 0
+    layer_rois = 0
+    rs = np.random.RandomState(seed)
+    feat = np.maximum(rs.normal(size=(n_img, H, W, C)), 0).astype(np.float32)
     try:
-        def one_image(k, weak):
-            prob, pred, feat = inputs(k)
-            t0 = time.perf_counter()
-            if train and not weak:
-                O.anchor_target_layer(np.zeros((1, H, W, 18), np.float32), gt, ng, info, None, [16], [8, 16, 32],
-                                      "SNUBH", rng=np.random.RandomState(seed + k))
-            rois = O.proposal_layer(prob, pred, info, train, False, [16], [8, 16, 32])
-            if train and not weak:
-                rois = O.proposal_target_layer(rois, gt, ng, 3, True, False,
-                                               rng=np.random.RandomState(seed + k))[0]
-            t1 = time.perf_counter()
-            top, arg = c_oracle.roi_pool_forward(feat, rois, 7, 7, 1.0 / 16, "cuda", threads=cores)
-            if train:
-                c_oracle.roi_pool_backward(top, arg, rois, feat.shape, 7, 7, 1.0 / 16)
-            t2 = time.perf_counter()
-            return t1 - t0, t2 - t1, rois.shape[0]
-        while passes < 4 and (passes == 0 or t_layers + t_pool < 10.0):
+        while passes < 3 and (passes == 0 or t_layers + t_pool < 10.0):
+            layer_rois = 0
+            generated = []
             for k in range(n_img):
-                a, b, r = one_image(passes * n_img + k, weak=k >= wl["n_sup"])
-                t_layers += a
-                t_pool += b
-                n_rois += r
+                weak = k >= wl["n_sup"]
+                prob, pred = inputs(passes * n_img + k)
+                t0 = time.perf_counter()
+                if train and not weak:
+                    O.anchor_target_layer(np.zeros((1, H, W, 18), np.float32), gt, ng, info, None, [16], [8, 16, 32],
+                                          "SNUBH", rng=np.random.RandomState(seed + k))
+                rois = O.proposal_layer(prob, pred, info, train, False, [16], [8, 16, 32])
+                if train and not weak:
+                    rois = O.proposal_target_layer(rois, gt, ng, 3, True, False,
+                                                   rng=np.random.RandomState(seed + k))[0]
+                t_layers += time.perf_counter() - t0
+                layer_rois += rois.shape[0]
+                rois = rois.copy()
+                rois[:, 0] = k
+                generated.append(rois)
+            pool_rois = fixed_rois if fixed_rois is not None else np.concatenate(generated).astype(np.float32)
+            t0 = time.perf_counter()
+            top, arg = c_oracle.roi_pool_forward(feat, pool_rois, 7, 7, 1.0 / 16, "cuda", threads=cores)
+            if train:
+                c_oracle.roi_pool_backward(top, arg, pool_rois, feat.shape, 7, 7, 1.0 / 16, threads=cores)
+            t_pool += time.perf_counter() - t0
             passes += 1
     finally:
         if use_ref:
@@ -137,12 +152,76 @@ def cpu_baseline(wl, seed=3):
         value=n_img / t_step, unit="images/s (hot path only: anchor targets + proposal layer + "
                                    "proposal targets + RoI pool fwd/bwd; no backbone)",
         cores=cores, kind="port",
-        sample="the per-GPU mini-batch of this workload (%d supervised + %d weak images, %d RoIs per pass), "
-               "%d pass(es), %.1f s of CPU work (layers %.1f s, RoI pool %.1f s); layers single-threaded like "
-               "the reference (GIL), RoI pool on %d threads like its Shard(); NMS/IoU inner kernels = %s"
-               % (wl["n_sup"], wl["n_ws"], n_rois // passes, passes, t_layers + t_pool, t_layers, t_pool, cores,
-                  "the reference's own Cython (oracle/_ref)" if use_ref else "C port (oracle/_ref absent)"),
+        sample="%d pass(es) over the per-GPU mini-batch of this workload (%d supervised + %d weak images), "
+               "%.1f s of CPU work: layers %.1f s single-threaded like the reference (GIL; they produced %d RoIs "
+               "per pass), RoI pool forward + backward %.1f s on %d host threads over R = %d RoIs%s, C = %d; "
+               "NMS/IoU inner kernels = %s"
+               % (passes, wl["n_sup"], wl["n_ws"], t_layers + t_pool, t_layers, layer_rois, t_pool, cores,
+                  pool_rois.shape[0], " (the fixed set of the GPU roofline leg)" if fixed_rois is not None else "",
+                  C, "the reference's own Cython (oracle/_ref)" if use_ref else "C port (oracle/_ref absent)"),
+        roi_pool_rois=int(pool_rois.shape[0]),
+        cpu_roi_pool_ms=t_pool / passes * 1e3, cpu_layers_ms=t_layers / passes * 1e3,
         cpu_hot_path_ms_per_step=t_step * 1e3)
+
+
+def fixed_roi_set(wl, net, blobs):
+    """The RoI set of the roofline leg: the committed file for the default workload, otherwise
+    n_sup * 128 sampled + n_ws * post_nms_topN proposals built from the network like
+    tools/make_roofline_rois.py does."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import roofline_leg
+    if wl.get("fixed_rois") and os.path.exists(roofline_leg.ROIS_PATH):
+        return roofline_leg.load_rois()
+    import torch
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.rpn_msr.proposal_layer_tf_bus import proposal_layer_padded
+    train = wl["mode"] != "test"
+    with torch.no_grad():
+        was = net.training
+        net.train(train)
+        L = net(blobs["data"], blobs["im_info"], blobs["gt_boxes"], blobs["num_gt_boxes"], is_training=train,
+                is_ws=(wl["mode"] == "alter" and wl["n_sup"] == 0), test_net=not train)
+        net.train(was)
+    post = int((cfg.TRAIN if train else cfg.TEST).RPN_POST_NMS_TOP_N)
+    rp, cnt, dec, sidx, scnt = [t.cpu().numpy() for t in proposal_layer_padded(
+        L["rpn_cls_score"], L["rpn_bbox_pred"], blobs["im_info"], train, debug=True, from_logits=True)]
+    rows = []
+    n_valid = L["roi-data"][1].shape[0] if (train and isinstance(L["roi-data"], tuple)) else 0
+    sampled = L["roi-data"][0][:n_valid].cpu().numpy() if n_valid else np.zeros((0, 5), np.float32)
+    n_img = blobs["data"].shape[0]
+    for i in range(n_img):
+        r = sampled[sampled[:, 0] == i]
+        if r.shape[0]:
+            rows.append(r)
+            continue
+        kept = rp[i, :cnt[i], 1:]
+        cand = dec[i][sidx[i, :scnt[i]]]
+        seen = set(map(bytes, np.ascontiguousarray(kept)))
+        extra = np.array([c for c in cand if bytes(np.ascontiguousarray(c)) not in seen][:post - len(kept)],
+                         dtype=np.float32).reshape(-1, 4)
+        boxes = np.concatenate([kept, extra])
+        rows.append(np.concatenate([np.full((len(boxes), 1), i, np.float32), boxes], axis=1))
+    rois = np.ascontiguousarray(np.concatenate(rows).astype(np.float32))
+    return rois, "generated from this run's network (%d rows)" % rois.shape[0]
+
+
+def hbm_traffic(kernel_key, meta):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/hotpath_traffic.json, tools/profile_round.sh) -- only when they were taken on the same
+    kernel sources and the same launch shape as this run; otherwise null."""
+    tpath = os.path.join(ROOT, "profiles", "hotpath_traffic.json")
+    if not os.path.exists(tpath):
+        return None, "no PMC passes committed"
+    tj = json.load(open(tpath))
+    want = {k: meta[k] for k in ("N", "H", "W", "C", "R", "argmax_bytes", "kernel_source_id")}
+    have = tj.get("launch", {})
+    if any(have.get(k) != v for k, v in want.items()):
+        return None, "stale: profiles/hotpath_traffic.json was taken for %s, this run is %s" % (have, want)
+    for k, v in tj.get("kernels", {}).items():
+        if kernel_key in k:
+            return int(v["hbm_bytes_per_launch"]), "profiles/hotpath_traffic.json (%s)" % k
+    return None, "kernel not in profiles/hotpath_traffic.json"
 
 
 def main():
@@ -156,8 +235,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--miopen-benchmark", action="store_true",
                     help="torch.backends.cudnn.benchmark for the (static-shape) trunk convolutions")
-    ap.add_argument("--fused-rpn-softmax", action="store_true",
-                    help="f2: fuse reshape->softmax->reshape into the proposal decode kernel")
+    ap.add_argument("--no-fused-rpn-softmax", action="store_true",
+                    help="materialise rpn_cls_prob with separate reshape / softmax / reshape ops instead of "
+                         "fusing them into the proposal decode kernel (f2, the default)")
+    ap.add_argument("--roofline-iters", type=int, default=20, help="launches of the fixed-RoI roofline leg")
     args = ap.parse_args()
 
     import numpy as np
@@ -181,7 +262,7 @@ def main():
     cfg.TRAIN.IMS_PER_BATCH = wl["n_sup"]
     cfg.TRAIN.WS_IMS_PER_BATCH = wl["n_ws"]
     cfg.SAMPLING_RNG = args.sampling_rng
-    cfg.FUSED_RPN_SOFTMAX = bool(args.fused_rpn_softmax)
+    cfg.FUSED_RPN_SOFTMAX = not args.no_fused_rpn_softmax
     seed = ctx.seed(cfg.RNG_SEED)
     cfg.DEVICE_RNG_SEED = seed              # the device samplers draw a different stream on every rank
     np.random.seed(seed)
@@ -251,42 +332,47 @@ def main():
         torch.cuda.synchronize()
         return 5 * 2 * a.numel() * 4 / (s.elapsed_time(e) * 1e-3) / 1e9
 
+    # ---- roofline leg: the RoI-pool pair of the training path on the FIXED RoI set (every rank
+    # runs it so that ranks stay in step; rank 0 reports)
+    tl = _lib.timeline.summary()          # hot-path launches of the timed region (this rank)
+    feat_key = "conv5_3" if wl["net"].startswith("VGG") else "group2/relu"
+    leg_blobs = blobs_s if mode == "alter" else blobs
+    rois_fixed, roi_tag = fixed_roi_set(wl, net, leg_blobs)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import roofline_leg
+    N_leg = int(leg_blobs["data"].shape[0])
+    H_leg, W_leg, C_leg = [int(v) for v in net.layers[feat_key].shape[1:4]]
+    if rois_fixed.shape[0] == 0 or int(rois_fixed[:, 0].max()) >= N_leg:
+        N_leg = int(rois_fixed[:, 0].max()) + 1 if rois_fixed.shape[0] else N_leg
+    leg, leg_meta = roofline_leg.run(rois_fixed, N_leg, H_leg, W_leg, C_leg, iters=args.roofline_iters)
+
     if ctx.rank == 0:
-        tl = _lib.timeline.summary()
         hot_ms = sum(d["total_ms"] for d in tl.values()) / max(args.steps, 1)
-        # dominant kernel = the single-kernel hot-path launch with the largest total time in the
-        # timed region.  proposal_layer / anchor_target_layer / proposal_target_layer are chains of
-        # several small latency-bound kernels (listed in per_kernel, not eligible here).
-        single = ("roi_pool_forward", "roi_pool_backward")
-        dom = max((k for k in tl if k in single), key=lambda k: tl[k]["total_ms"], default=None)
-        if dom is None:
-            dom = max((k for k in tl if alg_bytes(k, tl[k]["metas"][0]) > 0),
-                      key=lambda k: tl[k]["total_ms"], default=None)
-        roofline = None
-        if dom:
-            d = tl[dom]
-            byt = sum(alg_bytes(dom, m) for m in d["metas"]) / d["calls"]
-            ach = byt / (d["avg_ms"] * 1e-3) / 1e9
-            # PMC traffic cannot be collected inside this process; tools/profile_round.sh runs the
-            # FETCH_SIZE / WRITE_SIZE passes of this same command and commits the per-launch means
-            traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "hotpath_traffic.json")
-            kname = {"roi_pool_forward": "roi_pool_fwd", "roi_pool_backward": "roi_pool_bwd"}.get(dom)
-            if kname and os.path.exists(tpath) and args.workload == "resnet50_joint_b8":
-                tj = json.load(open(tpath))
-                for k, v in tj.get("kernels", {}).items():
-                    if kname in k:
-                        traffic, traffic_src = int(v["hbm_bytes_per_launch"]), "profiles/hotpath_traffic.json"
-            roofline = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_src,
-                            measured_d2d_copy=round(measured_copy_gbps(), 1),
-                            avg_launch_ms=round(d["avg_ms"], 4), alg_bytes_per_launch=int(byt),
-                            launches=d["calls"],
-                            per_kernel={k: dict(avg_ms=round(v["avg_ms"], 4), calls=v["calls"],
-                                                kernels=1 if k in single else "chain",
-                                                GBps=round(sum(alg_bytes(k, m) for m in v["metas"]) / v["calls"]
-                                                           / (v["avg_ms"] * 1e-3) / 1e9, 1))
-                                        for k, v in tl.items()})
+        # dominant kernel = the single-kernel launch of the leg with the largest average duration
+        # (roi_pool_backward = the walk kernel alone; its list-building prepare step, like the
+        # proposal / target layers, is a chain of small latency-bound kernels: per_kernel only)
+        single = [k for k in ("roi_pool_forward", "roi_pool_backward") if k in leg]
+        dom = max(single, key=lambda k: leg[k]["avg_ms"])
+        d = leg[dom]
+        kernel_key = {"roi_pool_forward": "roi_pool_fwd", "roi_pool_backward": "roi_pool_bwd"}[dom]
+        traffic, traffic_src = hbm_traffic(kernel_key, leg_meta)
+        roofline = dict(
+            bound="hbm", kernel=dom, achieved=round(d["GBps"], 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+            frac=round(d["GBps"] / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_src,
+            R=int(rois_fixed.shape[0]), roi_set=roi_tag, launch=leg_meta,
+            avg_launch_ms=round(d["avg_ms"], 4), alg_bytes_per_launch=int(d["alg_bytes_per_launch"]),
+            launches=d["calls"], measured_d2d_copy=round(measured_copy_gbps(), 1),
+            note="achieved = algorithmic bytes of SURVEY.md 8(d) (f32 top + i32 argmax layout of the reference) / "
+                 "launch time; the training path moves a 1-byte arg-max instead (min_moved_bytes in fixed_set). "
+                 "RoI-pool parity is pinned by hand-computed cases and two independent oracle restatements, not "
+                 "by reference outputs (TensorFlow op cannot be built here: 'parity unpinned', DESIGN.md section 2)",
+            fixed_set={k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                       for k, v in leg.items()},
+            per_kernel={k: dict(avg_ms=round(v["avg_ms"], 4), calls=v["calls"],
+                                kernels=1 if k in ("roi_pool_forward", "roi_pool_backward") else "chain",
+                                GBps=round(sum(alg_bytes(k, m) for m in v["metas"]) / v["calls"]
+                                           / (v["avg_ms"] * 1e-3) / 1e9, 1))
+                        for k, v in tl.items()})
         result = {
             "metric": "images/sec (train step, 600x1000)" if mode != "test" else "images/sec (test forward, 1000x1600)",
             "value": round(images_per_step * ctx.world_size * args.steps / elapsed, 3),
@@ -300,15 +386,21 @@ def main():
                        "image": "%dx%d" % (im_h, im_w), "images_per_gpu": images_per_step,
                        "supervised_per_gpu": wl["n_sup"], "weak_per_gpu": wl["n_ws"], "mode": mode,
                        "parallelism": "image-parallel dp%d, RCCL grad all-reduce" % ctx.world_size,
-                       "sampling_rng": args.sampling_rng},
+                       "sampling_rng": args.sampling_rng, "fused_rpn_softmax": bool(cfg.FUSED_RPN_SOFTMAX),
+                       "roi_pool_argmax_bytes": leg_meta["argmax_bytes"]},
             "roofline": roofline,
             "hot_path": {"gpu_ms_per_step": round(hot_ms, 3),
                          "gpu_images_per_s": round(images_per_step / (hot_ms * 1e-3), 1) if hot_ms > 0 else None},
             "final_loss": loss_val,
         }
         if ctx.world_size == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(wl)
+            cb = cpu_baseline(wl, rois_fixed)
             result["cpu_baseline"] = cb
+            gpu_pool_ms = sum(leg[k]["avg_ms"] for k in ("roi_pool_forward", "roi_pool_backward_prepare",
+                                                          "roi_pool_backward") if k in leg)
+            result["hot_path"]["roi_pool_same_set"] = {
+                "R": int(rois_fixed.shape[0]), "gpu_ms": round(gpu_pool_ms, 3),
+                "cpu_ms": round(cb["cpu_roi_pool_ms"], 1), "ratio": round(cb["cpu_roi_pool_ms"] / gpu_pool_ms, 1)}
             if hot_ms > 0:
                 result["hot_path"]["speedup_vs_cpu_baseline"] = round(cb["cpu_hot_path_ms_per_step"] / hot_ms, 1)
         print(json.dumps(result))

@@ -296,6 +296,44 @@ void orc_roi_pool_backward_scatter(const float *top_diff, const int32_t *argmax,
     }
 }
 
+/* The ordered scatter restricted to channels [c0, c1) and WITHOUT the zero fill, for the
+ * cpu_baseline leg: channels are independent, so the caller zeroes bottom_diff once and runs
+ * one call per host thread on disjoint channel ranges; per destination element the f32
+ * additions still happen in the order roi^, ph^, pw^ (results identical to the function above). */
+void orc_roi_pool_backward_scatter_channels(const float *top_diff, const int32_t *argmax,
+                                            const float *rois, int R, int N, int H, int W,
+                                            int C, int PH, int PW, float scale, int c0, int c1,
+                                            float *bottom_diff)
+{
+    for (int r = 0; r < R; ++r) {
+        roi_geom g = roi_geometry(rois + 5 * r, scale, PH, PW);
+        if (g.batch < 0 || g.batch >= N)
+            continue;
+        float *img = bottom_diff + (size_t)g.batch * H * W * C;
+        for (int ph = 0; ph < PH; ++ph)
+            for (int pw = 0; pw < PW; ++pw) {
+                size_t o = (((size_t)r * PH + ph) * PW + pw) * C;
+                for (int c = c0; c < c1; ++c) {
+                    int idx = argmax[o + c];
+                    if (idx < 0 || idx % C != c)
+                        continue;
+                    int cell = idx / C;
+                    int h = cell / W, w = cell % W;
+                    if (h >= H)
+                        continue;
+                    if (!(w >= g.sw && w <= g.ew && h >= g.sh && h <= g.eh))
+                        continue;
+                    int phstart = clampi((int)floorf((float)(h - g.sh) / g.bin_h), 0, PH);
+                    int phend = clampi((int)ceilf((float)(h - g.sh + 1) / g.bin_h), 0, PH);
+                    int pwstart = clampi((int)floorf((float)(w - g.sw) / g.bin_w), 0, PW);
+                    int pwend = clampi((int)ceilf((float)(w - g.sw + 1) / g.bin_w), 0, PW);
+                    if (ph >= phstart && ph < phend && pw >= pwstart && pw < pwend)
+                        img[idx] += top_diff[o + c];
+                }
+            }
+    }
+}
+
 /* Threaded forward for the cpu_baseline leg: the reference shards the flat
  * output range over TF's intra-op pool (roi_pooling_op.cc:198-203); here the
  * RoI range is split over `nthreads` OpenMP-free pthreads-free workers by the

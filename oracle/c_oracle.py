@@ -54,6 +54,9 @@ def lib():
                 f = getattr(L, name)
                 f.argtypes = [fp, ip, fp, i32, i32, i32, i32, i32, i32, i32, ctypes.c_float, fp]
                 f.restype = None
+            L.orc_roi_pool_backward_scatter_channels.argtypes = [fp, ip, fp, i32, i32, i32, i32, i32, i32, i32,
+                                                                 ctypes.c_float, i32, i32, fp]
+            L.orc_roi_pool_backward_scatter_channels.restype = None
             _lib = L
     return _lib
 
@@ -128,11 +131,26 @@ def roi_pool_forward(bottom, rois, pooled_h, pooled_w, spatial_scale, mode="cuda
 
 
 def roi_pool_backward(top_diff, argmax, rois, bottom_shape, pooled_h, pooled_w, spatial_scale,
-                      literal=False):
+                      literal=False, threads=1):
     top_diff = np.ascontiguousarray(top_diff, dtype=np.float32)
     argmax = np.ascontiguousarray(argmax, dtype=np.int32)
     rois = np.ascontiguousarray(rois, dtype=np.float32).reshape(-1, 5)
     N, H, W, C = bottom_shape
+    if threads > 1 and not literal and C >= threads:
+        # channels are independent: one host thread per channel range (ctypes releases the GIL)
+        out = np.zeros((N, H, W, C), dtype=np.float32)
+        bounds = np.linspace(0, C, threads + 1).astype(int)
+        ts = []
+        for t in range(threads):
+            a = (_p(top_diff, ctypes.c_float), _p(argmax, ctypes.c_int32), _p(rois, ctypes.c_float),
+                 rois.shape[0], N, H, W, C, pooled_h, pooled_w, float(spatial_scale), int(bounds[t]),
+                 int(bounds[t + 1]), _p(out, ctypes.c_float))
+            th = threading.Thread(target=lib().orc_roi_pool_backward_scatter_channels, args=a)
+            th.start()
+            ts.append(th)
+        for th in ts:
+            th.join()
+        return out
     out = np.empty((N, H, W, C), dtype=np.float32)
     f = lib().orc_roi_pool_backward if literal else lib().orc_roi_pool_backward_scatter
     f(_p(top_diff, ctypes.c_float), _p(argmax, ctypes.c_int32), _p(rois, ctypes.c_float),

@@ -153,3 +153,8 @@ def test_threaded_forward_matches_single_thread():
     a = c_oracle.roi_pool_forward(f, rois, 7, 7, 1.0 / 16, "cuda", threads=1)
     b = c_oracle.roi_pool_forward(f, rois, 7, 7, 1.0 / 16, "cuda", threads=4)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # backward: channel ranges on host threads == the single-threaded ordered scatter, bit for bit
+    d = rs.normal(size=a[0].shape).astype(np.float32)
+    g1 = c_oracle.roi_pool_backward(d, a[1], rois, f.shape, 7, 7, 1.0 / 16)
+    g4 = c_oracle.roi_pool_backward(d, a[1], rois, f.shape, 7, 7, 1.0 / 16, threads=4)
+    assert np.array_equal(g1, g4)

@@ -37,6 +37,11 @@ namespace wssdl {
 #define WSSDL_BWDC_ABLATE 0
 #endif
 
+// tuning builds only: -DWSSDL_FWDC_ABLATE=1 forward without its stores, =2 without its loads
+#ifndef WSSDL_FWDC_ABLATE
+#define WSSDL_FWDC_ABLATE 0
+#endif
+
 // tuning builds only (-DWSSDL_BWDC_TRACE=1): every workgroup of the backward records
 // (start, end) of s_memrealtime (100 MHz) and its record / bin counts into a buffer set with
 // wssdl_debug_set_trace (tools/bwd_trace.py)
@@ -117,7 +122,11 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_compact_kernel(
                     for (int j = 0; j < BATCH; ++j) {
                         const int wj = min(w + j, we - 1);
                         code[j] = rcode | (unsigned)(wj - ws);
+#if WSSDL_FWDC_ABLATE == 2
+                        v[j] = (float4v)((float)(wj + h));
+#else
                         v[j] = *reinterpret_cast<const float4v *>(img + row_base + wj * C);
+#endif
                     }
 #pragma unroll
                     for (int j = 0; j < BATCH; ++j) {
@@ -129,8 +138,12 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_compact_kernel(
                 }
             }
         }
+#if WSSDL_FWDC_ABLATE == 1
+        if (mv.x == 12345.678f && m0 == 77u) top[o] = mv.y + mv.z + mv.w + (float)(m1 + m2 + m3);
+#else
         __builtin_nontemporal_store(mv, reinterpret_cast<float4v *>(top + o));
         __builtin_nontemporal_store(m0 | (m1 << 8) | (m2 << 16) | (m3 << 24), arg8 + (o >> 2));
+#endif
     }
 }
 
