@@ -48,11 +48,18 @@ def test_compact_pair_vs_oracle(torch_cuda, shape, mode):
     rois = _rois_for(rs, R, N, H, W)
     et, ea = c_oracle.roi_pool_forward(f, rois, 7, 7, 1.0 / 16, mode, threads=16)
     ft, rt = torch.from_numpy(f).cuda(), torch.from_numpy(rois).cuda()
-    top, arg8 = op.roi_pool_compact(ft, rt, 7, 7, 1.0 / 16, rounding=mode)
-    assert arg8.dtype == torch.uint8 and tuple(arg8.shape) == (R, 7, 7, C)
-    assert np.array_equal(top.cpu().numpy(), et)
-    arg = op.expand_argmax(arg8, rt, shape, 7, 7, 1.0 / 16, rounding=mode)
-    assert np.array_equal(arg.cpu().numpy(), ea)
+    # forward kernels: 0 = wave-uniform rows x 256 channels (default), 2 = x 128 channels, 3 = one RoI
+    # (7 rows) per workgroup, 9 = the two-rows-per-wave sliced kernel
+    for fwd in ("9", "3", "2", "0"):
+        os.environ["WSSDL_ROI_FWD_VARIANT"] = fwd
+        try:
+            top, arg8 = op.roi_pool_compact(ft, rt, 7, 7, 1.0 / 16, rounding=mode)
+        finally:
+            os.environ.pop("WSSDL_ROI_FWD_VARIANT", None)
+        assert arg8.dtype == torch.uint8 and tuple(arg8.shape) == (R, 7, 7, C)
+        assert np.array_equal(top.cpu().numpy(), et), fwd
+        arg = op.expand_argmax(arg8, rt, shape, 7, 7, 1.0 / 16, rounding=mode)
+        assert np.array_equal(arg.cpu().numpy(), ea), fwd
     # the i32 pair of the reference contract gives the same tensors
     top_i, arg_i = op.roi_pool(ft, rt, 7, 7, 1.0 / 16, rounding=mode)
     assert torch.equal(top_i, top) and torch.equal(arg_i, arg)

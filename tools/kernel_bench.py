@@ -96,10 +96,15 @@ def main():
     if compact_supported(H, W, C, 7, 7):
         top_c, arg8 = roi_pool_compact(feat, rois, 7, 7, 1.0 / 16)
         assert os.environ.get("KB_NO_CHECK") or torch.equal(top_c, top)
-        ms = timeit(lambda: roi_pool_compact(feat, rois, 7, 7, 1.0 / 16), args.iters)
-        byt = N * H * W * C * 4 + R * 20 + R * 49 * C * 8
-        out.append(dict(op="roi_pool_forward_compact", ms=ms, R=R, C=C, alg_bytes=byt, GBps=byt / ms / 1e6,
-                        moved_bytes=N * H * W * C * 4 + R * 20 + R * 49 * C * 5))
+        for fv in os.environ.get("KB_FWD_VARIANTS", "0").split(","):
+            os.environ["WSSDL_ROI_FWD_VARIANT"] = fv
+            t2, a2 = roi_pool_compact(feat, rois, 7, 7, 1.0 / 16)
+            assert os.environ.get("KB_NO_CHECK") or (torch.equal(t2, top) and torch.equal(a2, arg8))
+            ms = timeit(lambda: roi_pool_compact(feat, rois, 7, 7, 1.0 / 16), args.iters, warmup=5)
+            byt = N * H * W * C * 4 + R * 20 + R * 49 * C * 8
+            out.append(dict(op="roi_pool_forward_compact[v%s]" % fv, ms=ms, R=R, C=C, alg_bytes=byt, GBps=byt / ms / 1e6,
+                            moved_bytes=N * H * W * C * 4 + R * 20 + R * 49 * C * 5))
+        os.environ.pop("WSSDL_ROI_FWD_VARIANT", None)
         ref_g = roi_pool_grad(feat, rois, arg, diff, 7, 7, 1.0 / 16)
         from wssdl_bus_amd.roi_pooling_layer.roi_pooling_op import roi_pool_grad_prepare
         shape = tuple(feat.shape)

@@ -147,6 +147,115 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_compact_kernel(
     }
 }
 
+// Forward, wave-uniform form: ONE wave = one (roi, ph) bin row x 64*CPL channels, so the window
+// bounds, the loops over the window and the cell offsets are scalar (SALU); a cell costs one
+// buffer load (scalar cell offset + constant lane offset) and 3 VALU per channel.  The sliced
+// kernel above packs two bin rows with different windows into a wave: its loops are vector code
+// under exec masks and every cell pays 64-bit address arithmetic (measured: 0.49 ms with the
+// loads removed, 0.59 ms with the stores removed, 0.72 ms together at R = 8512 for 2.2 GB of
+// HBM traffic -- instruction issue, not bandwidth; this form: 0.44 / 0.63 / 0.59 ms).  Channel
+// slice <-> blockIdx % 8 as above (without the slicing: 1.13 ms).  Tried without gain: four
+// cells in flight, 7 rows (one RoI) per workgroup, plain instead of non-temporal stores (+5-10 %).
+template <int CPL>
+struct LaneVec;
+template <>
+struct LaneVec<4> {
+    typedef float4v vec;
+    static __device__ __forceinline__ vec load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+#if WSSDL_FWDC_ABLATE == 2
+        return (vec)((float)(soff & 1023));
+#else
+        return __builtin_bit_cast(vec, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+#endif
+    }
+};
+typedef float float2w __attribute__((ext_vector_type(2)));
+template <>
+struct LaneVec<2> {
+    typedef float2w vec;
+    static __device__ __forceinline__ vec load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __builtin_bit_cast(vec, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    }
+};
+
+template <int CPL, int RPW /* bin rows (waves) per workgroup */>
+__global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
+    const float *__restrict__ bottom, int N, int H, int W, int C, const float *__restrict__ rois,
+    int R, int PH, int PW, float scale, int rounding, float *__restrict__ top,
+    unsigned char *__restrict__ arg8, int *__restrict__ overflow, int slices) {
+    typedef typename LaneVec<CPL>::vec vec;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // blockIdx -> (channel slice, group of RPW rows): all groups of a slice share blockIdx % 8
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    int slice, group;
+    if (slices >= 8) { const int per = slices >> 3;  slice = xcd + 8 * (q % per);  group = q / per; }
+    else { const int share = 8 / slices;  slice = xcd % slices;  group = q * share + xcd / slices; }
+    const long long row = (long long)group * RPW + wave;
+    const long long rows = (long long)R * PH;
+    if (row >= rows) return;
+    const int r = (int)(row / PH), ph = (int)(row - (long long)r * PH);
+    const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);        // wave-uniform values
+    const int batch = __builtin_amdgcn_readfirstlane(g.batch);
+    const bool bad = batch < 0 || batch >= N;
+    const int hs = __builtin_amdgcn_readfirstlane(win_start(ph, g.bin_h, g.sh, H, rounding));
+    const int he = __builtin_amdgcn_readfirstlane(win_end(ph, g.bin_h, g.sh, H, rounding));
+    const int c0 = (slice * 64 + lane) * CPL;
+    const bool lane_ok = c0 < C;
+    const int voff = (lane_ok ? c0 : 0) * 4;
+    const int cell_bytes = C * 4;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(bottom + (size_t)(bad ? 0 : batch) * H * W * C), 0, H * W * cell_bytes, 0x00020000);
+    size_t o = ((size_t)row * PW) * C + c0;
+    for (int pw = 0; pw < PW; ++pw, o += C) {
+        const int ws = __builtin_amdgcn_readfirstlane(win_start(pw, g.bin_w, g.sw, W, rounding));
+        const int we = __builtin_amdgcn_readfirstlane(win_end(pw, g.bin_w, g.sw, W, rounding));
+        const bool empty = (he <= hs) || (we <= ws) || bad;
+        vec mv;
+        unsigned mi[CPL];
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) { mv[k] = empty ? 0.0f : -FLT_MAX;  mi[k] = ARG8_EMPTY; }
+        if (!empty) {
+            if ((he - hs > ARG8_MAX_WIN_H || we - ws > ARG8_MAX_WIN_W) && overflow && lane == 0) atomicOr(overflow, 1);
+            for (int h = hs; h < he; ++h) {
+                const int so_row = h * W * cell_bytes;
+                const unsigned rcode = (unsigned)(h - hs) << 4;
+                int w = ws;
+                for (; w + 1 < we; w += 2) {          // two cells in flight
+                    const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
+                    const vec v1 = LaneVec<CPL>::load(rs, voff, so_row + (w + 1) * cell_bytes);
+                    const unsigned code0 = rcode | (unsigned)(w - ws), code1 = code0 + 1u;
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) if (v0[k] > mv[k]) { mv[k] = v0[k];  mi[k] = code0; }
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) if (v1[k] > mv[k]) { mv[k] = v1[k];  mi[k] = code1; }
+                }
+                if (w < we) {
+                    const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
+                    const unsigned code0 = rcode | (unsigned)(w - ws);
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) if (v0[k] > mv[k]) { mv[k] = v0[k];  mi[k] = code0; }
+                }
+            }
+        }
+#if WSSDL_FWDC_ABLATE == 1
+        if (mv[0] == 12345.678f && mi[0] == 77u) top[o] = mv[1] + (float)mi[1];
+        if (false)
+#else
+        if (lane_ok)
+#endif
+        {
+            __builtin_nontemporal_store(mv, reinterpret_cast<vec *>(top + o));
+            if (CPL == 4)
+                __builtin_nontemporal_store(mi[0] | (mi[1] << 8) | (mi[2 % CPL] << 16) | (mi[3 % CPL] << 24),
+                                            reinterpret_cast<unsigned *>(arg8 + o));
+            else
+                __builtin_nontemporal_store((unsigned short)(mi[0] | (mi[1] << 8)),
+                                            reinterpret_cast<unsigned short *>(arg8 + o));
+        }
+    }
+}
+
 // codes -> the reference's flat NHWC index (roi_pooling_op_gpu.cu.cc:71-79); one lane = 4 channels
 __global__ __launch_bounds__(256) void roi_argmax_expand_kernel(
     const unsigned *__restrict__ arg8, const float *__restrict__ rois, long long total4, int H, int W,
@@ -527,6 +636,30 @@ extern "C" int wssdl_roi_pool_forward_compact(const float *bottom, int N, int H,
     const long long row_blocks = ((long long)R * pooled_h + rows_per_block - 1) / rows_per_block;
     if (row_blocks * 8 > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
     unsigned *a8 = reinterpret_cast<unsigned *>(argmax8);
+    int variant = 0;
+    if (const char *e = getenv("WSSDL_ROI_FWD_VARIANT")) variant = atoi(e);      // tuning
+    // wave-uniform kernel: one wave per (roi, ph) row x 256 (or 128) channels
+    if (variant != 9) {
+        const int cpl = (variant == 2 || C % 256 != 0) ? 2 : 4;
+        const int slices = cdiv(C, 64 * cpl);
+        const int rpw = (variant == 3 && cpl == 4) ? 7 : 4;
+        if (((slices >= 8 && slices % 8 == 0) || (slices < 8 && 8 % slices == 0)) &&
+            (long long)H * W * C * 4 < 0x7fffffffLL) {
+            const long long groups = ((long long)R * pooled_h + rpw - 1) / rpw;
+            long long blocks = slices >= 8 ? groups * slices : 8 * ((groups + 8 / slices - 1) / (8 / slices));
+            if (blocks <= 0x7fffffffLL) {
+#define WSSDL_FWD_ROWS(CPL, RPW) \
+    hipLaunchKernelGGL((roi_pool_fwd_rows_kernel<CPL, RPW>), dim3((unsigned)blocks), dim3(64 * RPW), 0, st, bottom, N, \
+                       H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top, argmax8, overflow, slices)
+                if (cpl == 2) WSSDL_FWD_ROWS(2, 4);
+                else if (variant == 3) WSSDL_FWD_ROWS(4, 7);
+
+                else WSSDL_FWD_ROWS(4, 4);
+#undef WSSDL_FWD_ROWS
+                return check_launch();
+            }
+        }
+    }
     if (row_blocks * 8 <= 4096)      // less than ~4 workgroups per CU: latency-bound, fetch 2 cells at a time
         hipLaunchKernelGGL(roi_pool_fwd_compact_kernel<2>, dim3((unsigned)(row_blocks * 8)), dim3(256), 0, st,
                            bottom, N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top, a8,
