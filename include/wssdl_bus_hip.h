@@ -287,6 +287,30 @@ WSSDL_API int wssdl_mil_select(const float *instance_logits, int R, int num_clas
                      int selector_other, int32_t *row_out, int32_t *count_out,
                      wssdl_stream_t stream);
 
+/* ---------------------------------------------------------------------- f4 ---
+ * The pinnable half of the host image path, on the device.  utils/blob.py:34-79
+ * (prep_im_for_blob), :19-32 (im_list_to_blob), roi_data_layer/minibatch_bus.py:269-272 (grey plane
+ * stacked three times, horizontal flip), datasets/imdb.py:106-121 (boxes of flipped images).
+ * skimage.transform.resize (blob.py:74-77) is NOT part of this library (not pinnable: absent,
+ * version unknown); the path is cut around it:
+ *   wssdl_image_prep     gray [h, row_stride] u8 -> out [h,w,3] f32 = what the reference hands to
+ *                        the resize: flip, /255, optional brightness (+delta, clip to [0,1]),
+ *                        optional contrast ((x - mean(x)) * factor + mean(x), clip), - pixel_mean/255.
+ *                        delta / factor are the values the caller drew (the reference:
+ *                        np.random.uniform, blob.py:50,55).  workspace: wssdl_image_prep_workspace_bytes.
+ *   wssdl_image_to_blob  im [h,w,3] f64 (im_is_f64) or f32 = the resize's output -> blob
+ *                        [n_images,Hmax,Wmax,3] f32, image `index`: x / scale (divide != 0: ResNet,
+ *                        scale = pixel_std/255) or x * scale (VGG: 255), zero outside [h,w].
+ *   wssdl_flip_boxes     in place on boxes [n, stride >= 4] f32: x1' = width - x2 - 1, x2' = width - x1 - 1. */
+WSSDL_API size_t wssdl_image_prep_workspace_bytes(void);
+WSSDL_API int wssdl_image_prep(const uint8_t *gray, int h, int w, int row_stride, int flipped,
+                     int use_brightness, float brightness_delta, int use_contrast,
+                     float contrast_factor, double pixel_mean, float *out, void *workspace,
+                     size_t workspace_bytes, wssdl_stream_t stream);
+WSSDL_API int wssdl_image_to_blob(const void *im, int im_is_f64, int h, int w, double scale, int divide,
+                     float *blob, int index, int n_images, int Hmax, int Wmax, wssdl_stream_t stream);
+WSSDL_API int wssdl_flip_boxes(float *boxes, int n, int stride, float width, wssdl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

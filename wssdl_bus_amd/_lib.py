@@ -56,6 +56,10 @@ SYMBOLS = {
     "wssdl_roi_pool_backward_compact": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _i,
                                              _vp]),
     "wssdl_roi_argmax_expand": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "wssdl_image_prep_workspace_bytes": (_sz, []),
+    "wssdl_image_prep": (_i, [_vp, _i, _i, _i, _i, _i, _f, _i, _f, _d, _vp, _vp, _sz, _vp]),
+    "wssdl_image_to_blob": (_i, [_vp, _i, _i, _i, _d, _i, _vp, _i, _i, _i, _i, _vp]),
+    "wssdl_flip_boxes": (_i, [_vp, _i, _i, _f, _vp]),
     "wssdl_mil_select": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
 }
 

@@ -1,0 +1,113 @@
+"""Blob helper functions on the GPU (the pinnable half of the reference's host image path).
+
+Reference: code/lib/utils/blob.py:19-32 (im_list_to_blob), :34-79 (prep_im_for_blob),
+roi_data_layer/minibatch_bus.py:269-272 (grey plane stacked x3, flip), datasets/imdb.py:106-121
+(box mirroring).  Same function names and argument meaning; images live on the device.
+
+``skimage.transform.resize`` (blob.py:74-77) is not reimplemented: the library is absent here and
+its version unpinned, so no oracle could pin it.  prep_im_for_blob therefore
+takes the resize as a callable; the default is torch's bilinear interpolation, which is a
+DIFFERENT filter than skimage's and is not parity-checked -- everything around it is.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+from ..fast_rcnn.config import cfg
+
+PIXEL_MEANS = np.array([[[68.274, 68.274, 68.274]]])     # fast_rcnn/config.py:284
+PIXEL_STDS = np.array([[[52.802, 52.802, 52.802]]])      # fast_rcnn/config.py:287
+
+
+def _ws(dev):
+    n = _lib.lib().wssdl_image_prep_workspace_bytes()
+    return torch.empty((n,), dtype=torch.uint8, device=dev), n
+
+
+def prep_im_pre_resize(gray, flipped=False, brightness_delta=None, contrast_factor=None,
+                       pixel_means=PIXEL_MEANS):
+    """gray [h,w] u8 (GPU tensor or numpy) -> f32 [h,w,3] GPU tensor: the array the reference hands
+    to skimage.transform.resize (blob.py:34-60 after minibatch_bus.py:269-272).  `brightness_delta`
+    / `contrast_factor`: the values of the reference's two np.random.uniform draws, None = off."""
+    g = _lib.to_device(gray, torch.uint8)
+    if g.dim() != 2:
+        raise ValueError("expected one grey plane [h, w]")
+    h, w = g.shape
+    out = torch.empty((h, w, 3), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        ws, n = _ws(g.device)
+        _lib.check(_lib.lib().wssdl_image_prep(
+            _lib.ptr(g), h, w, g.stride(0), int(bool(flipped)),
+            int(brightness_delta is not None), float(brightness_delta or 0.0),
+            int(contrast_factor is not None), float(contrast_factor if contrast_factor is not None else 1.0),
+            float(np.asarray(pixel_means).reshape(-1)[0]), _lib.ptr(out), _lib.ptr(ws), n, _lib.stream()),
+            "wssdl_image_prep")
+    return out
+
+
+def torch_bilinear_resize(im, shape):
+    """Stand-in for skimage.transform.resize (NOT the same filter, not parity-checked)."""
+    x = im.permute(2, 0, 1).unsqueeze(0).to(torch.float64)
+    y = torch.nn.functional.interpolate(x, size=tuple(int(s) for s in shape), mode="bilinear", align_corners=False)
+    return y.squeeze(0).permute(1, 2, 0).contiguous()
+
+
+def prep_im_for_blob(gray, net_name, pixel_means, pixel_stds, target_size, max_size, is_training,
+                     is_ws=False, flipped=False, rng=None, resize=None):
+    """blob.py:34-79 for one grey plane.  Returns (im [h',w',3] on the GPU, im_scale).  The two
+    augmentation draws come from `rng` (default: numpy's global stream, like the reference) in the
+    reference's order; rotation and cropping of weak images (blob.py:39-46) need skimage / are a
+    plain slice and are left to the caller."""
+    rng = np.random if rng is None else rng
+    delta = factor = None
+    if is_training:
+        if cfg.TRAIN.get("USE_BRIGHTNESS_ADJUSTMENT", True):
+            d = cfg.TRAIN.get("BRIGHTNESS_ADJUSTMENT_MAX_DELTA", 0.2)
+            delta = rng.uniform(-d, d)
+        if cfg.TRAIN.get("USE_CONTRAST_ADJUSTMENT", True):
+            factor = rng.uniform(cfg.TRAIN.get("CONTRAST_ADJUSTMENT_LOWER_FACTOR", 0.2),
+                                 cfg.TRAIN.get("CONTRAST_ADJUSTMENT_UPPER_FACTOR", 1.8))
+    pre = prep_im_pre_resize(gray, flipped, delta, factor, pixel_means)
+    h, w = pre.shape[:2]
+    im_scale = float(target_size) / float(min(h, w))
+    if np.round(im_scale * max(h, w)) > max_size:
+        im_scale = float(max_size) / float(max(h, w))
+    shape = (int(np.round(h * im_scale)), int(np.round(w * im_scale)))
+    resized = (resize or torch_bilinear_resize)(pre, shape)
+    std = float(np.asarray(pixel_stds).reshape(-1)[0])
+    if net_name[:6] == 'Resnet':
+        im = _scale_image(resized, std / 255.0, True)
+    else:
+        im = _scale_image(resized, 255.0, False)
+    return im, im_scale
+
+
+def _scale_image(resized, scale, divide):
+    blob = im_list_to_blob([resized], scale=scale, divide=divide)
+    return blob[0]
+
+
+def im_list_to_blob(ims, scale=1.0, divide=False):
+    """blob.py:19-32: images [h_i,w_i,3] (f32 or f64 GPU tensors) -> zero-padded f32 blob
+    [n, max_h, max_w, 3].  `scale` / `divide` fold blob.py:75-77 into the copy (x / scale or x * scale)."""
+    ims = [_lib.to_device(im, im.dtype if isinstance(im, torch.Tensor) else torch.float64) for im in ims]
+    dev = ims[0].device
+    Hm, Wm = max(im.shape[0] for im in ims), max(im.shape[1] for im in ims)
+    blob = torch.empty((len(ims), Hm, Wm, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        for i, im in enumerate(ims):
+            if im.dim() != 3 or im.shape[2] != 3 or im.dtype not in (torch.float32, torch.float64):
+                raise ValueError("images must be [h,w,3] f32 / f64")
+            _lib.check(_lib.lib().wssdl_image_to_blob(
+                _lib.ptr(im), int(im.dtype == torch.float64), im.shape[0], im.shape[1], float(scale), int(divide),
+                _lib.ptr(blob), i, len(ims), Hm, Wm, _lib.stream()), "wssdl_image_to_blob")
+    return blob
+
+
+def flip_boxes(boxes, width):
+    """datasets/imdb.py:106-121 on a GPU tensor [n, >=4] f32 (returns a mirrored copy)."""
+    b = _lib.to_device(boxes, torch.float32).clone()
+    with torch.cuda.device(b.device):
+        _lib.check(_lib.lib().wssdl_flip_boxes(_lib.ptr(b), b.shape[0], b.stride(0), float(width), _lib.stream()),
+                   "wssdl_flip_boxes")
+    return b
