@@ -189,7 +189,10 @@ WSSDL_API int wssdl_anchor_targets(const int8_t *labels, const int32_t *argmax_g
  *   = (n_fg, n_bg).  Rows of other images (batch index != images[s]) are ignored.
  * Stage 3  wssdl_roi_targets: for the kept rows: labels (bg clamped to 0, :265),
  *   bbox_transform in f32 (:220), expansion to 4*num_classes with inside/outside
- *   weights (:187-210, :89).  keep [n_keep] i32 indexes rois; is_fg [n_keep] u8. */
+ *   weights (:187-210, :89).  keep [n_keep] i32 indexes rois; is_fg [n_keep] u8.  A negative keep
+ *   entry is a padding slot of a fixed-shape list (wssdl_roi_sample_device pads with -1 when an
+ *   image runs short of candidates): its output row is (-1,0,0,0,0), label -1, zero targets and
+ *   weights, so that consumers can run on the full shape without reading the counts back. */
 WSSDL_API int wssdl_roi_gt_assign(const float *rois, int R, const float *gt_boxes, int max_gt,
                         const int32_t *num_pos_boxes, int n_images, double *max_overlap,
                         int32_t *assignment, wssdl_stream_t stream);

@@ -500,8 +500,10 @@ def test_fused_batchnorm2d_channels_last_matches_stock(torch_cuda):
 
 
 def test_proposal_target_device_sampling_short_image(torch_cuda):
-    """Fewer background candidates than the quota: the image contributes fewer than
-    rois_per_image rows (the padded -1 slots of the sampler are dropped), like the reference."""
+    """Fewer background candidates than the quota: the reference returns fewer than rois_per_image
+    rows for that image; the device path keeps the shape fixed (no read-back of the counts) and fills
+    the image's slot with padding rows (-1,0,0,0,0), label -1, zero weights, which RoI pooling, the
+    losses and the MIL selection ignore."""
     import torch
     from wssdl_bus_amd.fast_rcnn.config import cfg
     from wssdl_bus_amd.rpn_msr import proposal_target_layer_tf_bus as ptl
@@ -524,13 +526,27 @@ def test_proposal_target_device_sampling_short_image(torch_cuda):
                                       torch.from_numpy(ng).to(dev), 3, True, False)
         out_rois, labels = o[0].cpu().numpy(), o[1].cpu().numpy()[:, 0]
         fg_rpi = int(np.round(cfg.TRAIN.FG_FRACTION * cfg.TRAIN.BATCH_SIZE))
+        rpi = int(cfg.TRAIN.BATCH_SIZE)
+        assert out_rois.shape == (2 * rpi, 5) and o[2].shape == (2 * rpi, 12)
         n0 = int(np.sum(out_rois[:, 0] == 0))
         n1 = int(np.sum(out_rois[:, 0] == 1))
         assert n0 == fg_rpi                      # all candidates of image 0 are fg: 32 fg, 0 bg
-        assert n1 == int(cfg.TRAIN.BATCH_SIZE)   # image 1: 32 fg + 96 bg
-        assert np.all(labels[:n0] == 1)
-        assert np.all(labels[n0:n0 + fg_rpi] == 2) and np.all(labels[n0 + fg_rpi:] == 0)
-        assert o[2].shape == (n0 + n1, 12)
+        assert n1 == rpi                         # image 1: 32 fg + 96 bg
+        assert np.all(out_rois[:n0, 0] == 0) and np.all(labels[:n0] == 1)
+        pad = slice(n0, rpi)                     # the rest of image 0's slot is padding
+        assert np.all(out_rois[pad, 0] == -1) and not out_rois[pad, 1:].any() and np.all(labels[pad] == -1)
+        assert not o[2].cpu().numpy()[pad].any() and not o[3].cpu().numpy()[pad].any() and not o[4].cpu().numpy()[pad].any()
+        assert np.all(labels[rpi:rpi + fg_rpi] == 2) and np.all(labels[rpi + fg_rpi:] == 0)
+        # the losses leave the padding rows out: CE over 32 + 128 rows, box loss averaged over them
+        from wssdl_bus_amd.fast_rcnn.train_bus import rcnn_box_loss, rcnn_cls_loss
+        cls = torch.randn((2 * rpi, 3), device=dev)
+        live = labels >= 0
+        want = torch.nn.functional.cross_entropy(cls[torch.from_numpy(live).to(dev)],
+                                                 torch.from_numpy(labels[live]).long().to(dev))
+        assert abs(float(rcnn_cls_loss(cls, o[1])) - float(want)) < 1e-6
+        bp = torch.randn((2 * rpi, 12), device=dev)
+        per = (o[4] * (o[3] * (bp - o[2]).abs())).sum(1)
+        assert abs(float(rcnn_box_loss(bp, o)) - float(per.sum() / int(live.sum()))) < 1e-6
     finally:
         cfg.SAMPLING_RNG = old
 

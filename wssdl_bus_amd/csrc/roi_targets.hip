@@ -64,16 +64,23 @@ __global__ __launch_bounds__(256) void roi_targets_kernel(
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_keep) return;
     const int r = keep[p];
-    const float *b = rois + (size_t)r * 5;
     float *ro = rois_out + (size_t)p * 5;
-    ro[0] = b[0]; ro[1] = b[1]; ro[2] = b[2]; ro[3] = b[3]; ro[4] = b[4];
-    const int img = (int)b[0];
-    const int k = assignment[r];
     const int width = 4 * num_classes;
     float *to = bbox_targets + (size_t)p * width;
     float *io = inside_w + (size_t)p * width;
     float *oo = outside_w + (size_t)p * width;
     for (int j = 0; j < width; ++j) { to[j] = 0.0f; io[j] = 0.0f; oo[j] = 0.0f; }
+    if (r < 0) {
+        // padding slot of a fixed-shape keep list (an image ran short of candidates): a row no
+        // consumer acts on -- batch index -1 (RoI pooling treats it as empty), label -1 (ignored)
+        ro[0] = -1.0f; ro[1] = 0.0f; ro[2] = 0.0f; ro[3] = 0.0f; ro[4] = 0.0f;
+        labels[p] = -1.0f;
+        return;
+    }
+    const float *b = rois + (size_t)r * 5;
+    ro[0] = b[0]; ro[1] = b[1]; ro[2] = b[2]; ro[3] = b[3]; ro[4] = b[4];
+    const int img = (int)b[0];
+    const int k = assignment[r];
     float label = 0.0f;
     if (k >= 0 && is_fg[p]) {
         const float *g = gt_boxes + ((size_t)img * max_gt + k) * 5;

@@ -82,6 +82,11 @@ __C.ROI_POOL_ROUNDING = "cuda"
 # training path: the autograd pair hands a 1-byte arg-max from RoiPool to RoiPoolGrad when the
 # library supports the shape (include/wssdl_bus_hip.h); False = the reference's i32 layout
 __C.ROI_POOL_COMPACT_ARGMAX = True
+# True: the proposal layer hands out a fixed-shape blob [N * post_nms_topN, 5] (unused rows carry batch
+# index -1) and nothing between the backbone and the loss copies to the host: the hot path can be
+# captured in a hipGraph.  The per-RoI head then runs on the padded row count (batch-norm masked to the
+# live rows).  False (default): the blob is compacted, which costs one read-back of N counts per step.
+__C.PADDED_ROIS = False
 
 
 def cfg_from_list(cfg_list):

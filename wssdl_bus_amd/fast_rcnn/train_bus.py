@@ -43,14 +43,19 @@ def rpn_box_loss(rpn_bbox_pred, rpn_data, n_images=None):
 def rcnn_cls_loss(cls_score, labels):
     """train_bus.py:218 / :623-630: CE over the first len(labels) rows."""
     label = labels.reshape(-1).to(torch.int64)
-    return F.cross_entropy(cls_score[:label.numel()], label)
+    # label -1 = padding row of a fixed-shape RoI list (an image short of candidates): not a row of
+    # the reference's blob, so it is left out of the mean
+    return F.cross_entropy(cls_score[:label.numel()], label, ignore_index=-1)
 
 
 def rcnn_box_loss(bbox_pred, roi_data):
     """train_bus.py:231-235 / :641-647: plain L1, mean over rows of the weighted row sums."""
     tg, inw, outw = roi_data[2], roi_data[3], roi_data[4]
     pred = bbox_pred[:tg.shape[0]]
-    return (outw * (inw * (pred - tg).abs())).sum(dim=1).mean()
+    per_row = (outw * (inw * (pred - tg).abs())).sum(dim=1)
+    # mean over the rows of the reference's blob: padding rows (label -1, zero weights) do not count
+    n_rows = (roi_data[1].reshape(-1) >= 0).sum().clamp_min(1)
+    return per_row.sum() / n_rows
 
 
 def mil_loss(cls_score_ws, batch_inds, mil_label, n_bags, global_step, funcs, counts_host=None):
@@ -66,8 +71,7 @@ def mil_loss(cls_score_ws, batch_inds, mil_label, n_bags, global_step, funcs, co
         bag_logits, _ = mil_core.get_bag_logit(cls_score_ws, batch_inds, 3, mil_label, n_bags,
                                                funcs, counts_host)
     label = mil_label.reshape(-1).to(torch.int64)
-    w = torch.tensor([0.0, cfg.TRAIN.WS_MAL_PCT, 1 - cfg.TRAIN.WS_MAL_PCT],
-                     dtype=bag_logits.dtype, device=bag_logits.device)[label]
+    w = _class_prior(bag_logits)[label]
     if valid is not None:                          # an empty bag (no proposals) carries no loss
         w = w * valid.to(w.dtype)
     ce = F.cross_entropy(bag_logits, label, reduction='none')
@@ -76,6 +80,20 @@ def mil_loss(cls_score_ws, batch_inds, mil_label, n_bags, global_step, funcs, co
     else:
         scale = cfg.TRAIN.WS_LOSS_SCALE_FACTOR
     return (scale * (w * ce)).mean()
+
+
+_prior_cache = {}
+
+
+def _class_prior(like):
+    """[0, WS_MAL_PCT, 1 - WS_MAL_PCT] on like's device (train_bus.py:252,664), built once: a tensor
+    made from a Python list is a blocking host->device copy."""
+    key = (float(cfg.TRAIN.WS_MAL_PCT), str(like.device), like.dtype)
+    t = _prior_cache.get(key)
+    if t is None:
+        t = torch.tensor([0.0, key[0], 1 - key[0]], dtype=like.dtype, device=like.device)
+        _prior_cache[key] = t
+    return t
 
 
 def l2_weight_decay(params):

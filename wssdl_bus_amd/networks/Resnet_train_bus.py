@@ -86,7 +86,18 @@ class Resnet_train_bus(nn.Module, Network):
                  .proposal_target_layer_joint(n_classes, is_training, name='roi-data'))
         (self.feed('group2/relu', 'roi-data')
              .roi_pool(7, 7, 1.0 / 16, name='roi_pool'))
-        gap = self.head(self.layers['roi_pool'])                      # [R,7,7,C] NHWC, GEMM head
+        if cfg.PADDED_ROIS and self.training:
+            # fixed-shape RoI blob: rows with batch index -1 are dead; the head's batch statistics
+            # are taken over the live rows only
+            from . import roi_head
+            rois_in = self.layers['roi-data'][0] if isinstance(self.layers['roi-data'], tuple) else self.layers['roi-data']
+            roi_head.set_roi_mask((rois_in[:, 0] >= 0).to(torch.float32))
+            try:
+                gap = self.head(self.layers['roi_pool'])
+            finally:
+                roi_head.set_roi_mask(None)
+        else:
+            gap = self.head(self.layers['roi_pool'])                  # [R,7,7,C] NHWC, GEMM head
         self.layers['gap'] = gap
         self.layers['cls_score'] = self.cls_score(gap)
         self.layers['cls_prob'] = torch.softmax(self.layers['cls_score'], dim=-1)

@@ -37,11 +37,12 @@ def layer(op):
 
 
 def _blob(out):
-    """[-1, 5] view of a proposal blob that keeps its per-image row-count tag."""
+    """[-1, 5] view of a proposal blob that keeps its per-image row-count tags."""
     r = out.reshape(-1, 5)
-    c = getattr(out, "_wssdl_counts", None)
-    if c is not None:
-        r._wssdl_counts = c
+    for tag in ("_wssdl_counts", "_wssdl_pitch", "_wssdl_counts_dev"):
+        c = getattr(out, tag, None)
+        if c is not None:
+            setattr(r, tag, c)
     return r
 
 

@@ -73,6 +73,32 @@ class _FusedRowBatchNormFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+# cfg.PADDED_ROIS: the head then sees a fixed number of RoI rows of which only some are live.
+# The networks set this mask ([R] f32, 1 = live) around the head call; batch statistics are
+# taken over the live rows only and dead rows are zeroed after every normalisation, so that the
+# live rows come out as if the blob had been compacted.  Plain PyTorch ops (no host sync).
+_ROI_MASK = None
+
+
+def set_roi_mask(mask):
+    global _ROI_MASK
+    _ROI_MASK = mask
+
+
+def _masked_row_batch_norm(x, weight, bias, eps, relu, roi_mask):
+    M = x.shape[0]
+    per = M // roi_mask.shape[0]
+    m = roi_mask.repeat_interleave(per).unsqueeze(1)
+    n = (roi_mask.sum() * per).clamp_min(1.0)
+    mean = (x * m).sum(0) / n
+    d = (x - mean) * m
+    var = (d * d).sum(0) / n
+    y = d * (torch.rsqrt(var + eps) * weight) + bias
+    if relu:
+        y = F.relu(y)
+    return y * m, mean.detach(), var.detach(), n
+
+
 class RowBatchNorm(nn.Module):
     """BatchNorm over rows ([M, C] input) with the usual running statistics; `relu=True`
     applies the ReLU that follows it in the network inside the same kernels."""
@@ -94,6 +120,12 @@ class RowBatchNorm(nn.Module):
                 return _plumbing.rowbn_apply(x, scale.contiguous(), shift.contiguous(), relu)
             y = torch.addcmul(shift, x, scale)
             return F.relu(y) if relu else y
+        if _ROI_MASK is not None:
+            y, mean, var, n = _masked_row_batch_norm(x, self.weight, self.bias, self.eps, relu, _ROI_MASK)
+            with torch.no_grad():
+                self.running_mean.lerp_(mean, self.momentum)
+                self.running_var.lerp_(var * (n / (n - 1).clamp_min(1.0)), self.momentum)
+            return y
         if fused:
             y, mean, var = _FusedRowBatchNormFn.apply(x, self.weight, self.bias, self.eps, bool(relu))
         else:

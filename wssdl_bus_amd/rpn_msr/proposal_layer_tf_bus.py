@@ -85,6 +85,27 @@ def compact_rois(rois_padded, counts, counts_host=None):
     return out
 
 
+def padded_blob(rois_padded, counts):
+    """cfg.PADDED_ROIS: the fixed-shape form of the blob, [N * post_nms_topN, 5] with batch index
+    -1 on the rows an image does not use -- no device->host copy.  RoI pooling treats such rows as
+    empty, the proposal-target layer never samples them, the MIL selection never matches them."""
+    N, P = rois_padded.shape[:2]
+    live = torch.arange(P, device=rois_padded.device).view(1, P) < counts.view(N, 1).to(torch.int64)
+    out = rois_padded.clone()
+    out[:, :, 0] = torch.where(live, out[:, :, 0], torch.full_like(out[:, :, 0], -1.0))
+    out = out.reshape(N * P, 5)
+    out._wssdl_pitch = P
+    out._wssdl_counts_dev = counts
+    return out
+
+
+def _blob(rois, counts, as_np):
+    if cfg.PADDED_ROIS and not as_np:
+        return padded_blob(rois, counts)
+    blob = compact_rois(rois, counts)
+    return blob.cpu().numpy() if as_np else blob
+
+
 def proposal_layer(rpn_cls_prob_reshape, rpn_bbox_pred, im_info, is_training, is_ws,
                    _feat_stride=[16, ], anchor_scales=[8, 16, 32]):
     """Same contract as the reference: returns the rois blob [sum R_i, 5] f32 with
@@ -93,8 +114,7 @@ def proposal_layer(rpn_cls_prob_reshape, rpn_bbox_pred, im_info, is_training, is
     as_np = _lib.wants_numpy(rpn_cls_prob_reshape, rpn_bbox_pred, im_info)
     rois, counts = proposal_layer_padded(rpn_cls_prob_reshape, rpn_bbox_pred, im_info,
                                          is_training, _feat_stride, anchor_scales)
-    blob = compact_rois(rois, counts)
-    return blob.cpu().numpy() if as_np else blob
+    return _blob(rois, counts, as_np)
 
 
 def proposal_layer_from_score(rpn_cls_score, rpn_bbox_pred, im_info, is_training, is_ws=False,
@@ -105,5 +125,4 @@ def proposal_layer_from_score(rpn_cls_score, rpn_bbox_pred, im_info, is_training
     as_np = _lib.wants_numpy(rpn_cls_score, rpn_bbox_pred, im_info)
     rois, counts = proposal_layer_padded(rpn_cls_score, rpn_bbox_pred, im_info, is_training,
                                          _feat_stride, anchor_scales, from_logits=True)
-    blob = compact_rois(rois, counts)
-    return blob.cpu().numpy() if as_np else blob
+    return _blob(rois, counts, as_np)

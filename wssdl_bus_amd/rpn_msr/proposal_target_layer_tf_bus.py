@@ -10,8 +10,9 @@ gather + labels + bbox_transform + class expansion for the sampled rows
 (``wssdl_roi_targets``).  The fg/bg sampling between the two consumes
 ``numpy.random`` exactly like the reference (same seed and call order => same rows);
 with ``cfg.SAMPLING_RNG = 'device'`` it is ``wssdl_roi_sample_device`` instead (same
-distribution, counter-based device RNG) and the layer needs no host copy of the
-candidates: one 8-byte-per-image read-back of the row counts is its only sync.
+distribution, counter-based device RNG) and the layer needs no host copy at all: its output
+has the fixed shape S * 128 rows; an image that runs short of candidates (the reference then
+returns fewer rows) leaves padding rows (-1,0,0,0,0) with label -1 and zero weights.
 """
 import numpy as np
 import numpy.random as npr
@@ -102,13 +103,11 @@ def _supervised_device(rois, gt_dev, ng_dev, images, append_gt, num_classes):
                 float(cfg.TRAIN.FG_THRESH), float(cfg.TRAIN.BG_THRESH_HI),
                 float(cfg.TRAIN.BG_THRESH_LO), seed, _lib.ptr(keep), _lib.ptr(is_fg),
                 _lib.ptr(counts), _lib.stream()), "wssdl_roi_sample_device")
-            n_rows = counts.cpu().numpy().sum(axis=1)                   # the layer's one sync
-            if int(n_rows.sum()) == S * rpi:
-                keep_flat, fg_flat = keep.reshape(-1), is_fg.reshape(-1)
-            else:                                                       # an image ran short of bg rows
-                m = keep.reshape(-1) >= 0
-                keep_flat, fg_flat = keep.reshape(-1)[m].contiguous(), is_fg.reshape(-1)[m].contiguous()
-            n_keep = int(n_rows.sum())
+            # fixed shape, no read-back: an image that runs short of candidates leaves -1 slots in
+            # `keep`; wssdl_roi_targets turns them into rows (-1,0,0,0,0) with label -1 and zero
+            # weights, which RoI pooling, the losses and the MIL selection all ignore
+            keep_flat, fg_flat = keep.reshape(-1), is_fg.reshape(-1)
+            n_keep = S * rpi
             out_rois = torch.empty((n_keep, 5), dtype=torch.float32, device=dev)
             labels = torch.empty((n_keep, 1), dtype=torch.float32, device=dev)
             tg = torch.empty((n_keep, 4 * num_classes), dtype=torch.float32, device=dev)
@@ -238,6 +237,13 @@ def _finish(outs, as_np):
 def _weak_rois(rpn_rois, rois, images):
     """Rows of the weak `images`, in order (hint from the proposal layer, else read-back)."""
     images = list(images)
+    pitch = getattr(rpn_rois, "_wssdl_pitch", None)
+    if pitch is not None and images:
+        # padded blob (cfg.PADDED_ROIS): image i owns rows [i*pitch, (i+1)*pitch), the unused ones
+        # carry batch index -1 -- a fixed-shape slice, no read-back
+        if images == list(range(images[0], images[-1] + 1)):
+            return rois[images[0] * pitch:(images[-1] + 1) * pitch]
+        return torch.cat([rois[i * pitch:(i + 1) * pitch] for i in images], dim=0)
     hint = _counts_hint(rpn_rois, images[-1] + 1) if (images and isinstance(rpn_rois, torch.Tensor)) else None
     if hint is not None:
         return _rois_of_images_hinted(rois, hint, images)
