@@ -239,6 +239,9 @@ def main():
                     help="materialise rpn_cls_prob with separate reshape / softmax / reshape ops instead of "
                          "fusing them into the proposal decode kernel (f2, the default)")
     ap.add_argument("--roofline-iters", type=int, default=20, help="launches of the fixed-RoI roofline leg")
+    ap.add_argument("--padded-rois", action="store_true",
+                    help="fixed-shape RoI blob (dead rows carry batch index -1): no device->host copy between "
+                         "the backbone and the loss; the per-RoI head then runs on the padded row count")
     args = ap.parse_args()
 
     import numpy as np
@@ -263,6 +266,7 @@ def main():
     cfg.TRAIN.WS_IMS_PER_BATCH = wl["n_ws"]
     cfg.SAMPLING_RNG = args.sampling_rng
     cfg.FUSED_RPN_SOFTMAX = not args.no_fused_rpn_softmax
+    cfg.PADDED_ROIS = bool(args.padded_rois)
     seed = ctx.seed(cfg.RNG_SEED)
     cfg.DEVICE_RNG_SEED = seed              # the device samplers draw a different stream on every rank
     np.random.seed(seed)
@@ -386,7 +390,7 @@ def main():
                        "image": "%dx%d" % (im_h, im_w), "images_per_gpu": images_per_step,
                        "supervised_per_gpu": wl["n_sup"], "weak_per_gpu": wl["n_ws"], "mode": mode,
                        "parallelism": "image-parallel dp%d, RCCL grad all-reduce" % ctx.world_size,
-                       "sampling_rng": args.sampling_rng, "fused_rpn_softmax": bool(cfg.FUSED_RPN_SOFTMAX),
+                       "sampling_rng": args.sampling_rng, "fused_rpn_softmax": bool(cfg.FUSED_RPN_SOFTMAX), "padded_rois": bool(cfg.PADDED_ROIS),
                        "roi_pool_argmax_bytes": leg_meta["argmax_bytes"]},
             "roofline": roofline,
             "hot_path": {"gpu_ms_per_step": round(hot_ms, 3),
