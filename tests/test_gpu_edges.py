@@ -575,3 +575,55 @@ def test_im2col3x3_matches_unfold(torch_cuda):
         ca.backward(d)
         cb.backward(d)
         assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * (1.0 + float(xb.grad.abs().max()))
+
+
+def test_proposal_layer_two_pass_nms_equals_one_pass_and_oracle(torch_cuda):
+    """The proposal layer's NMS runs as a probe over the first candidates plus, for the images the
+    probe cannot settle, a completion pass (nms.hip: launch_nms_two_pass).  (a) Heavy suppression:
+    zero deltas make the proposals the anchors themselves, neighbours suppress each other, far
+    fewer than 2000 survive among the first 8192 candidates -> the completion pass runs; boxes are
+    exact (exp(0) = 1), so the rows must equal the oracle's.  (b) On the golden inputs both forms
+    give identical blobs.  (c) Mixed batch: one image settled by the probe, one not."""
+    import os
+    torch = torch_cuda
+    from wssdl_bus_amd.rpn_msr.proposal_layer_tf_bus import proposal_layer
+    rs = np.random.RandomState(23)
+    N, H, W, A = 2, 38, 63, 9
+    info = np.array([[600, 1000, 1.0, 1], [600, 1000, 1.0, 2]], np.float32)
+    prob = np.zeros((N, H, W, 2 * A), np.float32)
+    prob[..., A:] = rs.permutation(N * H * W * A).reshape(N, H, W, A).astype(np.float32) / (N * H * W * A) * 0.9 + 0.05
+    prob[..., :A] = 1 - prob[..., A:]
+    pred = np.zeros((N, H, W, 4 * A), np.float32)
+    pred[1] = rs.normal(0, 0.3, size=(H, W, 4 * A)).astype(np.float32)          # image 1: ordinary proposals
+
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    old_thresh = cfg.TRAIN.RPN_NMS_THRESH
+    cfg.TRAIN.RPN_NMS_THRESH = 0.3             # anchors of neighbouring cells suppress each other
+
+    def run(one_pass):
+        if one_pass:
+            os.environ["WSSDL_NMS_ONE_PASS"] = "1"
+        try:
+            return proposal_layer(prob, pred, info, True, False)
+        finally:
+            os.environ.pop("WSSDL_NMS_ONE_PASS", None)
+    try:
+        two, one = run(False), run(True)
+    finally:
+        cfg.TRAIN.RPN_NMS_THRESH = old_thresh
+    assert np.array_equal(two, one)
+    n0 = int((two[:, 0] == 0).sum())
+    assert 0 < n0 < 2000                       # image 0 needed every candidate (completion pass)
+    want = O.proposal_layer(prob[:1], pred[:1], info[:1], True, False, STRIDE, SCALES,
+                            cfg=dict(TRAIN_RPN_NMS_THRESH=0.3))
+    assert np.array_equal(two[:n0], want)
+    g = load_golden("proposal_layer")
+    for case in ("res_38x63_train", "res_63x100_test"):
+        prob_g, pred_g, info_g = g[case + "/prob"], g[case + "/pred"], g[case + "/im_info"]
+        train = bool(g[case + "/is_training"])
+        os.environ["WSSDL_NMS_ONE_PASS"] = "1"
+        try:
+            a = proposal_layer(prob_g, pred_g, info_g, train, False)
+        finally:
+            os.environ.pop("WSSDL_NMS_ONE_PASS", None)
+        assert np.array_equal(proposal_layer(prob_g, pred_g, info_g, train, False), a)

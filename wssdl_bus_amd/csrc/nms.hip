@@ -311,10 +311,15 @@ constexpr int MASK_SEG = 16;     // column blocks per workgroup
 __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
     const float *__restrict__ boxes, int box_stride_img, const int *__restrict__ n_dev, int n_max,
     double thresh, unsigned long long *__restrict__ mask, int ncb,
-    unsigned long long *__restrict__ diag_t, unsigned long long *__restrict__ summ, int sw) {
+    unsigned long long *__restrict__ diag_t, unsigned long long *__restrict__ summ, int sw,
+    int n_limit, int cb_min, const int *__restrict__ done) {
     const int rb = blockIdx.x, seg = blockIdx.y, img = blockIdx.z;
-    const int n = min(n_dev[img], n_max);
-    if (rb * 64 >= n || (seg + 1) * MASK_SEG <= rb || seg * MASK_SEG * 64 >= n) return;
+    // two-pass use (launch_nms_two_pass): the first pass covers the candidates below n_limit only,
+    // the second one the column blocks >= cb_min of the images the first pass could not finish
+    if (done && done[img]) return;
+    const int n = min(min(n_dev[img], n_max), n_limit);
+    const int cb_first = max(rb, cb_min);
+    if (rb * 64 >= n || (seg + 1) * MASK_SEG <= cb_first || seg * MASK_SEG * 64 >= n) return;
     __shared__ float cbox[MASK_WAVES][5][64];
     const float *b = boxes + (size_t)img * box_stride_img;
     // wave index through readfirstlane: the column-block loop and its trip counts are then
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
     const float iarea = box_area_ref(ix1, iy1, ix2, iy2);
     const float t_lo = (float)(thresh * (1.0 - 1e-4)), t_hi = (float)(thresh * (1.0 + 1e-4));
     const int cb_end = min((n + 63) / 64, (seg + 1) * MASK_SEG);
-    for (int cb = max(rb, seg * MASK_SEG) + wave; cb < cb_end; cb += MASK_WAVES) {
+    for (int cb = max(cb_first, seg * MASK_SEG) + wave; cb < cb_end; cb += MASK_WAVES) {
         const int col = cb * 64 + lane;
         float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
         if (col < n) { x1 = b[col * 4 + 0]; y1 = b[col * 4 + 1]; x2 = b[col * 4 + 2]; y2 = b[col * 4 + 3]; }
@@ -410,15 +415,18 @@ int nms_summary_words(int n_max) { return cdiv(cdiv(n_max, 64), 64); }
 
 int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, int n_max,
                     int n_images, double thresh, unsigned long long *mask,
-                    unsigned long long *diag_t, unsigned long long *summ, hipStream_t st) {
+                    unsigned long long *diag_t, unsigned long long *summ, hipStream_t st,
+                    int n_limit, int cb_min, const int *done) {
     int ncb = cdiv(n_max, 64);
     if (ncb == 0 || n_images == 0) return WSSDL_OK;
     const int sw = nms_summary_words(n_max);
-    if (summ && hipMemsetAsync(summ, 0, sizeof(unsigned long long) * (size_t)n_images * n_max * sw, st) !=
-                    hipSuccess)
+    // (the second pass of a two-pass run adds to the summary of the first)
+    if (summ && cb_min == 0 &&
+        hipMemsetAsync(summ, 0, sizeof(unsigned long long) * (size_t)n_images * n_max * sw, st) != hipSuccess)
         return WSSDL_ERR_LAUNCH;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(ncb, cdiv(ncb, MASK_SEG), n_images), dim3(64 * MASK_WAVES), 0, st, boxes,
-                       box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, sw);
+    const int ncb_eff = cdiv(min(n_max, n_limit), 64);      // row / column blocks this pass can touch
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(ncb_eff, cdiv(ncb_eff, MASK_SEG), n_images), dim3(64 * MASK_WAVES), 0, st,
+                       boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, sw, n_limit, cb_min, done);
     return check_launch();
 }
 
@@ -473,8 +481,9 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_kernel(
     int max_keep, const int *__restrict__ order, int order_stride_img,
     int *__restrict__ keep, int *__restrict__ num_keep,
     const float *__restrict__ boxes, int box_stride_img, float *__restrict__ rois_padded,
-    int *__restrict__ kept_scratch) {
-    extern __shared__ int kept_lds[];                // [max_keep + 64] rows kept so far, in order
+    int *__restrict__ kept_scratch, int n_limit, const int *__restrict__ done_in, int *__restrict__ done_out) {
+    extern __shared__ int kept_lds[];
+    if (done_in && done_in[blockIdx.x]) return;                // [max_keep + 64] rows kept so far, in order
     // (global scratch instead when the list does not fit in LDS: same-CU visibility after the
     // workgroup barrier is all that is needed)
     int *kept_rows = kept_scratch ? kept_scratch + (size_t)blockIdx.x * (max_keep + 64) : kept_lds;
@@ -482,7 +491,7 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_kernel(
     __shared__ unsigned long long s_own[2];          // wave 0's contribution for the next chunk
     __shared__ int s_count;
     const int img = blockIdx.x;
-    const int n = min(n_dev[img], n_max);
+    const int n = min(min(n_dev[img], n_max), n_limit);
     const unsigned long long *m = mask + (size_t)img * n_max * ncb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NHELP = SWEEP_BLOCK - 64;
@@ -561,7 +570,10 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_kernel(
         count = s_count;
         if (count >= max_keep) break;
     }
-    if (tid == 0) num_keep[img] = min(count, max_keep);
+    if (tid == 0) {
+        num_keep[img] = min(count, max_keep);
+        if (done_out) done_out[img] = (count >= max_keep || n_dev[img] <= n_limit) ? 1 : 0;
+    }
 }
 
 
@@ -621,15 +633,17 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(
     const int *__restrict__ n_dev, int n_max, int ncb,
     int max_keep, const int *__restrict__ order, int order_stride_img,
     int *__restrict__ keep, int *__restrict__ num_keep,
-    const float *__restrict__ boxes, int box_stride_img, float *__restrict__ rois_padded) {
+    const float *__restrict__ boxes, int box_stride_img, float *__restrict__ rois_padded,
+    int n_limit, const int *__restrict__ done_in, int *__restrict__ done_out) {
     extern __shared__ unsigned long long sweep_dyn[];
+    if (done_in && done_in[blockIdx.x]) return;
     // dynamic LDS: per kept box the summary of its non-zero mask words [max_keep + 64][sw], then
     // the kept list [max_keep + 64]
     unsigned long long *ksum = sweep_dyn;
     int *kept_rows = reinterpret_cast<int *>(sweep_dyn + (size_t)(max_keep + 64) * sw);
     __shared__ SweepShared sh;
     const int img = blockIdx.x;
-    const int n = min(n_dev[img], n_max);
+    const int n = min(min(n_dev[img], n_max), n_limit);
     const int nchunks = (n + 63) / 64;
     const unsigned long long *m = mask + (size_t)img * n_max * ncb;
     const unsigned long long *dt = diag_t + (size_t)img * n_max;
@@ -798,14 +812,17 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(
         flush();
         if (((last + 1) & 1) == group) { expand(last); flush(); }
     }
-    if (tid == 0) num_keep[img] = min(count, max_keep);
+    if (tid == 0) {
+        num_keep[img] = min(count, max_keep);
+        if (done_out) done_out[img] = (count >= max_keep || n_dev[img] <= n_limit) ? 1 : 0;
+    }
 }
 
 int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *diag_t,
                      const unsigned long long *summ, const int *n_dev, int n_max, int n_images,
                      int max_keep, const int *order, int order_stride_img, int *keep,
                      int *num_keep, const float *boxes, int box_stride_img, float *rois_padded,
-                     int *kept_scratch, hipStream_t st) {
+                     int *kept_scratch, hipStream_t st, int n_limit, const int *done_in, int *done_out) {
     int ncb = cdiv(n_max, 64);
     if (n_images == 0) return WSSDL_OK;
     size_t lds = ((size_t)max_keep + 64) * sizeof(int);
@@ -815,7 +832,7 @@ int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *d
         n_max < (1 << 24) && (long long)n_max * ncb < (1LL << 31)) {
         hipLaunchKernelGGL(nms_sweep_pipelined_kernel, dim3(n_images), dim3(SWEEP_BLOCK), lds_p, st,
                            mask, diag_t, summ, sw, n_dev, n_max, ncb, max_keep, order, order_stride_img,
-                           keep, num_keep, boxes, box_stride_img, rois_padded);
+                           keep, num_keep, boxes, box_stride_img, rois_padded, n_limit, done_in, done_out);
         return check_launch();
     }
     if (lds > SWEEP_LDS_LIMIT) {
@@ -826,8 +843,51 @@ int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *d
     }
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(n_images), dim3(SWEEP_BLOCK), lds, st, mask, n_dev,
                        n_max, ncb, max_keep, order, order_stride_img, keep, num_keep, boxes,
-                       box_stride_img, rois_padded, kept_scratch);
+                       box_stride_img, rois_padded, kept_scratch, n_limit, done_in, done_out);
     return check_launch();
+}
+
+// Greedy NMS only ever consults the rows of KEPT boxes and stops after max_keep of them: with
+// 12000 candidates and 2000 to keep the sweep ends around candidate 4700-7000, yet the mask
+// kernel (the largest piece of the proposal chain, VALU-bound) tests all 72 M pairs.  Two
+// passes: (1) mask + sweep over the first `probe` candidates only; an image is done when that
+// kept max_keep boxes or had no more candidates; (2) for the other images the mask kernel adds
+// the column blocks beyond the probe (rows below it re-use pass 1's words) and the sweep runs
+// again over everything.  Both passes of pass 2 return at once for finished images, so the usual
+// case costs (probe / n)^2 of the pair tests plus two empty launches, the worst case one extra sweep.
+int nms_probe_size(int n_max, int max_keep) {
+    long long p = ((long long)max_keep * 4 + 1023) / 1024 * 1024;      // whole mask segments (16 x 64)
+    if (p < 2048) p = 2048;
+    return (p * 4 <= (long long)n_max * 3) ? (int)p : n_max;            // not worth it above 3/4 n
+}
+
+int launch_nms_two_pass(const float *boxes, int box_stride_img, const int *n_dev, int n_max, int n_images,
+                        double thresh, unsigned long long *mask, unsigned long long *diag_t,
+                        unsigned long long *summ, int max_keep, const int *order, int order_stride_img,
+                        int *keep, int *num_keep, float *rois_padded, int *kept_scratch, int *done,
+                        hipStream_t st) {
+    const int probe = done ? nms_probe_size(n_max, max_keep) : n_max;
+    const int NO_LIMIT = 0x7fffffff;
+    int rc;
+    if (probe >= n_max) {
+        if ((rc = launch_nms_mask(boxes, box_stride_img, n_dev, n_max, n_images, thresh, mask, diag_t, summ, st,
+                                  NO_LIMIT, 0, nullptr)))
+            return rc;
+        return launch_nms_sweep(mask, diag_t, summ, n_dev, n_max, n_images, max_keep, order, order_stride_img, keep,
+                                num_keep, boxes, box_stride_img, rois_padded, kept_scratch, st, NO_LIMIT, nullptr,
+                                nullptr);
+    }
+    if ((rc = launch_nms_mask(boxes, box_stride_img, n_dev, n_max, n_images, thresh, mask, diag_t, summ, st, probe, 0,
+                              nullptr)))
+        return rc;
+    if ((rc = launch_nms_sweep(mask, diag_t, summ, n_dev, n_max, n_images, max_keep, order, order_stride_img, keep,
+                               num_keep, boxes, box_stride_img, rois_padded, kept_scratch, st, probe, nullptr, done)))
+        return rc;
+    if ((rc = launch_nms_mask(boxes, box_stride_img, n_dev, n_max, n_images, thresh, mask, diag_t, summ, st, NO_LIMIT,
+                              probe / 64, done)))
+        return rc;
+    return launch_nms_sweep(mask, diag_t, summ, n_dev, n_max, n_images, max_keep, order, order_stride_img, keep,
+                            num_keep, boxes, box_stride_img, rois_padded, kept_scratch, st, NO_LIMIT, done, nullptr);
 }
 
 // ------------------------------------------------------- standalone nms entry ---
@@ -907,8 +967,8 @@ extern "C" int wssdl_nms(const float *dets, int n, double thresh, int max_keep, 
                        w.n_sorted, n, w.boxes);
     rc = check_launch();
     if (rc) return rc;
-    rc = launch_nms_mask(w.boxes, n * 4, w.n_sorted, n, 1, thresh, w.mask, w.cand, w.summ, st);
+    rc = launch_nms_mask(w.boxes, n * 4, w.n_sorted, n, 1, thresh, w.mask, w.cand, w.summ, st, 0x7fffffff, 0, nullptr);
     if (rc) return rc;
     return launch_nms_sweep(w.mask, w.cand, w.summ, w.n_sorted, n, 1, max_keep, w.order, n, keep, num_keep,
-                            nullptr, 0, nullptr, w.kept, st);
+                            nullptr, 0, nullptr, w.kept, st, 0x7fffffff, nullptr, nullptr);
 }

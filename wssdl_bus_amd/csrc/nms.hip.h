@@ -34,7 +34,8 @@ int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int to
 int nms_summary_words(int n_max);
 int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, int n_max,
                     int n_images, double thresh, unsigned long long *mask,
-                    unsigned long long *diag_t, unsigned long long *summ, hipStream_t st);
+                    unsigned long long *diag_t, unsigned long long *summ, hipStream_t st,
+                    int n_limit, int cb_min, const int *done);
 
 // keep (optional) [n_images, max_keep] i32; rois_padded (optional) [n_images, max_keep, 5];
 // kept_scratch [n_images, max_keep + 64] i32: only needed when the kept list does not fit in
@@ -43,6 +44,15 @@ int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *d
                      const unsigned long long *summ, const int *n_dev, int n_max, int n_images,
                      int max_keep, const int *order, int order_stride_img, int *keep,
                      int *num_keep, const float *boxes, int box_stride_img, float *rois_padded,
-                     int *kept_scratch, hipStream_t st);
+                     int *kept_scratch, hipStream_t st, int n_limit, const int *done_in, int *done_out);
+
+// mask + sweep in two passes (a probe over the first candidates, then the rest for the images that
+// need it); `done` [n_images] i32 scratch, NULL = one pass.  See nms.hip.
+int nms_probe_size(int n_max, int max_keep);
+int launch_nms_two_pass(const float *boxes, int box_stride_img, const int *n_dev, int n_max, int n_images,
+                        double thresh, unsigned long long *mask, unsigned long long *diag_t,
+                        unsigned long long *summ, int max_keep, const int *order, int order_stride_img,
+                        int *keep, int *num_keep, float *rois_padded, int *kept_scratch, int *done,
+                        hipStream_t st);
 
 }  // namespace wssdl

@@ -15,6 +15,8 @@
 // accurate to ~2.5 ulp, so decoded boxes are tolerance-level by nature).
 #include "nms.hip.h"
 
+#include <stdlib.h>
+
 namespace wssdl {
 
 typedef float float4v __attribute__((ext_vector_type(4)));
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void proposal_compact_kernel(
 struct ProposalWs {
     unsigned long long *keys, *cand, *thresh, *mask, *summ;
     float *boxes, *sorted_boxes;
-    int *sorted_index, *n_sorted, *cand_fill, *kept;
+    int *sorted_index, *n_sorted, *cand_fill, *kept, *done;
 };
 
 static size_t carve_proposal(void *ws, int N, int M, int topn, ProposalWs *out) {
@@ -119,6 +121,7 @@ static size_t carve_proposal(void *ws, int N, int M, int topn, ProposalWs *out) 
     w.sorted_index = c.take<int>((size_t)N * topn);
     w.n_sorted = c.take<int>((size_t)N + 64);
     w.cand_fill = c.take<int>((size_t)N + 64);
+    w.done = c.take<int>((size_t)N + 64);
     w.thresh = c.take<unsigned long long>((size_t)N + 32);
     w.cand = c.take<unsigned long long>((size_t)N * topn);
     w.kept = c.take<int>((size_t)N * ((size_t)topn + 64));
@@ -194,13 +197,12 @@ static int proposal_layer_impl(int from_logits, const float *rpn_cls_prob, const
                        sidx, nsorted, M, topn, w.sorted_boxes);
     if ((rc = check_launch())) return rc;
     // w.cand is free once the ranking is done: it receives the transposed diagonal blocks
-    if ((rc = launch_nms_mask(w.sorted_boxes, topn * 4, nsorted, topn, N, nms_thresh, w.mask, w.cand, w.summ, st)))
-        return rc;
-    // the sweep writes (batch_idx, box) rows straight into rois_padded and stops
-    // after `pitch` kept boxes
-    if ((rc = launch_nms_sweep(w.mask, w.cand, w.summ, nsorted, topn, N, pitch, nullptr, 0, nullptr, roi_counts,
-                               w.sorted_boxes, topn * 4, rois_padded,
-                               pitch <= topn ? w.kept : nullptr, st)))
+    // mask + sweep (two passes when a probe over the first candidates can settle an image, nms.hip);
+    // the sweep writes (batch_idx, box) rows straight into rois_padded and stops after `pitch` kept boxes
+    const bool one_pass = getenv("WSSDL_NMS_ONE_PASS") != nullptr;       // tuning / A-B comparisons
+    if ((rc = launch_nms_two_pass(w.sorted_boxes, topn * 4, nsorted, topn, N, nms_thresh, w.mask, w.cand, w.summ, pitch,
+                                  nullptr, 0, nullptr, roi_counts, rois_padded, pitch <= topn ? w.kept : nullptr,
+                                  one_pass ? nullptr : w.done, st)))
         return rc;
     if (sorted_index &&
         hipMemcpyAsync(sorted_index, sidx, sizeof(int) * (size_t)N * topn, hipMemcpyDeviceToDevice,
