@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_compact_kernel(
 // loads removed, 0.59 ms with the stores removed, 0.72 ms together at R = 8512 for 2.2 GB of
 // HBM traffic -- instruction issue, not bandwidth; this form: 0.44 / 0.63 / 0.59 ms).  Channel
 // slice <-> blockIdx % 8 as above (without the slicing: 1.13 ms).  Tried without gain: four
-// cells in flight, 7 rows (one RoI) per workgroup, plain instead of non-temporal stores (+5-10 %).
+// cells in flight, 7 rows (one RoI) per workgroup, plain instead of non-temporal stores (+5-10 %);
+// 512 channels per wave (coarser L2 slices): 0.80 ms; the stores alone take 0.32-0.37 ms.
 template <int CPL>
 struct LaneVec;
 template <>
@@ -215,7 +216,11 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
         unsigned mi[CPL];
 #pragma unroll
         for (int k = 0; k < CPL; ++k) { mv[k] = empty ? 0.0f : -FLT_MAX;  mi[k] = ARG8_EMPTY; }
+#if WSSDL_FWDC_ABLATE == 3
+        if (false) {
+#else
         if (!empty) {
+#endif
             if ((he - hs > ARG8_MAX_WIN_H || we - ws > ARG8_MAX_WIN_W) && overflow && lane == 0) atomicOr(overflow, 1);
             for (int h = hs; h < he; ++h) {
                 const int so_row = h * W * cell_bytes;

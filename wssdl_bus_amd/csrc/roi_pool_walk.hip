@@ -43,7 +43,6 @@ namespace wssdl {
 
 constexpr unsigned ARG8_EMPTY_W = 0xffu;
 constexpr int WALK_SLOTS = 8;            // slots per record (64 B)
-constexpr int WALK_CH = 128;             // channels per wave (2 per lane)
 
 __device__ __forceinline__ int win_start_w(int p, float bin, int rs, int limit, int rounding) {
     const float v = (float)p * bin;
@@ -333,9 +332,10 @@ struct SlotRec {                 // one record = 8 slots, wave-uniform (scalar r
     unsigned hi[WALK_SLOTS];     // masks and window offsets
 };
 
+template <int CPL>
 struct SlotData {                // what a lane holds of one record
-    unsigned a[WALK_SLOTS];      // two 1-byte codes
-    float2v td[WALK_SLOTS];      // two top_diff values
+    unsigned a[WALK_SLOTS];      // CPL 1-byte codes
+    float td[WALK_SLOTS][CPL];   // CPL top_diff values
 };
 
 // a record is fetched by lanes 0..15 (one dword each) and broadcast with v_readlane: that keeps the
@@ -358,17 +358,24 @@ __device__ __forceinline__ SlotRec spread_rec(unsigned v, bool valid, unsigned t
     return r;
 }
 
-__device__ __forceinline__ void issue_rec(SlotData &d, const SlotRec &r, __amdgpu_buffer_rsrc_t ra,
+template <int CPL>
+__device__ __forceinline__ void issue_rec(SlotData<CPL> &d, const SlotRec &r, __amdgpu_buffer_rsrc_t ra,
                                           __amdgpu_buffer_rsrc_t rt, int voff8, int voff) {
 #pragma unroll
     for (int s = 0; s < WALK_SLOTS; ++s) {
-        d.a[s] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(ra, voff8, (int)r.lo[s], 0);
-        d.td[s] = __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(rt, voff, (int)(r.lo[s] << 2), 0));
+        if (CPL == 2) {
+            d.a[s] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(ra, voff8, (int)r.lo[s], 0);
+            const float2v t = __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(rt, voff, (int)(r.lo[s] << 2), 0));
+            d.td[s][0] = t.x;  d.td[s][CPL - 1] = t.y;
+        } else {
+            d.a[s] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(ra, voff8, (int)r.lo[s], 0);
+            d.td[s][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, voff, (int)(r.lo[s] << 2), 0));
+        }
     }
 }
 
-template <int TH, int TW>
-__device__ __forceinline__ void process_rec(const SlotData &d, const SlotRec &r, float *acc, int lane, bool lane_ok) {
+template <int TH, int TW, int CPL>
+__device__ __forceinline__ void process_rec(const SlotData<CPL> &d, const SlotRec &r, float *acc, int lane, bool lane_ok) {
     constexpr int DUMMY = TH * TW;
 #pragma unroll
     for (int s = 0; s < WALK_SLOTS; ++s) {
@@ -376,10 +383,10 @@ __device__ __forceinline__ void process_rec(const SlotData &d, const SlotRec &r,
         const unsigned rm = w & 0xffu, cm = (w >> 8) & 0xffu;
         const int hs = ((int)(w << 11)) >> 27, ws = ((int)(w << 6)) >> 27;     // sign-extended 5-bit fields
         const unsigned a = d.a[s];
-        int idx[2];
-        float val[2];
+        int idx[CPL];
+        float val[CPL];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < CPL; ++p) {
             const unsigned code = (a >> (8 * p)) & 0xffu;
             const int th = hs + (int)(code >> 4), tw = ws + (int)(code & 15u);
             // tile, in_roi and candidate-bin tests: the masks have no bits where a cell outside the
@@ -387,12 +394,14 @@ __device__ __forceinline__ void process_rec(const SlotData &d, const SlotRec &r,
             const unsigned bits = (rm >> (th & 31)) & (cm >> (tw & 31)) & 1u;
             const bool ok = (bits != 0u) & (code != ARG8_EMPTY_W) & lane_ok;
             const int cell = ok ? th * TW + tw : DUMMY;
-            idx[p] = (cell * 2 + p) * 64 + lane;
+            idx[p] = (cell * CPL + p) * 64 + lane;
             val[p] = ok ? d.td[s][p] : 0.0f;
         }
-        const float v0 = acc[idx[0]], v1 = acc[idx[1]];
-        acc[idx[0]] = v0 + val[0];
-        acc[idx[1]] = v1 + val[1];
+        float v[CPL];
+#pragma unroll
+        for (int p = 0; p < CPL; ++p) v[p] = acc[idx[p]];
+#pragma unroll
+        for (int p = 0; p < CPL; ++p) acc[idx[p]] = v[p] + val[p];
     }
 }
 
@@ -405,14 +414,14 @@ unsigned long long *g_walk_trace = nullptr;
 #define WSSDL_WALK_TRACE_ARG
 #endif
 
-template <int TH, int TW, int DEPTH, int MINW>
+template <int TH, int TW, int DEPTH, int MINW, int CPL>
 __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
     const float *__restrict__ top_diff, const unsigned char *__restrict__ arg8,
     const unsigned *__restrict__ slots, const int *__restrict__ tile_off, const int *__restrict__ tile_slots,
     const int *__restrict__ order, int items, int tiles_w, int tiles, int G, int H, int W, int C,
     unsigned total_elems, float *__restrict__ bottom_diff WSSDL_WALK_TRACE_PARAM) {
     static_assert(TH <= 8 && TW <= 8 && DEPTH >= 2 && DEPTH <= 4, "8-bit masks; 2..4 records in flight");
-    __shared__ float acc[(TH * TW + 1) * 2 * 64];
+    __shared__ float acc[(TH * TW + 1) * CPL * 64];
 #if WSSDL_BWDC_TRACE
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -423,8 +432,10 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
     const int b = blockIdx.x;
     int k, g;
     if ((G & 7) == 0) {
+        // consecutive channel groups on one XCD (they share the 128-byte lines of the codes when a
+        // group is only 64 channels wide)
         const int per = G >> 3, q = b >> 3;
-        g = (b & 7) + 8 * (q % per);
+        g = (b & 7) * per + (q % per);
         k = q / per;
     } else if (G < 8 && (8 % G) == 0) {
         const int share = 8 / G, x = b & 7;
@@ -440,12 +451,12 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
     const int ty = tile / tiles_w, tx = tile - ty * tiles_w;
     const int h0 = ty * TH, w0 = tx * TW;
     const int lane = threadIdx.x;
-    const int c0 = g * WALK_CH + 2 * lane;
+    const int c0 = g * (64 * CPL) + CPL * lane;
     const bool lane_ok = c0 < C;
     const int cl = lane_ok ? c0 : 0;
 
 #pragma unroll
-    for (int i = 0; i < (TH * TW + 1) * 2; ++i) acc[i * 64 + lane] = 0.0f;
+    for (int i = 0; i < (TH * TW + 1) * CPL; ++i) acc[i * 64 + lane] = 0.0f;
 
     const int nrec = (tile_slots[item] + WALK_SLOTS - 1) / WALK_SLOTS;
     const unsigned *rp = slots + (size_t)tile_off[item] * 16;
@@ -458,7 +469,7 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
     // DEPTH records in flight: while record i is accumulated the data of records i+1 .. i+DEPTH-1
     // and the descriptor of record i+DEPTH travel.  r[j] describes the data in d[j].
     SlotRec r[DEPTH];
-    SlotData d[DEPTH];
+    SlotData<CPL> d[DEPTH];
 #pragma unroll
     for (int j = 0; j < DEPTH - 1; ++j) {
         r[j] = spread_rec(fetch_rec(rp, j, nrec, lane), j < nrec, total_elems);
@@ -473,7 +484,7 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
             const unsigned next = fetch_rec(rp, i + j + DEPTH, nrec, lane);
             r[x] = spread_rec(pending, i + j + DEPTH - 1 < nrec, total_elems);
             issue_rec(d[x], r[x], ra, rt, voff8, voff);
-            process_rec<TH, TW>(d[j], r[j], acc, lane, lane_ok);
+            process_rec<TH, TW, CPL>(d[j], r[j], acc, lane, lane_ok);
             pending = next;
         }
     }
@@ -484,10 +495,14 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
         for (int i = 0; i < TH * TW; ++i) {
             const int h = h0 + i / TW, w = w0 + i % TW;
             if (h < H && w < W) {
-                float2v o;
-                o.x = acc[(i * 2) * 64 + lane];
-                o.y = acc[(i * 2 + 1) * 64 + lane];
-                *reinterpret_cast<float2v *>(img + ((size_t)h * W + w) * C + c0) = o;
+                if (CPL == 2) {
+                    float2v o;
+                    o.x = acc[(i * CPL) * 64 + lane];
+                    o.y = acc[(i * CPL + CPL - 1) * 64 + lane];
+                    *reinterpret_cast<float2v *>(img + ((size_t)h * W + w) * C + c0) = o;
+                } else {
+                    img[((size_t)h * W + w) * C + c0] = acc[i * 64 + lane];
+                }
             }
         }
     }
@@ -502,7 +517,7 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
 
 // A plan = tile shape, records in flight and the waves per SIMD the launch bounds ask for.
 // WSSDL_ROI_BWD_PLAN (tuning) overrides the default.
-constexpr int WALK_PLANS = 6;
+constexpr int WALK_PLANS = 9;
 constexpr int WALK_DEFAULT_PLAN = 1;
 
 static int walk_plan_from_env() {
@@ -514,7 +529,7 @@ static int walk_plan_from_env() {
 }
 
 static void plan_shape(int plan, int *th, int *tw) {
-    static const int shapes[WALK_PLANS][2] = {{4, 4}, {4, 8}, {8, 8}, {4, 8}, {8, 8}, {4, 4}};
+    static const int shapes[WALK_PLANS][2] = {{4, 4}, {4, 8}, {8, 8}, {4, 8}, {8, 8}, {4, 4}, {8, 8}, {8, 8}, {8, 8}};
     *th = shapes[plan][0];
     *tw = shapes[plan][1];
 }
@@ -570,7 +585,7 @@ int walk_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, i
     return rc;
 }
 
-template <int TH, int TW, int DEPTH, int MINW>
+template <int TH, int TW, int DEPTH, int MINW, int CPL>
 static int launch_walk_t(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C,
                          int PH, int PW, float *bottom_diff, void *workspace, size_t workspace_bytes,
                          hipStream_t st) {
@@ -580,13 +595,13 @@ static int launch_walk_t(const float *top_diff, const unsigned char *arg8, int R
     if (carve_walk(workspace, R, N, tiles_h, tiles_w, walk_record_bound(R, N, H, W, PH, PW, TH, TW), &ws) > workspace_bytes)
         return WSSDL_ERR_WORKSPACE;
     const unsigned total_elems = (unsigned)((long long)R * PH * PW * C);
-    const int G = cdiv(C, WALK_CH);
+    const int G = cdiv(C, 64 * CPL);
     long long blocks;
     if ((G & 7) == 0) blocks = (long long)items * G;
     else if (G < 8 && (8 % G) == 0) blocks = 8LL * cdiv(items, 8 / G);
     else blocks = (long long)items * G;
     if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<TH, TW, DEPTH, MINW>), dim3((unsigned)blocks), dim3(64), 0, st,
+    hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<TH, TW, DEPTH, MINW, CPL>), dim3((unsigned)blocks), dim3(64), 0, st,
                        top_diff, arg8, reinterpret_cast<const unsigned *>(ws.slots), ws.tile_off, ws.tile_slots,
                        ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff WSSDL_WALK_TRACE_ARG);
     return check_launch();
@@ -594,16 +609,19 @@ static int launch_walk_t(const float *top_diff, const unsigned char *arg8, int R
 
 int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH,
                 int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, hipStream_t st) {
-#define WSSDL_WALK(TH, TW, DEPTH, MINW) \
-    launch_walk_t<TH, TW, DEPTH, MINW>(top_diff, arg8, R, N, H, W, C, PH, PW, bottom_diff, workspace, \
-                                       workspace_bytes, st)
+#define WSSDL_WALK(TH, TW, DEPTH, MINW, CPL) \
+    launch_walk_t<TH, TW, DEPTH, MINW, CPL>(top_diff, arg8, R, N, H, W, C, PH, PW, bottom_diff, workspace, \
+                                            workspace_bytes, st)
     switch (plan) {
-        case 0: return WSSDL_WALK(4, 4, 2, 5);
-        case 1: return WSSDL_WALK(4, 8, 2, 2);
-        case 2: return WSSDL_WALK(8, 8, 3, 1);
-        case 3: return WSSDL_WALK(4, 8, 3, 2);
-        case 4: return WSSDL_WALK(8, 8, 4, 1);
-        case 5: return WSSDL_WALK(4, 4, 3, 4);
+        case 0: return WSSDL_WALK(4, 4, 2, 5, 2);
+        case 1: return WSSDL_WALK(4, 8, 2, 2, 2);
+        case 2: return WSSDL_WALK(8, 8, 3, 1, 2);
+        case 3: return WSSDL_WALK(4, 8, 3, 2, 2);
+        case 4: return WSSDL_WALK(8, 8, 4, 1, 2);
+        case 5: return WSSDL_WALK(4, 4, 3, 4, 2);
+        case 6: return WSSDL_WALK(8, 8, 4, 2, 1);       // one channel per lane: 8x8 tiles at 4x8's LDS
+        case 7: return WSSDL_WALK(8, 8, 3, 2, 1);
+        case 8: return WSSDL_WALK(8, 8, 2, 2, 1);
         default: return WSSDL_ERR_INVALID_ARGUMENT;
     }
 #undef WSSDL_WALK
