@@ -627,3 +627,45 @@ def test_proposal_layer_two_pass_nms_equals_one_pass_and_oracle(torch_cuda):
         finally:
             os.environ.pop("WSSDL_NMS_ONE_PASS", None)
         assert np.array_equal(proposal_layer(prob_g, pred_g, info_g, train, False), a)
+
+
+# ------------------------------------------------ NMS: the geometric prefilter's corners ---
+def test_nms_prefilter_thresholds_and_degenerate_boxes(torch_cuda):
+    """The mask kernel only runs the exact overlap rule (cpu_nms.pyx:43-66) on pairs whose centres
+    are close enough to reach the threshold at all (0.25 <= thresh < 1).  Cases that sit on that
+    filter's edges: thresholds at and around the range limits, pairs whose overlap equals the
+    threshold, boxes with non-positive width or height (negative 'areas': the reference still
+    computes with them), exact duplicates, boxes far from the origin (centre rounding), and the
+    same workspace re-used with a different threshold (words of the earlier call that are zero
+    now are not rewritten and must not be read)."""
+    from wssdl_bus_amd.nms.hip_nms import hip_nms
+    rs = np.random.RandomState(11)
+    n = 3000
+    c = rs.uniform(0, 600, size=(n, 2))
+    wh = np.exp(rs.uniform(np.log(4), np.log(400), size=(n, 2)))
+    b = np.hstack((c - wh / 2, c + wh / 2))
+    # degenerate rows: swapped corners, zero and negative extents
+    bad = rs.choice(n, 200, replace=False)
+    b[bad[:80], 2] = b[bad[:80], 0] - rs.uniform(0, 30, 80)            # x2 < x1
+    b[bad[80:140], 3] = b[bad[80:140], 1] - 1.0                        # height exactly 0
+    b[bad[140:], 2:] = b[bad[140:], :2] - rs.uniform(1, 50, (60, 2))   # both negative
+    # duplicates and near-duplicates of other rows
+    b[100:200] = b[0:100]
+    b[200:300] = b[0:100] + rs.uniform(-1, 1, (100, 4))
+    d = np.hstack((b, rs.permutation(n)[:, None] / float(n))).astype(np.float32)
+    for th in (0.95, 0.3, 0.25, 0.2499, 0.5, 0.7, 0.999, 1.0, 1.0001, 0.05):
+        assert hip_nms(d, th) == O.nms(d, th), th
+    # far from the origin: centres near 1e5 px, where f32 spacing is ~0.008 px
+    d2 = d.copy()
+    d2[:, :4] += np.float32(1e5)
+    for th in (0.3, 0.7):
+        assert hip_nms(d2, th) == O.nms(d2, th), th
+    # pairs whose overlap is exactly the threshold: width-w boxes shifted so that inter/union = 1/2, 1/3, 3/4
+    rows = []
+    for w, s in ((30, 10), (40, 20), (70, 10), (9, 3), (64, 32), (100, 25)):
+        rows += [[0, 0, w - 1, 9], [s, 0, s + w - 1, 9]]
+    e = np.array(rows, np.float32)
+    e[:, [1, 3]] += 20.0 * (np.arange(len(e)) // 2)[:, None]
+    e = np.hstack((e, np.linspace(1, 0.5, len(e), dtype=np.float32)[:, None]))
+    for th in (0.5, 1.0 / 3.0, 0.75, 0.6, 0.25, float(np.float32(0.5)), float(np.float32(1.0 / 3.0))):
+        assert hip_nms(e, th) == O.nms(e, th), th

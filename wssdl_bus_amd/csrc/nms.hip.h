@@ -26,7 +26,9 @@ int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int to
                      hipStream_t st);
 
 // boxes: per image [n_max, 4] f32 in score order (image stride box_stride_img floats);
-// mask: per image [n_max, ceil(n_max/64)] u64, upper triangle written.
+// mask: per image [n_max, ceil(n_max/64)] u64, upper triangle written -- every word when the sweep
+// for (n_max, max_keep) is the general one; only the non-zero words and the band next to the diagonal
+// when it is the pipelined one, which finds the others through summ.
 // diag_t (optional): per image [n_max] u64, for box i the boxes of ITS OWN 64-chunk with a lower
 // index that suppress it (the transposed diagonal block), consumed by the pipelined sweep.
 // summ (optional): per image [n_max, nms_summary_words(n_max)] u64, bit w of a row = its mask
@@ -35,7 +37,7 @@ int nms_summary_words(int n_max);
 int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, int n_max,
                     int n_images, double thresh, unsigned long long *mask,
                     unsigned long long *diag_t, unsigned long long *summ, hipStream_t st,
-                    int n_limit, int cb_min, const int *done);
+                    int n_limit, int cb_min, const int *done, int max_keep);
 
 // keep (optional) [n_images, max_keep] i32; rois_padded (optional) [n_images, max_keep, 5];
 // kept_scratch [n_images, max_keep + 64] i32: only needed when the kept list does not fit in
