@@ -48,9 +48,10 @@ def test_compact_pair_vs_oracle(torch_cuda, shape, mode):
     rois = _rois_for(rs, R, N, H, W)
     et, ea = c_oracle.roi_pool_forward(f, rois, 7, 7, 1.0 / 16, mode, threads=16)
     ft, rt = torch.from_numpy(f).cuda(), torch.from_numpy(rois).cuda()
-    # forward kernels: 0 = wave-uniform rows x 256 channels (default), 2 = x 128 channels, 3 = one RoI
-    # (7 rows) per workgroup, 9 = the two-rows-per-wave sliced kernel
-    for fwd in ("9", "3", "2", "0"):
+    # forward kernels: 0 = automatic (a whole RoI or one bin row per wave by launch size), 1 = one bin
+    # row per wave with a store per bin, 2 = 128-channel waves, 3 = one RoI (7 one-row waves) per
+    # workgroup, 4 = one bin row per wave, 5 = a whole RoI per wave, 9 = the two-rows-per-wave sliced kernel
+    for fwd in ("9", "3", "2", "1", "4", "5", "0"):
         os.environ["WSSDL_ROI_FWD_VARIANT"] = fwd
         try:
             top, arg8 = op.roi_pool_compact(ft, rt, 7, 7, 1.0 / 16, rounding=mode)

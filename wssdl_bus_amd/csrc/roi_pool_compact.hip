@@ -37,10 +37,14 @@ namespace wssdl {
 #define WSSDL_BWDC_ABLATE 0
 #endif
 
-// tuning builds only: -DWSSDL_FWDC_ABLATE=1 forward without its stores, =2 without its loads
+// tuning builds only: -DWSSDL_FWDC_ABLATE=1 forward without its stores, =2 without its loads,
+// =3 stores only (row-loop kernel), =4 loads + one v_max per value (no arg-max tracking),
+// =5 neither loads nor stores
 #ifndef WSSDL_FWDC_ABLATE
 #define WSSDL_FWDC_ABLATE 0
 #endif
+#define WSSDL_FWDC_NOLOAD (WSSDL_FWDC_ABLATE == 2 || WSSDL_FWDC_ABLATE == 5)
+#define WSSDL_FWDC_NOSTORE (WSSDL_FWDC_ABLATE == 1 || WSSDL_FWDC_ABLATE == 5)
 
 // tuning builds only (-DWSSDL_BWDC_TRACE=1): every workgroup of the backward records
 // (start, end) of s_memrealtime (100 MHz) and its record / bin counts into a buffer set with
@@ -163,7 +167,7 @@ template <>
 struct LaneVec<4> {
     typedef float4v vec;
     static __device__ __forceinline__ vec load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-#if WSSDL_FWDC_ABLATE == 2
+#if WSSDL_FWDC_NOLOAD
         return (vec)((float)(soff & 1023));
 #else
         return __builtin_bit_cast(vec, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
@@ -179,7 +183,8 @@ struct LaneVec<2> {
     }
 };
 
-template <int CPL, int RPW /* bin rows (waves) per workgroup */>
+template <int CPL, int RPW /* waves per workgroup */, int PWS /* PW when known at compile time, else 0 */,
+          bool WHOLE_ROI /* a wave walks all PH bin rows of one RoI instead of one bin row */>
 __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
     const float *__restrict__ bottom, int N, int H, int W, int C, const float *__restrict__ rois,
     int R, int PH, int PW, float scale, int rounding, float *__restrict__ top,
@@ -187,77 +192,140 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
     typedef typename LaneVec<CPL>::vec vec;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // blockIdx -> (channel slice, group of RPW rows): all groups of a slice share blockIdx % 8
+    // blockIdx -> (channel slice, group of RPW items): all groups of a slice share blockIdx % 8.
+    // (divisions by run-time values are ~20 VALU instructions each: shifts when `slices` is a power
+    // of two, a constant divisor when PH == PWS)
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const bool pow2 = (slices & (slices - 1)) == 0;
+    const int sh = 31 - __builtin_clz(slices);
     int slice, group;
-    if (slices >= 8) { const int per = slices >> 3;  slice = xcd + 8 * (q % per);  group = q / per; }
-    else { const int share = 8 / slices;  slice = xcd % slices;  group = q * share + xcd / slices; }
-    const long long row = (long long)group * RPW + wave;
-    const long long rows = (long long)R * PH;
-    if (row >= rows) return;
-    const int r = (int)(row / PH), ph = (int)(row - (long long)r * PH);
+    if (slices >= 8) {
+        const int per = slices >> 3;
+        if (pow2) { slice = xcd + 8 * (q & (per - 1));  group = q >> (sh - 3); }
+        else { slice = xcd + 8 * (q % per);  group = q / per; }
+    } else {       // 1, 2 or 4 slices
+        slice = xcd & (slices - 1);
+        group = (q << (3 - sh)) + (xcd >> sh);
+    }
+    // item = one RoI (WHOLE_ROI) or one (roi, ph) bin row
+    const long long item = (long long)group * RPW + wave;
+    const long long items = WHOLE_ROI ? (long long)R : (long long)R * PH;
+    if (item >= items) return;
+    const int r = WHOLE_ROI ? (int)item : ((PWS > 0 && PH == PWS) ? (int)(item / (PWS > 0 ? PWS : 1)) : (int)(item / PH));
+    const int ph_first = WHOLE_ROI ? 0 : (int)(item - (long long)r * PH);
+    const int ph_last = WHOLE_ROI ? PH : ph_first + 1;
+    // The geometry of the RoI costs ~160 VALU instructions per wave (coordinates, two IEEE
+    // divisions, the windows): a sixth of a one-row wave's VALU work, and the kernel's VALU is 74 %
+    // busy (SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES) -- a wave that walks the whole RoI pays it once.
     const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);        // wave-uniform values
     const int batch = __builtin_amdgcn_readfirstlane(g.batch);
     const bool bad = batch < 0 || batch >= N;
-    const int hs = __builtin_amdgcn_readfirstlane(win_start(ph, g.bin_h, g.sh, H, rounding));
-    const int he = __builtin_amdgcn_readfirstlane(win_end(ph, g.bin_h, g.sh, H, rounding));
     const int c0 = (slice * 64 + lane) * CPL;
     const bool lane_ok = c0 < C;
     const int voff = (lane_ok ? c0 : 0) * 4;
     const int cell_bytes = C * 4;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(bottom + (size_t)(bad ? 0 : batch) * H * W * C), 0, H * W * cell_bytes, 0x00020000);
-    size_t o = ((size_t)row * PW) * C + c0;
-    for (int pw = 0; pw < PW; ++pw, o += C) {
-        const int ws = __builtin_amdgcn_readfirstlane(win_start(pw, g.bin_w, g.sw, W, rounding));
-        const int we = __builtin_amdgcn_readfirstlane(win_end(pw, g.bin_w, g.sw, W, rounding));
-        const bool empty = (he <= hs) || (we <= ws) || bad;
-        vec mv;
-        unsigned mi[CPL];
+    // windows of the bin columns and rows: lane p computes bin column p and bin row p once (a lane's
+    // own copy per bin cost ~20 VALU instructions per bin), read back with v_readlane; PW, PH <= 64
+    const int pme = (lane < PW) ? lane : 0;
+    const int my_ws = win_start(pme, g.bin_w, g.sw, W, rounding);
+    const int my_we = win_end(pme, g.bin_w, g.sw, W, rounding);
+    const int phme = (lane < PH) ? lane : 0;
+    const int my_hs = win_start(phme, g.bin_h, g.sh, H, rounding);
+    const int my_he = win_end(phme, g.bin_h, g.sh, H, rounding);
+    const unsigned long long wide = __ballot(lane < PW && my_we - my_ws > ARG8_MAX_WIN_W);    // (every lane votes)
+    const unsigned long long tall = __ballot(lane < PH && lane >= ph_first && lane < ph_last && my_he - my_hs > ARG8_MAX_WIN_H);
+    const unsigned long long cols = __ballot(lane < PW && my_we > my_ws);
+    const unsigned long long rows_live = __ballot(lane < PH && lane >= ph_first && lane < ph_last && my_he > my_hs);
+    if (overflow && !bad && lane == 0 && ((wide != 0ull && rows_live != 0ull) || (tall != 0ull && cols != 0ull)))
+        atomicOr(overflow, 1);
+
+    for (int ph = ph_first; ph < ph_last; ++ph) {
+    const int hs = __builtin_amdgcn_readlane(my_hs, ph), he = __builtin_amdgcn_readlane(my_he, ph);
+    const bool row_dead = (he <= hs) || bad;
+    const size_t o_row = (((size_t)r * PH + ph) * PW) * C + c0;
+    // one bin: the reference's scan (h ascending, w ascending, strict >: roi_pooling_op_gpu.cu.cc:66-79)
+    auto pool_bin = [&](int ws, int we, vec &mv, unsigned (&mi)[CPL]) {
+        const bool empty = row_dead || (we <= ws);
 #pragma unroll
         for (int k = 0; k < CPL; ++k) { mv[k] = empty ? 0.0f : -FLT_MAX;  mi[k] = ARG8_EMPTY; }
 #if WSSDL_FWDC_ABLATE == 3
-        if (false) {
-#else
-        if (!empty) {
+        if (true) return;
 #endif
-            if ((he - hs > ARG8_MAX_WIN_H || we - ws > ARG8_MAX_WIN_W) && overflow && lane == 0) atomicOr(overflow, 1);
-            for (int h = hs; h < he; ++h) {
-                const int so_row = h * W * cell_bytes;
-                const unsigned rcode = (unsigned)(h - hs) << 4;
-                int w = ws;
-                for (; w + 1 < we; w += 2) {          // two cells in flight
-                    const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
-                    const vec v1 = LaneVec<CPL>::load(rs, voff, so_row + (w + 1) * cell_bytes);
-                    const unsigned code0 = rcode | (unsigned)(w - ws), code1 = code0 + 1u;
+        if (empty) return;
+        for (int h = hs; h < he; ++h) {
+            const int so_row = h * W * cell_bytes;
+            const unsigned rcode = (unsigned)(h - hs) << 4;
+            int w = ws;
+            for (; w + 1 < we; w += 2) {          // two cells in flight
+                const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
+                const vec v1 = LaneVec<CPL>::load(rs, voff, so_row + (w + 1) * cell_bytes);
+                const unsigned code0 = rcode | (unsigned)(w - ws), code1 = code0 + 1u;
+#if WSSDL_FWDC_ABLATE == 4
 #pragma unroll
-                    for (int k = 0; k < CPL; ++k) if (v0[k] > mv[k]) { mv[k] = v0[k];  mi[k] = code0; }
+                for (int k = 0; k < CPL; ++k) { mv[k] = fmaxf(mv[k], fmaxf(v0[k], v1[k]));  mi[k] = code1; }
+#else
 #pragma unroll
-                    for (int k = 0; k < CPL; ++k) if (v1[k] > mv[k]) { mv[k] = v1[k];  mi[k] = code1; }
-                }
-                if (w < we) {
-                    const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
-                    const unsigned code0 = rcode | (unsigned)(w - ws);
+                for (int k = 0; k < CPL; ++k) if (v0[k] > mv[k]) { mv[k] = v0[k];  mi[k] = code0; }
 #pragma unroll
-                    for (int k = 0; k < CPL; ++k) if (v0[k] > mv[k]) { mv[k] = v0[k];  mi[k] = code0; }
-                }
+                for (int k = 0; k < CPL; ++k) if (v1[k] > mv[k]) { mv[k] = v1[k];  mi[k] = code1; }
+#endif
+            }
+            if (w < we) {
+                const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
+                const unsigned code0 = rcode | (unsigned)(w - ws);
+#if WSSDL_FWDC_ABLATE == 4
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) { mv[k] = fmaxf(mv[k], v0[k]);  mi[k] = code0; }
+#else
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) if (v0[k] > mv[k]) { mv[k] = v0[k];  mi[k] = code0; }
+#endif
             }
         }
-#if WSSDL_FWDC_ABLATE == 1
-        if (mv[0] == 12345.678f && mi[0] == 77u) top[o] = mv[1] + (float)mi[1];
+    };
+    auto store_bin = [&](int pw, const vec &mv, unsigned codes) {
+        const size_t o = o_row + (size_t)pw * C;
+#if WSSDL_FWDC_NOSTORE
+        if (mv[0] == 12345.678f && codes == 77u) top[o] = mv[1] + (float)codes;
         if (false)
 #else
         if (lane_ok)
 #endif
         {
             __builtin_nontemporal_store(mv, reinterpret_cast<vec *>(top + o));
-            if (CPL == 4)
-                __builtin_nontemporal_store(mi[0] | (mi[1] << 8) | (mi[2 % CPL] << 16) | (mi[3 % CPL] << 24),
-                                            reinterpret_cast<unsigned *>(arg8 + o));
-            else
-                __builtin_nontemporal_store((unsigned short)(mi[0] | (mi[1] << 8)),
-                                            reinterpret_cast<unsigned short *>(arg8 + o));
+            if (CPL == 4) __builtin_nontemporal_store(codes, reinterpret_cast<unsigned *>(arg8 + o));
+            else __builtin_nontemporal_store((unsigned short)codes, reinterpret_cast<unsigned short *>(arg8 + o));
         }
+    };
+    auto pack = [](const unsigned (&mi)[CPL]) -> unsigned {
+        return (CPL == 4) ? (mi[0] | (mi[1] << 8) | (mi[2 % CPL] << 16) | (mi[3 % CPL] << 24)) : (mi[0] | (mi[1] << 8));
+    };
+    if constexpr (PWS > 0) {
+        // PW known at compile time: the results of a bin row stay in registers (5 per bin) and its
+        // stores are issued together behind the last bin.  On gfx9-family hardware stores and loads
+        // share the in-order vmcnt counter: a wave that waits for a load also waits for every store
+        // it issued before it, so a store per bin puts a store acknowledgement on the wave's critical
+        // path per bin instead of per row.
+        vec res[PWS];
+        unsigned resc[PWS];
+#pragma unroll
+        for (int pw = 0; pw < PWS; ++pw) {
+            unsigned mi[CPL];
+            pool_bin(__builtin_amdgcn_readlane(my_ws, pw), __builtin_amdgcn_readlane(my_we, pw), res[pw], mi);
+            resc[pw] = pack(mi);
+        }
+#pragma unroll
+        for (int pw = 0; pw < PWS; ++pw) store_bin(pw, res[pw], resc[pw]);
+    } else {
+        for (int pw = 0; pw < PW; ++pw) {
+            vec mv;
+            unsigned mi[CPL];
+            pool_bin(__builtin_amdgcn_readlane(my_ws, pw), __builtin_amdgcn_readlane(my_we, pw), mv, mi);
+            store_bin(pw, mv, pack(mi));
+        }
+    }
     }
 }
 
@@ -608,7 +676,7 @@ static int launch_bwd_c(const float *top_diff, const unsigned char *arg8, const 
 
 static bool compact_supported(int H, int W, int C, int PH, int PW) {
     if (H < 1 || W < 1 || C < 32 || (C % 32) != 0 || C / 32 > 256 || PH < 1 || PW < 1) return false;
-    if (PH > 255 || PW > 255) return false;
+    if (PH > 64 || PW > 64) return false;       // (the forward keeps the bin windows in the lanes of a wave)
     // a RoI inside the map spans at most H+1 (W+1) cells after rounding: windows of at most
     // ceil((H+1)/PH) + 1 rows, ceil((W+1)/PW) + 1 columns
     return cdiv(H + 1, PH) + 1 <= ARG8_MAX_WIN_H && cdiv(W + 1, PW) + 1 <= ARG8_MAX_WIN_W;
@@ -643,23 +711,32 @@ extern "C" int wssdl_roi_pool_forward_compact(const float *bottom, int N, int H,
     unsigned *a8 = reinterpret_cast<unsigned *>(argmax8);
     int variant = 0;
     if (const char *e = getenv("WSSDL_ROI_FWD_VARIANT")) variant = atoi(e);      // tuning
-    // wave-uniform kernel: one wave per (roi, ph) row x 256 (or 128) channels
+    // wave-uniform kernel, 256 (or 128) channels per wave.  Variants: 0 = automatic, 1 = one bin row per
+    // wave with a store per bin, 2 = 128-channel waves, 3 = 7 one-row waves per workgroup, 4 = one bin
+    // row per wave, 5 = a whole RoI per wave, 9 = the sliced round-1 form
     if (variant != 9) {
         const int cpl = (variant == 2 || C % 256 != 0) ? 2 : 4;
         const int slices = cdiv(C, 64 * cpl);
         const int rpw = (variant == 3 && cpl == 4) ? 7 : 4;
         if (((slices >= 8 && slices % 8 == 0) || (slices < 8 && 8 % slices == 0)) &&
             (long long)H * W * C * 4 < 0x7fffffffLL) {
-            const long long groups = ((long long)R * pooled_h + rpw - 1) / rpw;
+            // a wave walks a whole RoI when that still gives every SIMD its 8 waves (R * slices >= 8192),
+            // else one (roi, ph) bin row; pooled_w == 7 is known at compile time: the stores of a row are
+            // issued together
+            const bool many = (long long)R * slices >= 8192;
+            const bool whole = pooled_w == 7 && variant == 5 && many;      // (measured slower: 0.80 against 0.57 ms)
+            const long long items = whole ? (long long)R : (long long)R * pooled_h;
+            const long long groups = (items + rpw - 1) / rpw;
             long long blocks = slices >= 8 ? groups * slices : 8 * ((groups + 8 / slices - 1) / (8 / slices));
             if (blocks <= 0x7fffffffLL) {
-#define WSSDL_FWD_ROWS(CPL, RPW) \
-    hipLaunchKernelGGL((roi_pool_fwd_rows_kernel<CPL, RPW>), dim3((unsigned)blocks), dim3(64 * RPW), 0, st, bottom, N, \
+#define WSSDL_FWD_ROWS(CPL, RPW, PWS, WHOLE) \
+    hipLaunchKernelGGL((roi_pool_fwd_rows_kernel<CPL, RPW, PWS, WHOLE>), dim3((unsigned)blocks), dim3(64 * RPW), 0, st, bottom, N, \
                        H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top, argmax8, overflow, slices)
-                if (cpl == 2) WSSDL_FWD_ROWS(2, 4);
-                else if (variant == 3) WSSDL_FWD_ROWS(4, 7);
-
-                else WSSDL_FWD_ROWS(4, 4);
+                if (variant == 3 && cpl == 4) WSSDL_FWD_ROWS(4, 7, 0, false);
+                else if (cpl == 2) { if (whole) WSSDL_FWD_ROWS(2, 4, 7, true); else WSSDL_FWD_ROWS(2, 4, 0, false); }
+                else if (whole) WSSDL_FWD_ROWS(4, 4, 7, true);
+                else if ((variant == 0 || variant == 4) && pooled_w == 7) WSSDL_FWD_ROWS(4, 4, 7, false);
+                else WSSDL_FWD_ROWS(4, 4, 0, false);
 #undef WSSDL_FWD_ROWS
                 return check_launch();
             }
