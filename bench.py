@@ -389,7 +389,8 @@ def main():
                        "backbone": "%s-%d" % ("ResNet" if wl["net"].startswith("Resnet") else "VGG", wl["depth"]),
                        "image": "%dx%d" % (im_h, im_w), "images_per_gpu": images_per_step,
                        "supervised_per_gpu": wl["n_sup"], "weak_per_gpu": wl["n_ws"], "mode": mode,
-                       "parallelism": "image-parallel dp%d, RCCL grad all-reduce" % ctx.world_size,
+                       "parallelism": "image-parallel dp%d, %s grad all-reduce" % (
+                           ctx.world_size, "RCCL" if (ctx.backend or "nccl") == "nccl" else ctx.backend),
                        "sampling_rng": args.sampling_rng, "fused_rpn_softmax": bool(cfg.FUSED_RPN_SOFTMAX), "padded_rois": bool(cfg.PADDED_ROIS),
                        "roi_pool_argmax_bytes": leg_meta["argmax_bytes"]},
             "roofline": roofline,
