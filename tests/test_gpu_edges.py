@@ -669,3 +669,55 @@ def test_nms_prefilter_thresholds_and_degenerate_boxes(torch_cuda):
     e = np.hstack((e, np.linspace(1, 0.5, len(e), dtype=np.float32)[:, None]))
     for th in (0.5, 1.0 / 3.0, 0.75, 0.6, 0.25, float(np.float32(0.5)), float(np.float32(1.0 / 3.0))):
         assert hip_nms(e, th) == O.nms(e, th), th
+
+
+def test_nms_prefilter_box_families_vs_oracle(torch_cuda):
+    """Whole keep-lists against the oracle (cpu_nms.pyx:17-68) for box populations that stress the
+    centre-distance prefilter in different ways: integer coordinates (overlaps that equal simple
+    thresholds exactly), boxes clipped to the image border (shared edges, extreme aspect ratios),
+    tiny boxes next to image-sized ones, and a proposal-like mix at 12000 candidates."""
+    from wssdl_bus_amd.nms.hip_nms import hip_nms
+    rs = np.random.RandomState(21)
+
+    def with_scores(b):
+        n = len(b)
+        return np.hstack((b, rs.permutation(n)[:, None] / float(n))).astype(np.float32)
+
+    # integer boxes on a coarse lattice: many pairs with IoU exactly 1/2, 1/3, 2/3, 3/4 ...
+    n = 4000
+    x1 = rs.randint(0, 40, n) * 8.0
+    y1 = rs.randint(0, 30, n) * 8.0
+    w = rs.choice([16, 24, 32, 48, 64], n).astype(np.float64)
+    h = rs.choice([16, 24, 32, 48, 64], n).astype(np.float64)
+    lattice = with_scores(np.stack([x1, y1, x1 + w - 1, y1 + h - 1], axis=1))
+    for th in (0.5, 1.0 / 3.0, 2.0 / 3.0, 0.75, 0.7, 0.25):
+        assert hip_nms(lattice, th) == O.nms(lattice, th), ("lattice", th)
+    # clipped to a 1000 x 600 image: edges pile up on the border, some boxes become slivers
+    c = rs.uniform(-100, 1100, size=(5000, 2)) * [1.0, 0.6]
+    wh = np.exp(rs.uniform(np.log(8), np.log(900), size=(5000, 2)))
+    b = np.hstack((c - wh / 2, c + wh / 2))
+    b[:, [0, 2]] = np.clip(b[:, [0, 2]], 0, 999)
+    b[:, [1, 3]] = np.clip(b[:, [1, 3]], 0, 599)
+    clipped = with_scores(b)
+    for th in (0.7, 0.3, 0.5):
+        assert hip_nms(clipped, th) == O.nms(clipped, th), ("clipped", th)
+    # tiny boxes inside image-sized ones
+    tiny = np.hstack((rs.uniform(0, 990, (3000, 1)), rs.uniform(0, 590, (3000, 1))))
+    tiny = np.hstack((tiny, tiny + rs.uniform(0, 6, (3000, 2))))
+    huge = np.hstack((rs.uniform(0, 30, (500, 2)), rs.uniform(960, 999, (500, 1)), rs.uniform(560, 599, (500, 1))))
+    mixed = with_scores(np.vstack((tiny, huge)))
+    for th in (0.7, 0.3, 0.9):
+        assert hip_nms(mixed, th) == O.nms(mixed, th), ("mixed", th)
+    # proposal-like population at the training size, with the training cut
+    n = 12000
+    c = rs.uniform(0, 1000, size=(n, 2)) * [1.0, 0.6]
+    s = np.exp(rs.normal(np.log(150), 0.7, size=(n, 1)))
+    ar = np.exp(rs.normal(0, 0.5, size=(n, 1)))
+    wh = np.hstack((s * np.sqrt(ar), s / np.sqrt(ar)))
+    b = np.hstack((c - wh / 2, c + wh / 2))
+    b[:, [0, 2]] = np.clip(b[:, [0, 2]], 0, 999)
+    b[:, [1, 3]] = np.clip(b[:, [1, 3]], 0, 599)
+    prop = with_scores(b)
+    want = O.nms(prop, 0.7)
+    assert hip_nms(prop, 0.7) == want
+    assert hip_nms(prop, 0.7, max_keep=2000) == want[:2000]
