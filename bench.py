@@ -238,6 +238,9 @@ def main():
     ap.add_argument("--no-fused-rpn-softmax", action="store_true",
                     help="materialise rpn_cls_prob with separate reshape / softmax / reshape ops instead of "
                          "fusing them into the proposal decode kernel (f2, the default)")
+    ap.add_argument("--no-fused-loss", action="store_true",
+                    help="the four supervised loss terms as the chain of torch ops instead of the one device op "
+                         "(a13, csrc/loss.hip, the default)")
     ap.add_argument("--roofline-iters", type=int, default=20, help="launches of the fixed-RoI roofline leg")
     ap.add_argument("--padded-rois", action="store_true",
                     help="fixed-shape RoI blob (dead rows carry batch index -1): no device->host copy between "
@@ -266,6 +269,7 @@ def main():
     cfg.TRAIN.WS_IMS_PER_BATCH = wl["n_ws"]
     cfg.SAMPLING_RNG = args.sampling_rng
     cfg.FUSED_RPN_SOFTMAX = not args.no_fused_rpn_softmax
+    cfg.FUSED_LOSS = not args.no_fused_loss
     cfg.PADDED_ROIS = bool(args.padded_rois)
     seed = ctx.seed(cfg.RNG_SEED)
     cfg.DEVICE_RNG_SEED = seed              # the device samplers draw a different stream on every rank
@@ -351,7 +355,11 @@ def main():
     leg, leg_meta = roofline_leg.run(rois_fixed, N_leg, H_leg, W_leg, C_leg, iters=args.roofline_iters)
 
     if ctx.rank == 0:
-        hot_ms = sum(d["total_ms"] for d in tl.values()) / max(args.steps, 1)
+        # hot_ms: the ops the CPU baseline also runs (layers + RoI pool); the fused loss op (a13) is
+        # listed beside it -- its CPU counterpart is the TF graph, which the baseline does not time
+        loss_ops = ("multi_task_loss", "multi_task_loss_backward")
+        hot_ms = sum(d["total_ms"] for k, d in tl.items() if k not in loss_ops) / max(args.steps, 1)
+        loss_ms = sum(d["total_ms"] for k, d in tl.items() if k in loss_ops) / max(args.steps, 1)
         # dominant kernel = the single-kernel launch of the leg with the largest average duration
         # (roi_pool_backward = the walk kernel alone; its list-building prepare step, like the
         # proposal / target layers, is a chain of small latency-bound kernels: per_kernel only)
@@ -395,7 +403,8 @@ def main():
                        "roi_pool_argmax_bytes": leg_meta["argmax_bytes"]},
             "roofline": roofline,
             "hot_path": {"gpu_ms_per_step": round(hot_ms, 3),
-                         "gpu_images_per_s": round(images_per_step / (hot_ms * 1e-3), 1) if hot_ms > 0 else None},
+                         "gpu_images_per_s": round(images_per_step / (hot_ms * 1e-3), 1) if hot_ms > 0 else None,
+                         "loss_op_ms_per_step": round(loss_ms, 4), "fused_loss": bool(cfg.get("FUSED_LOSS", True))},
             "final_loss": loss_val,
         }
         if ctx.world_size == 1 and not args.no_cpu_baseline:

@@ -275,6 +275,38 @@ WSSDL_API int wssdl_roi_argmax_expand(const uint8_t *argmax8, const float *rois,
                             int C, int pooled_h, int pooled_w, float spatial_scale, int rounding,
                             int32_t *argmax, wssdl_stream_t stream);
 
+/* --------------------------------------------------------------------- a13 ---
+ * Multi-task loss of the supervised images and its gradients: fast_rcnn/train_bus.py:186-192 /
+ * :605-610 (rpn_cross_entropy), :203-210 / :613-620 (rpn_loss_box, threshold |d| < 1 with the
+ * sigma = 3 pieces as written), :218 / :623-630 (cross_entropy), :231-235 / :641-647 (loss_box).
+ * Layouts are the layers' own (network.py:196-291): rpn_cls_score [n_images,H,W,2A] raw scores
+ * (channel c*A + a: the reshape to [n, A*H, W, 2] is an index map), rpn_labels [n_images,1,A*H,W] i32
+ * in {-1,0,1}, rpn_bbox_pred [n_images,H,W,4A], rpn targets / weights [n_images,4A,H,W]; the box term
+ * covers the first n_box_images images (combined mode: IMS_PER_BATCH; the others get zero gradient).
+ * cls_score [>= n_rows, num_classes], labels [n_rows] i32 (-1 = padding row: not counted),
+ * bbox_pred [>= n_rows, 4*num_classes], bbox targets / weights [n_rows, 4*num_classes].
+ * forward : losses[4] = rpn_cross_entropy, rpn_loss_box, cross_entropy, loss_box (f32; sums in f64,
+ *           combined in a fixed order); the workspace keeps the two counts for the backward.
+ * backward: grad_losses [4] f32 (device) = upstream gradient of each term; writes the gradients of
+ *           the four prediction tensors in full (rows_total >= n_rows rows of the two head outputs:
+ *           rows past n_rows and padding rows get zeros). */
+WSSDL_API size_t wssdl_multi_task_loss_workspace_bytes(int n_images, int H, int W, int A);
+WSSDL_API int wssdl_multi_task_loss_forward(
+    const float *rpn_cls_score, const int32_t *rpn_labels, const float *rpn_bbox_pred,
+    const float *rpn_bbox_targets, const float *rpn_inside_w, const float *rpn_outside_w, int n_images,
+    int n_box_images, int H, int W, int A, const float *cls_score, const int32_t *labels,
+    const float *bbox_pred, const float *bbox_targets, const float *bbox_inside_w,
+    const float *bbox_outside_w, int n_rows, int num_classes, float *losses, void *workspace,
+    size_t workspace_bytes, wssdl_stream_t stream);
+WSSDL_API int wssdl_multi_task_loss_backward(
+    const float *rpn_cls_score, const int32_t *rpn_labels, const float *rpn_bbox_pred,
+    const float *rpn_bbox_targets, const float *rpn_inside_w, const float *rpn_outside_w, int n_images,
+    int n_box_images, int H, int W, int A, const float *cls_score, const int32_t *labels,
+    const float *bbox_pred, const float *bbox_targets, const float *bbox_inside_w,
+    const float *bbox_outside_w, int n_rows, int rows_total, int num_classes, const float *grad_losses,
+    const void *workspace, float *grad_rpn_cls_score, float *grad_rpn_bbox_pred, float *grad_cls_score,
+    float *grad_bbox_pred, wssdl_stream_t stream);
+
 /* ---------------------------------------------------------------------- f1 ---
  * MIL bag-instance selection: mil/core.py:11-46 (get_bag_logit) with the selectors
  * get_mal_max_logit :60-69, get_ben_max_logit :49-57, get_mass_max_logit :88-96.

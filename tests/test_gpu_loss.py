@@ -1,0 +1,141 @@
+"""-m gpu: the fused multi-task loss op (csrc/loss.hip) against the oracle's
+f64 restatement of train_bus.py:186-235 / :605-647 and against the chain of torch ops it replaces
+(values and gradients)."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    from wssdl_bus_amd import _lib
+    _lib.lib()
+    return torch
+
+
+def _inputs(torch, rs, N, H, W, A, n_rows, rows_total, K=3, weak_from=None, pad_rows=0):
+    """Layer tensors of one step: scores / predictions (leaf tensors), rpn-data, roi-data."""
+    dev = "cuda"
+    rpn_cls = torch.tensor(rs.normal(0, 2, (N, H, W, 2 * A)), dtype=torch.float32, device=dev, requires_grad=True)
+    rpn_box = torch.tensor(rs.normal(0, 0.7, (N, H, W, 4 * A)), dtype=torch.float32, device=dev, requires_grad=True)
+    labels = rs.choice([-1, 0, 1], size=(N, 1, A * H, W), p=[0.8, 0.15, 0.05]).astype(np.int32)
+    tg = rs.normal(0, 0.7, (N, 4 * A, H, W)).astype(np.float32)
+    fg = (labels.reshape(N, A, H, W) == 1)
+    inw = np.repeat(fg, 4, axis=1).astype(np.float32)              # channel a*4 + j
+    n_ex = max(int((labels >= 0).sum()), 1)
+    outw = np.repeat(labels.reshape(N, A, H, W) >= 0, 4, axis=1).astype(np.float32) / n_ex
+    # a few large differences so that both branches of the |d| < 1 switch are taken on live elements
+    tg[inw > 0] += rs.choice([0.0, 3.0, -2.5], size=int((inw > 0).sum())).astype(np.float32)
+    if weak_from is not None:                                       # weak images: all-ignore labels, zero weights
+        labels[weak_from:] = -1
+        inw[weak_from:] = 0
+        outw[weak_from:] = 0
+    cls = torch.tensor(rs.normal(0, 1.5, (rows_total, K)), dtype=torch.float32, device=dev, requires_grad=True)
+    box = torch.tensor(rs.normal(0, 0.5, (rows_total, 4 * K)), dtype=torch.float32, device=dev, requires_grad=True)
+    lab = rs.randint(0, K, size=(n_rows, 1)).astype(np.int32)
+    if pad_rows:
+        lab[-pad_rows:] = -1
+    rtg = rs.normal(0, 0.5, (n_rows, 4 * K)).astype(np.float32)
+    rinw = np.zeros((n_rows, 4 * K), np.float32)
+    for r in range(n_rows):
+        if lab[r, 0] > 0:
+            rinw[r, 4 * lab[r, 0]:4 * lab[r, 0] + 4] = 1.0
+    routw = (rinw > 0).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    rpn_data = (t(labels), t(tg), t(inw), t(outw))
+    roi_data = (torch.zeros((n_rows, 5), device=dev), t(lab), t(rtg), t(rinw), t(routw))
+    return rpn_cls, rpn_box, cls, box, rpn_data, roi_data
+
+
+def _oracle_terms(rpn_cls, rpn_box, cls, box, rpn_data, roi_data, n_box):
+    npf = lambda x: x.detach().cpu().numpy()
+    reshape = O.reshape_layer(npf(rpn_cls), 2)
+    lab = npf(roi_data[1]).reshape(-1)
+    live = lab >= 0                                                  # padding rows are not rows of the reference's blob
+    rd = [npf(x) for x in roi_data]
+    return np.array([
+        O.loss_rpn_cross_entropy(reshape, npf(rpn_data[0])),
+        O.loss_rpn_box(npf(rpn_box), [npf(x) for x in rpn_data], n_box),
+        O.loss_rcnn_cross_entropy(npf(cls)[:lab.size][live], lab[live]),
+        O.loss_rcnn_box(npf(box)[:lab.size][live], rd[2][live], rd[3][live], rd[4][live]),
+    ])
+
+
+@pytest.mark.parametrize("case", ["joint_38x63", "sup_63x100", "small_padded", "vgg_37x62"])
+def test_fused_loss_values_and_gradients(torch_cuda, case):
+    torch = torch_cuda
+    from wssdl_bus_amd.fast_rcnn import train_bus as TB
+    from wssdl_bus_amd.fast_rcnn.loss_op import multi_task_loss
+    rs = np.random.RandomState(len(case))
+    if case == "joint_38x63":        # BASELINE configs[2]: 4 supervised + 4 weak images, 512 supervised rows of 8512
+        N, H, W, A, n_rows, rows_total, n_box, weak_from, pad = 8, 38, 63, 9, 512, 8512, 4, 4, 0
+    elif case == "sup_63x100":       # 1000x1600 map, supervised only
+        N, H, W, A, n_rows, rows_total, n_box, weak_from, pad = 1, 63, 100, 9, 128, 128, None, None, 0
+    elif case == "small_padded":     # fixed-shape RoI list with padding rows (label -1)
+        N, H, W, A, n_rows, rows_total, n_box, weak_from, pad = 2, 5, 7, 3, 40, 61, 2, None, 9
+    else:
+        N, H, W, A, n_rows, rows_total, n_box, weak_from, pad = 3, 37, 62, 9, 128, 4128, 1, 1, 0
+    rpn_cls, rpn_box, cls, box, rpn_data, roi_data = _inputs(torch, rs, N, H, W, A, n_rows, rows_total,
+                                                             weak_from=weak_from, pad_rows=pad)
+    terms = multi_task_loss(rpn_cls, rpn_box, cls, box, rpn_data, roi_data, n_box)
+    want = _oracle_terms(rpn_cls, rpn_box, cls, box, rpn_data, roi_data, n_box)
+    got = terms.detach().cpu().numpy().astype(np.float64)
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-7), (got, want)          # north_star tolerance: 1e-5
+
+    # gradients: the chain of torch ops the op replaces (autograd), with unequal upstream weights
+    wts = torch.tensor([0.7, 1.3, 2.0, 0.4], device="cuda")
+    (terms * wts).sum().backward()
+    fused = [x.grad.clone() for x in (rpn_cls, rpn_box, cls, box)]
+    for x in (rpn_cls, rpn_box, cls, box):
+        x.grad = None
+    n, h, w, c = rpn_cls.shape
+    reshaped = rpn_cls.permute(0, 3, 1, 2).reshape(n, 2, A * h, w).permute(0, 2, 3, 1)     # network.py:283-291, d = 2
+    ref = torch.stack([TB.rpn_cls_loss(reshaped, rpn_data[0]), TB.rpn_box_loss(rpn_box, rpn_data, n_box),
+                       TB.rcnn_cls_loss(cls, roi_data[1]), TB.rcnn_box_loss(box, roi_data)])
+    assert torch.allclose(ref, terms.detach(), rtol=2e-5, atol=1e-7)
+    (ref * wts).sum().backward()
+    for name, f, x in zip(("rpn_cls_score", "rpn_bbox_pred", "cls_score", "bbox_pred"), fused, (rpn_cls, rpn_box, cls, box)):
+        g = x.grad
+        scale = float(g.abs().max().clamp_min(1e-30))
+        assert float((f - g).abs().max()) <= 2e-5 * scale + 1e-12, name
+        assert torch.equal(f == 0, g == 0) or float((f - g).abs().max()) <= 1e-9, name    # same support (zeros stay zeros)
+
+
+def test_fused_loss_is_the_step_default_and_matches_unfused(torch_cuda):
+    """supervised_loss goes through the op for GPU layers (cfg.FUSED_LOSS) and gives the same terms as
+    the torch chain; a step without any labelled anchor yields NaN for the RPN CE like the mean of an
+    empty gather (train_bus.py:186-192)."""
+    torch = torch_cuda
+    from wssdl_bus_amd.fast_rcnn import train_bus as TB
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    rs = np.random.RandomState(4)
+    rpn_cls, rpn_box, cls, box, rpn_data, roi_data = _inputs(torch, rs, 2, 6, 9, 9, 64, 64)
+    n, h, w, c = rpn_cls.shape
+    layers = {"rpn_cls_score": rpn_cls, "rpn_bbox_pred": rpn_box, "cls_score": cls, "bbox_pred": box,
+              "rpn-data": rpn_data, "roi-data": roi_data,
+              "rpn_cls_score_reshape": rpn_cls.permute(0, 3, 1, 2).reshape(n, 2, 9 * h, w).permute(0, 2, 3, 1)}
+    old = cfg.get("FUSED_LOSS", True)
+    try:
+        cfg.FUSED_LOSS = True
+        a = TB.supervised_loss(layers, [], None)
+        cfg.FUSED_LOSS = False
+        b = TB.supervised_loss(layers, [], None)
+    finally:
+        cfg.FUSED_LOSS = old
+    for k in ("rpn_cross_entropy", "rpn_loss_box", "cross_entropy", "loss_box", "loss"):
+        assert torch.allclose(a[k], b[k], rtol=2e-5, atol=1e-7), k
+    # the fused terms are slices of the op's output, the unfused ones come from F.cross_entropy
+    assert "MultiTaskLoss" in type(a["rpn_cross_entropy"].grad_fn.next_functions[0][0]).__name__
+    assert "MultiTaskLoss" not in type(b["rpn_cross_entropy"].grad_fn).__name__
+    # no labelled anchor at all
+    ignore = (torch.full_like(rpn_data[0], -1),) + tuple(rpn_data[1:])
+    from wssdl_bus_amd.fast_rcnn.loss_op import multi_task_loss
+    t = multi_task_loss(rpn_cls, rpn_box, cls, box, ignore, roi_data, None)
+    assert torch.isnan(t[0]) and torch.isfinite(t[1:]).all()
+    t[1:].sum().backward()                                           # gradients of the other terms stay finite
+    assert torch.isfinite(rpn_box.grad).all() and float(rpn_cls.grad.abs().max()) == 0.0

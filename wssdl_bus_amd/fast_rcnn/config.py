@@ -87,6 +87,9 @@ __C.ROI_POOL_COMPACT_ARGMAX = True
 # captured in a hipGraph.  The per-RoI head then runs on the padded row count (batch-norm masked to the
 # live rows).  False (default): the blob is compacted, which costs one read-back of N counts per step.
 __C.PADDED_ROIS = False
+# a13: the four supervised loss terms and their gradients as one device op (csrc/loss.hip) when the
+# layers are on the GPU; False = the chain of torch ops in fast_rcnn/train_bus.py
+__C.FUSED_LOSS = True
 
 
 def cfg_from_list(cfg_list):

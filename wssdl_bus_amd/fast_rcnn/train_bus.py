@@ -104,12 +104,19 @@ def l2_weight_decay(params):
 
 
 def supervised_loss(layers, params, n_sup=None):
-    l = dict(
-        rpn_cross_entropy=rpn_cls_loss(layers['rpn_cls_score_reshape'], layers['rpn-data'][0]),
-        rpn_loss_box=rpn_box_loss(layers['rpn_bbox_pred'], layers['rpn-data'], n_sup),
-        cross_entropy=rcnn_cls_loss(layers['cls_score'], layers['roi-data'][1]),
-        loss_box=rcnn_box_loss(layers['bbox_pred'], layers['roi-data']),
-    )
+    if cfg.get('FUSED_LOSS', True) and layers['cls_score'].is_cuda and 'rpn_cls_score' in layers:
+        # the four terms and their gradients as one device op (csrc/loss.hip)
+        from .loss_op import multi_task_loss, TERMS
+        terms = multi_task_loss(layers['rpn_cls_score'], layers['rpn_bbox_pred'], layers['cls_score'],
+                                layers['bbox_pred'], layers['rpn-data'], layers['roi-data'], n_sup)
+        l = {name: terms[i] for i, name in enumerate(TERMS)}
+    else:
+        l = dict(
+            rpn_cross_entropy=rpn_cls_loss(layers['rpn_cls_score_reshape'], layers['rpn-data'][0]),
+            rpn_loss_box=rpn_box_loss(layers['rpn_bbox_pred'], layers['rpn-data'], n_sup),
+            cross_entropy=rcnn_cls_loss(layers['cls_score'], layers['roi-data'][1]),
+            loss_box=rcnn_box_loss(layers['bbox_pred'], layers['roi-data']),
+        )
     l['weight_decay'] = l2_weight_decay(params)
     l['loss'] = (l['cross_entropy'] + l['loss_box'] + l['rpn_cross_entropy'] + l['rpn_loss_box']
                  + l['weight_decay'])
