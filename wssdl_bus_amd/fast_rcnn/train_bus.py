@@ -6,6 +6,8 @@ losses), :286-301 / :694-705 (optimisers and the per-variable sum of the two gra
 the hot path's backward is restated here; data loading, LR
 schedules, snapshots and logging are out of scope.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -138,7 +140,7 @@ class SolverWrapper(object):
         # (:694-705).  Alternating mode: the supervised op is Adam.minimize(loss) WITHOUT a
         # global step, the weak op a SECOND Adam whose apply_gradients counts it (:286-301);
         # the two keep their own moments and bias-correction powers.
-        self.optimizer = torch.optim.Adam(self.params, lr=self.lr, eps=0.1)
+        self.optimizer = self._adam()
         self.optimizer_ws = None                  # created by the first alternating iteration
         self.global_step = 0
         self.dist = dist_ctx
@@ -146,6 +148,13 @@ class SolverWrapper(object):
             cfg.DEVICE_RNG_SEED = dist_ctx.seed(cfg.RNG_SEED)   # for the device samplers too
         # data parallel: bucketed gradient all-reduce overlapped with backward
         self.overlap = dist_ctx.overlap(self.params) if (dist_ctx is not None and dist_ctx.enabled) else None
+
+    def _adam(self):
+        # plumbing: on the GPU ask for the multi-tensor ("fused") implementation -- the per-parameter
+        # loop is ~7 small launches for each of ~160 parameters per step
+        fused = bool(self.params) and all(p.is_cuda for p in self.params) and os.environ.get("WSSDL_ADAM_FUSED", "1") != "0"
+        return torch.optim.Adam(self.params, lr=self.lr, eps=0.1, fused=True) if fused \
+            else torch.optim.Adam(self.params, lr=self.lr, eps=0.1)
 
     def _apply(self, optimizer=None, count_step=True):
         if self.overlap is not None:
@@ -210,6 +219,6 @@ class SolverWrapper(object):
         self._apply(self.optimizer, count_step=False)              # train_op_s: no global_step
         losses['mil_cross_entropy'] = self.weak_backward(blobs_ws)
         if self.optimizer_ws is None:
-            self.optimizer_ws = torch.optim.Adam(self.params, lr=self.lr, eps=0.1)
+            self.optimizer_ws = self._adam()
         self._apply(self.optimizer_ws, count_step=True)            # train_op_ws counts the step
         return losses
