@@ -357,7 +357,7 @@ def main():
     if ctx.rank == 0:
         # hot_ms: the ops the CPU baseline also runs (layers + RoI pool); the fused loss op (a13) is
         # listed beside it -- its CPU counterpart is the TF graph, which the baseline does not time
-        loss_ops = ("multi_task_loss", "multi_task_loss_backward")
+        loss_ops = ("multi_task_loss", "multi_task_loss_backward", "mil_loss", "mil_loss_backward")
         hot_ms = sum(d["total_ms"] for k, d in tl.items() if k not in loss_ops) / max(args.steps, 1)
         loss_ms = sum(d["total_ms"] for k, d in tl.items() if k in loss_ops) / max(args.steps, 1)
         # dominant kernel = the single-kernel launch of the leg with the largest average duration

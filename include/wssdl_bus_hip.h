@@ -322,6 +322,25 @@ WSSDL_API int wssdl_mil_select(const float *instance_logits, int R, int num_clas
                      int selector_other, int32_t *row_out, int32_t *count_out,
                      wssdl_stream_t stream);
 
+/* The MIL term as one op: selection as above, then fast_rcnn/train_bus.py:246-260 / :657-671 --
+ * softmax CE of the selected instance against the bag label, weighted by class_weights_host[label]
+ * ([0, WS_MAL_PCT, 1 - WS_MAL_PCT], :252,:664; host array [num_classes]) and by `scale`
+ * (1 - 0.99 * 0.9^floor(step/2000) or the constant, :248,:659), mean over the n_bags bags.  An empty
+ * bag contributes 0 and still counts in the mean.  loss [1] f32; row_out [n_bags] i32 and bag_loss
+ * [n_bags] f32 are outputs the backward (row_out) and the caller may read.  The backward writes the
+ * gradient of the whole [R,num_classes] logits block (zeros except the selected rows);
+ * grad_loss [1] f32 on the device. */
+WSSDL_API int wssdl_mil_loss_forward(const float *instance_logits, int R, int num_classes,
+                           const float *bag_of_row, int bag_stride, float bag_offset,
+                           const int32_t *bag_labels, int n_bags, int selector_label1,
+                           int selector_other, const float *class_weights_host, float scale,
+                           float *loss, int32_t *row_out, float *bag_loss, wssdl_stream_t stream);
+WSSDL_API int wssdl_mil_loss_backward(const float *instance_logits, int R, int num_classes,
+                            const float *bag_of_row, int bag_stride, float bag_offset,
+                            const int32_t *bag_labels, int n_bags, const int32_t *rows,
+                            const float *class_weights_host, float scale, const float *grad_loss,
+                            float *grad_logits, wssdl_stream_t stream);
+
 /* ---------------------------------------------------------------------- f4 ---
  * The pinnable half of the host image path, on the device.  utils/blob.py:34-79
  * (prep_im_for_blob), :19-32 (im_list_to_blob), roi_data_layer/minibatch_bus.py:269-272 (grey plane

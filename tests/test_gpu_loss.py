@@ -139,3 +139,60 @@ def test_fused_loss_is_the_step_default_and_matches_unfused(torch_cuda):
     assert torch.isnan(t[0]) and torch.isfinite(t[1:]).all()
     t[1:].sum().backward()                                           # gradients of the other terms stay finite
     assert torch.isfinite(rpn_box.grad).all() and float(rpn_cls.grad.abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ the MIL term (f1) ---
+@pytest.mark.parametrize("mode", ["combined", "alter"])
+def test_fused_mil_loss_values_and_gradients(torch_cuda, mode):
+    """wssdl_mil_loss_forward / _backward against the oracle's loss_mil (train_bus.py:239-260 /
+    :650-671, f64) and against autograd through the selection op + torch CE it replaces: ties in the
+    selected column (first instance wins), a single-instance bag, an empty bag, both bag labels (the
+    alternating mode switches the selector on label 1, :241), the bag index read from a strided
+    column of the rois blob with an offset (:653), and both forms of the scale factor."""
+    torch = torch_cuda
+    from wssdl_bus_amd.fast_rcnn import train_bus as TB
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.mil import core as M
+    rs = np.random.RandomState(7 if mode == "combined" else 8)
+    counts = [40, 1, 0, 25, 2000]                              # bag 2 is empty
+    n_bags = len(counts)
+    bag_labels = np.array([1, 2, 1, 2, 1], np.int32)
+    R = sum(counts)
+    logits_np = rs.normal(0, 2, (R, 3)).astype(np.float32)
+    logits_np[3:9, 2] = logits_np[:40, 2].max() + 1.0          # six-way tie of the malignant logit in bag 0
+    logits_np[45:50, 0] = logits_np[41:66, 0].min() - 1.0      # tie of the smallest background logit in bag 3
+    offset = 4.0 if mode == "combined" else 0.0                 # batch column minus IMS_PER_BATCH (:653)
+    rois = np.zeros((R, 5), np.float32)
+    rois[:, 0] = np.repeat(np.arange(n_bags), counts) + offset
+    funcs_t = [M.get_mal_max_logit, M.get_mal_max_logit] if mode == "combined" else [M.get_mass_max_logit, M.get_mal_max_logit]
+    funcs_o = [O.mil_mal_max, O.mil_mal_max] if mode == "combined" else [O.mil_mass_max, O.mil_mal_max]
+    old = (cfg.TRAIN.WS_LOSS_USE_ADAPTIVE_SCALE_FACTOR, cfg.get("FUSED_LOSS", True))
+    try:
+        for adaptive, step in ((True, 4100), (True, 0), (False, 10)):
+            cfg.TRAIN.WS_LOSS_USE_ADAPTIVE_SCALE_FACTOR = adaptive
+            # the oracle has no notion of an empty bag (tf.arg_max would fail): evaluate it on the
+            # non-empty bags and rescale the mean to all bags
+            keep = [b for b in range(n_bags) if counts[b] > 0]
+            sel_rows = np.concatenate([np.nonzero(rois[:, 0] - offset == b)[0] for b in keep])
+            inds = np.repeat(np.arange(len(keep)), [counts[b] for b in keep])
+            want = O.loss_mil(logits_np[sel_rows], inds, bag_labels[keep], len(keep), step, funcs_o,
+                              dict(WS_LOSS_USE_ADAPTIVE_SCALE_FACTOR=adaptive,
+                                   WS_LOSS_SCALE_FACTOR=cfg.TRAIN.WS_LOSS_SCALE_FACTOR,
+                                   WS_MAL_PCT=cfg.TRAIN.WS_MAL_PCT)) * len(keep) / n_bags
+            res = []
+            for fused in (True, False):
+                cfg.FUSED_LOSS = fused
+                x = torch.tensor(logits_np, device="cuda", requires_grad=True)
+                col = torch.from_numpy(rois).cuda()[:, 0] - offset          # strided view, like rois[n_valid:, 0] - n_s
+                lab = torch.from_numpy(bag_labels).cuda()
+                loss = TB.mil_loss(x, col, lab, n_bags, step, funcs_t)
+                (loss * 1.7).backward()
+                res.append((float(loss.detach()), x.grad.clone()))
+            assert abs(res[0][0] - want) <= 1e-5 * max(abs(want), 1e-3), (mode, adaptive, step, res[0][0], want)
+            assert abs(res[0][0] - res[1][0]) <= 2e-6 * max(abs(want), 1e-3)
+            g_f, g_t = res[0][1], res[1][1]
+            assert float((g_f - g_t).abs().max()) <= 2e-6 * float(g_t.abs().max().clamp_min(1e-12))
+            assert int((g_f != 0).any(dim=1).sum()) <= n_bags - 1            # one row per non-empty bag at most
+            assert torch.equal((g_f != 0).any(dim=1), (g_t != 0).any(dim=1))
+    finally:
+        cfg.TRAIN.WS_LOSS_USE_ADAPTIVE_SCALE_FACTOR, cfg.FUSED_LOSS = old

@@ -61,6 +61,8 @@ SYMBOLS = {
     "wssdl_image_to_blob": (_i, [_vp, _i, _i, _i, _d, _i, _vp, _i, _i, _i, _i, _vp]),
     "wssdl_flip_boxes": (_i, [_vp, _i, _i, _f, _vp]),
     "wssdl_mil_select": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "wssdl_mil_loss_forward": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp]),
+    "wssdl_mil_loss_backward": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "wssdl_multi_task_loss_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "wssdl_multi_task_loss_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
                                            _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),

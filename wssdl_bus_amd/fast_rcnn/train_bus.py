@@ -65,6 +65,14 @@ def mil_loss(cls_score_ws, batch_inds, mil_label, n_bags, global_step, funcs, co
     [0, WS_MAL_PCT, 1-WS_MAL_PCT] and by 1 - 0.99*0.9^floor(step/2000) (or a constant).
     On the GPU the bag selection is the HIP op (no host round trip); on CPU tensors (tests) the
     host-side restatement of mil/core.py runs."""
+    if cfg.TRAIN.WS_LOSS_USE_ADAPTIVE_SCALE_FACTOR:
+        scale = 1.0 - 0.99 * (0.9 ** (int(global_step) // 2000))      # exponential_decay, staircase
+    else:
+        scale = cfg.TRAIN.WS_LOSS_SCALE_FACTOR
+    if cls_score_ws.is_cuda and cfg.get('FUSED_LOSS', True):
+        # selection + weighted CE + mean as one device op with its own backward (f1)
+        prior = [0.0, float(cfg.TRAIN.WS_MAL_PCT), 1.0 - float(cfg.TRAIN.WS_MAL_PCT)]
+        return mil_core.mil_loss_device(cls_score_ws, batch_inds, 0.0, mil_label, n_bags, funcs, prior, scale)
     valid = None
     if cls_score_ws.is_cuda:
         bag_logits, _, valid = mil_core.get_bag_logit_device(cls_score_ws, batch_inds, 0.0, mil_label,
@@ -77,10 +85,6 @@ def mil_loss(cls_score_ws, batch_inds, mil_label, n_bags, global_step, funcs, co
     if valid is not None:                          # an empty bag (no proposals) carries no loss
         w = w * valid.to(w.dtype)
     ce = F.cross_entropy(bag_logits, label, reduction='none')
-    if cfg.TRAIN.WS_LOSS_USE_ADAPTIVE_SCALE_FACTOR:
-        scale = 1.0 - 0.99 * (0.9 ** (int(global_step) // 2000))      # exponential_decay, staircase
-    else:
-        scale = cfg.TRAIN.WS_LOSS_SCALE_FACTOR
     return (scale * (w * ce)).mean()
 
 

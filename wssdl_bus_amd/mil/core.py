@@ -93,3 +93,56 @@ def get_bag_logit_device(instance_logits, bag_column, bag_offset, bag_labels, ba
     if return_valid:
         return bag_logits, scale, valid
     return bag_logits, scale
+
+
+class _MilLoss(torch.autograd.Function):
+    """The MIL term as one device op (csrc/mil.hip): selection + weighted CE + mean, and its backward."""
+
+    @staticmethod
+    def forward(ctx, instance_logits, bag_column, bag_offset, bag_labels, n_bags, sel1, sel_other, class_weights, scale):
+        import numpy as np
+        from .. import _lib
+        logits = instance_logits.contiguous()
+        R, K = logits.shape
+        col = bag_column if bag_column.dtype == torch.float32 else bag_column.to(torch.float32)
+        stride = col.stride(0) if col.dim() == 1 and R > 1 else 1
+        if col.dim() != 1 or (R > 1 and stride < 1):
+            col = col.reshape(-1).contiguous()
+            stride = 1
+        labels = bag_labels.reshape(-1).to(torch.int32).contiguous()
+        dev = logits.device
+        rows = torch.empty((n_bags,), dtype=torch.int32, device=dev)
+        bag_loss = torch.empty((n_bags,), dtype=torch.float32, device=dev)
+        loss = torch.empty((1,), dtype=torch.float32, device=dev)
+        cw = np.ascontiguousarray(np.asarray(class_weights, np.float32))
+        with torch.cuda.device(dev), _lib.timed("mil_loss", dict(R=R, bags=int(n_bags))):
+            _lib.check(_lib.lib().wssdl_mil_loss_forward(
+                _lib.ptr(logits), R, K, _lib.ptr(col), int(stride), float(bag_offset), _lib.ptr(labels), int(n_bags),
+                int(sel1), int(sel_other), _lib.host_ptr(cw), float(scale), _lib.ptr(loss), _lib.ptr(rows),
+                _lib.ptr(bag_loss), _lib.stream()), "wssdl_mil_loss_forward")
+        ctx.save_for_backward(logits, col, labels, rows)
+        ctx.misc = (R, K, int(stride), float(bag_offset), int(n_bags), cw, float(scale))
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        from .. import _lib
+        logits, col, labels, rows = ctx.saved_tensors
+        R, K, stride, bag_offset, n_bags, cw, scale = ctx.misc
+        g = torch.empty_like(logits)
+        gl = grad_loss.reshape(1).to(torch.float32).contiguous()
+        with torch.cuda.device(logits.device), _lib.timed("mil_loss_backward", dict(R=R, bags=n_bags)):
+            _lib.check(_lib.lib().wssdl_mil_loss_backward(
+                _lib.ptr(logits), R, K, _lib.ptr(col), stride, bag_offset, _lib.ptr(labels), n_bags, _lib.ptr(rows),
+                _lib.host_ptr(cw), scale, _lib.ptr(gl), _lib.ptr(g), _lib.stream()), "wssdl_mil_loss_backward")
+        return (g,) + (None,) * 8
+
+
+def mil_loss_device(instance_logits, bag_column, bag_offset, bag_labels, n_bags, funcs, class_weights, scale):
+    """train_bus.py:239-260 / :650-671 on the device: mean over the bags of
+    scale * class_weights[label] * CE(selected instance's logits, label); an empty bag contributes 0.
+    No instances at all raises ValueError like get_bag_logit_device."""
+    if instance_logits.shape[0] == 0 and n_bags > 0:
+        raise ValueError("get_bag_logit: no instances for %d bag(s)" % n_bags)
+    return _MilLoss.apply(instance_logits, bag_column, bag_offset, bag_labels, int(n_bags), _SELECTORS[funcs[0]],
+                          _SELECTORS[funcs[1]], class_weights, scale)
