@@ -214,9 +214,12 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
     const int r = WHOLE_ROI ? (int)item : ((PWS > 0 && PH == PWS) ? (int)(item / (PWS > 0 ? PWS : 1)) : (int)(item / PH));
     const int ph_first = WHOLE_ROI ? 0 : (int)(item - (long long)r * PH);
     const int ph_last = WHOLE_ROI ? PH : ph_first + 1;
-    // The geometry of the RoI costs ~160 VALU instructions per wave (coordinates, two IEEE
-    // divisions, the windows): a sixth of a one-row wave's VALU work, and the kernel's VALU is 74 %
-    // busy (SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES) -- a wave that walks the whole RoI pays it once.
+    // The geometry of the RoI costs ~170 VALU instructions per wave (coordinates, two IEEE
+    // divisions, the windows): a fifth of a one-row wave's VALU work, and the kernel's VALU is 75 %
+    // busy (SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES).  Paying it once per RoI was measured both ways
+    // and lost both times: a wave that walks the whole RoI (WHOLE_ROI: 0.80 ms, 34 k waves of very
+    // unequal length) and 7-wave workgroups whose wave 0 shares it through LDS (+4 %: the barrier
+    // and the coarser workgroup slots cost more than the instructions saved).
     const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);        // wave-uniform values
     const int batch = __builtin_amdgcn_readfirstlane(g.batch);
     const bool bad = batch < 0 || batch >= N;
@@ -303,21 +306,66 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
         return (CPL == 4) ? (mi[0] | (mi[1] << 8) | (mi[2 % CPL] << 16) | (mi[3 % CPL] << 24)) : (mi[0] | (mi[1] << 8));
     };
     if constexpr (PWS > 0) {
-        // PW known at compile time: the results of a bin row stay in registers (5 per bin) and its
-        // stores are issued together behind the last bin.  On gfx9-family hardware stores and loads
-        // share the in-order vmcnt counter: a wave that waits for a load also waits for every store
-        // it issued before it, so a store per bin puts a store acknowledgement on the wave's critical
-        // path per bin instead of per row.
+        // PW known at compile time: the bin row is walked ROW BY ROW through all its bins, with the
+        // PWS running maxima in registers (8 per bin).
+        // * Adjacent bins share a column whenever their boundary is not a whole cell
+        //   (floor / ceil, roi_pooling_op_gpu.cu.cc:55-58): the last cell a bin loads in a window row is
+        //   handed to the next bin in registers instead of being loaded again -- 26 % fewer loads on the
+        //   proposals of a train step (SQ_INSTS_VMEM_RD); the loads all go to L2 (the reuse distance
+        //   between two bins of a wave is ~190 KiB of other waves' traffic, the L1 holds 32), which runs at
+        //   55 % of its peak here.  A bin's own scan order is untouched: (h ascending, w ascending), strict >.
+        // * The stores of the row are issued together behind its last bin.  On gfx9-family hardware
+        //   stores and loads share the in-order vmcnt counter: a wave that waits for a load also waits
+        //   for every store it issued before it, so a store per bin puts a store acknowledgement on
+        //   the wave's critical path per bin instead of per row.
         vec res[PWS];
-        unsigned resc[PWS];
+        unsigned mi[PWS][CPL];
+        int wss[PWS], wes[PWS];
 #pragma unroll
         for (int pw = 0; pw < PWS; ++pw) {
-            unsigned mi[CPL];
-            pool_bin(__builtin_amdgcn_readlane(my_ws, pw), __builtin_amdgcn_readlane(my_we, pw), res[pw], mi);
-            resc[pw] = pack(mi);
-        }
+            wss[pw] = __builtin_amdgcn_readlane(my_ws, pw);
+            wes[pw] = __builtin_amdgcn_readlane(my_we, pw);
+            const bool empty = row_dead || (wes[pw] <= wss[pw]);
 #pragma unroll
-        for (int pw = 0; pw < PWS; ++pw) store_bin(pw, res[pw], resc[pw]);
+            for (int k = 0; k < CPL; ++k) { res[pw][k] = empty ? 0.0f : -FLT_MAX;  mi[pw][k] = ARG8_EMPTY; }
+        }
+        auto upd = [](vec &mv, unsigned (&m)[CPL], const vec &v, unsigned code) {
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) if (v[k] > mv[k]) { mv[k] = v[k];  m[k] = code; }
+        };
+#if WSSDL_FWDC_ABLATE != 3
+        if (!row_dead) {
+            for (int h = hs; h < he; ++h) {
+                const int so_row = h * W * cell_bytes;
+                const unsigned rcode = (unsigned)(h - hs) << 4;
+                vec carry = (vec)(0.0f);          // cell (h, carry_w): the last one the previous bin loaded
+                int carry_w = -1;
+#pragma unroll
+                for (int pw = 0; pw < PWS; ++pw) {
+                    const int ws = wss[pw], we = wes[pw];
+                    if (we <= ws) continue;
+                    int w = ws;
+                    if (carry_w == ws) { upd(res[pw], mi[pw], carry, rcode);  w = ws + 1; }
+                    for (; w + 1 < we; w += 2) {          // two cells in flight
+                        const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
+                        const vec v1 = LaneVec<CPL>::load(rs, voff, so_row + (w + 1) * cell_bytes);
+                        const unsigned code0 = rcode | (unsigned)(w - ws);
+                        upd(res[pw], mi[pw], v0, code0);
+                        upd(res[pw], mi[pw], v1, code0 + 1u);
+                        carry = v1;
+                    }
+                    if (w < we) {
+                        const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
+                        upd(res[pw], mi[pw], v0, rcode | (unsigned)(w - ws));
+                        carry = v0;
+                    }
+                    carry_w = we - 1;
+                }
+            }
+        }
+#endif
+#pragma unroll
+        for (int pw = 0; pw < PWS; ++pw) store_bin(pw, res[pw], pack(mi[pw]));
     } else {
         for (int pw = 0; pw < PW; ++pw) {
             vec mv;
