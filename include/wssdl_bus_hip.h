@@ -251,6 +251,20 @@ WSSDL_API int wssdl_roi_pool_forward_compact(const float *bottom, int N, int H, 
                            const float *rois, int R, int pooled_h, int pooled_w, float spatial_scale,
                            int rounding, float *top, uint8_t *argmax8, int32_t *overflow,
                            wssdl_stream_t stream);
+/* The same forward with the RoI geometry taken from a table: wssdl_roi_pool_forward_windows writes one
+ * 32-byte entry per (roi, bin row) -- batch index, the clipped window rows, the window columns of the 7
+ * bins (roi_pooling_op_gpu.cu.cc:36-64) -- and raises *overflow like the forward would;
+ * wssdl_roi_pool_forward_compact_windows reads it with scalar loads instead of recomputing it in every
+ * wave (~1/5 of the kernel's vector instructions).  7 x 7 bins, C % 256 == 0;
+ * wssdl_roi_pool_forward_windows_bytes returns 0 for shapes it does not take (use the call above). */
+WSSDL_API size_t wssdl_roi_pool_forward_windows_bytes(int R, int H, int W, int C, int pooled_h, int pooled_w);
+WSSDL_API int wssdl_roi_pool_forward_windows(const float *rois, int R, int N, int H, int W, int C, int pooled_h,
+                                   int pooled_w, float spatial_scale, int rounding, void *table,
+                                   size_t table_bytes, int32_t *overflow, wssdl_stream_t stream);
+WSSDL_API int wssdl_roi_pool_forward_compact_windows(const float *bottom, int N, int H, int W, int C,
+                                           const float *rois, int R, int pooled_h, int pooled_w,
+                                           float spatial_scale, int rounding, const void *table,
+                                           float *top, uint8_t *argmax8, wssdl_stream_t stream);
 /* Backward in two calls.  The lists that drive it depend on the RoIs and the shapes only, so
  * wssdl_roi_pool_backward_prepare can run as soon as the RoIs exist (e.g. right behind the
  * forward): per (image, tile) it builds the stream of candidate bins in the reference's

@@ -48,9 +48,10 @@ def test_compact_pair_vs_oracle(torch_cuda, shape, mode):
     rois = _rois_for(rs, R, N, H, W)
     et, ea = c_oracle.roi_pool_forward(f, rois, 7, 7, 1.0 / 16, mode, threads=16)
     ft, rt = torch.from_numpy(f).cuda(), torch.from_numpy(rois).cuda()
-    # forward kernels: 0 = automatic (a whole RoI or one bin row per wave by launch size), 1 = one bin
-    # row per wave with a store per bin, 2 = 128-channel waves, 3 = one RoI (7 one-row waves) per
-    # workgroup, 4 = one bin row per wave, 5 = a whole RoI per wave, 9 = the two-rows-per-wave sliced kernel
+    # forward kernels: 0 = default (windows from the table of wssdl_roi_pool_forward_windows when the shape
+    # allows, shared bin columns in registers), 1 = one bin row per wave with a store per bin, 2 =
+    # 128-channel waves, 3 = one RoI (7 one-row waves) per workgroup, 4 = as 0 with the geometry computed
+    # in the kernel, 5 = a whole RoI per wave, 9 = the two-rows-per-wave sliced kernel
     for fwd in ("9", "3", "2", "1", "4", "5", "0"):
         os.environ["WSSDL_ROI_FWD_VARIANT"] = fwd
         try:
@@ -143,6 +144,31 @@ def test_compact_overflow_flag_for_rois_far_outside_the_map(torch_cuda):
         return int(flag.item())
     assert run([[0, 0, 0, 1007, 607], [0, -40, -40, 1100, 700]]) == 0       # inside / slightly outside: fine
     assert run([[0, 0, 0, 1007, 607], [0, -9000, -9000, 9000, 9000]]) == 1  # one bin spans the whole map
+
+    # the window-table form raises the same flag from its table kernel, and pools the same values
+    f2 = torch.relu(torch.randn((1, 38, 63, 256), device="cuda"))
+    L = _lib.lib()
+    nwin = L.wssdl_roi_pool_forward_windows_bytes(2, 38, 63, 256, 7, 7)
+    assert nwin == 2 * 7 * 32 and L.wssdl_roi_pool_forward_windows_bytes(2, 38, 63, 64, 7, 7) == 0
+    assert L.wssdl_roi_pool_forward_windows_bytes(2, 38, 63, 256, 6, 6) == 0
+    table = torch.empty((nwin,), dtype=torch.uint8, device="cuda")
+    for rois, want in (([[0, 0, 0, 1007, 607], [0, -40, -40, 1100, 700]], 0),
+                       ([[0, 0, 0, 1007, 607], [0, -9000, -9000, 9000, 9000]], 1)):
+        r = torch.tensor(rois, dtype=torch.float32, device="cuda")
+        flag.zero_()
+        _lib.check(L.wssdl_roi_pool_forward_windows(_lib.ptr(r), 2, 1, 38, 63, 256, 7, 7, 1.0 / 16, 0, _lib.ptr(table),
+                                                    nwin, _lib.ptr(flag), _lib.stream()), "windows")
+        assert int(flag.item()) == want
+        if want == 0:
+            t1 = torch.empty((2, 7, 7, 256), device="cuda")
+            a1 = torch.empty((2, 7, 7, 256), dtype=torch.uint8, device="cuda")
+            t2, a2 = torch.empty_like(t1), torch.empty_like(a1)
+            _lib.check(L.wssdl_roi_pool_forward_compact_windows(_lib.ptr(f2), 1, 38, 63, 256, _lib.ptr(r), 2, 7, 7, 1.0 / 16,
+                                                                0, _lib.ptr(table), _lib.ptr(t1), _lib.ptr(a1),
+                                                                _lib.stream()), "fwd windows")
+            _lib.check(L.wssdl_roi_pool_forward_compact(_lib.ptr(f2), 1, 38, 63, 256, _lib.ptr(r), 2, 7, 7, 1.0 / 16, 0,
+                                                        _lib.ptr(t2), _lib.ptr(a2), _lib.ptr(flag), _lib.stream()), "fwd")
+            assert torch.equal(t1, t2) and torch.equal(a1, a2)
 
 
 def test_autograd_uses_compact_path_and_matches_oracle(torch_cuda):

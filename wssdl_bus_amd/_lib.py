@@ -51,6 +51,9 @@ SYMBOLS = {
     "wssdl_roi_pool_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "wssdl_roi_pool_compact_supported": (_i, [_i, _i, _i, _i, _i]),
     "wssdl_roi_pool_forward_compact": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "wssdl_roi_pool_forward_windows_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "wssdl_roi_pool_forward_windows": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp]),
+    "wssdl_roi_pool_forward_compact_windows": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "wssdl_roi_pool_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "wssdl_roi_pool_backward_prepare": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp]),
     "wssdl_roi_pool_backward_compact": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _i,

@@ -151,6 +151,40 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_compact_kernel(
     }
 }
 
+// Window table of the forward (7 x 7 bins): one 32-byte entry per (roi, ph) bin row,
+//   word 0 = batch index, word 1 = hs | he << 8 (clipped window rows of the bin row),
+//   bytes 8..14 = wstart of the 7 bin columns, bytes 16..22 = wend.
+// Written by roi_windows_kernel (one lane per bin row), read by the forward with two scalar loads: the
+// RoI geometry -- coordinates, two IEEE divisions, floor / ceil per bin -- then costs a forward wave no
+// vector instruction at all instead of ~170 of its ~890.
+constexpr int WIN_ENTRY_WORDS = 8;
+
+__global__ __launch_bounds__(256) void roi_windows_kernel(const float *__restrict__ rois, int R, int N, int H, int W,
+                                                          float scale, int rounding, unsigned *__restrict__ table,
+                                                          int *__restrict__ overflow) {
+    const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (item >= (long long)R * 7) return;
+    const int r = (int)(item / 7), ph = (int)(item - (long long)r * 7);
+    const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, 7, 7);
+    const int hs = win_start(ph, g.bin_h, g.sh, H, rounding), he = win_end(ph, g.bin_h, g.sh, H, rounding);
+    unsigned wsb[2] = {0u, 0u}, web[2] = {0u, 0u};
+    bool wide = false, any = false;
+#pragma unroll
+    for (int pw = 0; pw < 7; ++pw) {
+        const int ws = win_start(pw, g.bin_w, g.sw, W, rounding), we = win_end(pw, g.bin_w, g.sw, W, rounding);
+        wsb[pw >> 2] |= (unsigned)ws << (8 * (pw & 3));
+        web[pw >> 2] |= (unsigned)we << (8 * (pw & 3));
+        wide |= we - ws > ARG8_MAX_WIN_W;
+        any |= we > ws;
+    }
+    unsigned *e = table + (size_t)item * WIN_ENTRY_WORDS;
+    e[0] = (unsigned)g.batch;
+    e[1] = (unsigned)hs | ((unsigned)he << 8);
+    e[2] = wsb[0];  e[3] = wsb[1];  e[4] = web[0];  e[5] = web[1];  e[6] = 0u;  e[7] = 0u;
+    const bool bad = g.batch < 0 || g.batch >= N;
+    if (overflow && !bad && he > hs && any && (wide || he - hs > ARG8_MAX_WIN_H)) atomicOr(overflow, 1);
+}
+
 // Forward, wave-uniform form: ONE wave = one (roi, ph) bin row x 64*CPL channels, so the window
 // bounds, the loops over the window and the cell offsets are scalar (SALU); a cell costs one
 // buffer load (scalar cell offset + constant lane offset) and 3 VALU per channel.  The sliced
@@ -184,11 +218,13 @@ struct LaneVec<2> {
 };
 
 template <int CPL, int RPW /* waves per workgroup */, int PWS /* PW when known at compile time, else 0 */,
-          bool WHOLE_ROI /* a wave walks all PH bin rows of one RoI instead of one bin row */>
+          bool WHOLE_ROI /* a wave walks all PH bin rows of one RoI instead of one bin row */,
+          bool TAB /* the windows come from the table of roi_windows_kernel (PH = PWS = 7, one bin row per wave) */>
 __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
     const float *__restrict__ bottom, int N, int H, int W, int C, const float *__restrict__ rois,
     int R, int PH, int PW, float scale, int rounding, float *__restrict__ top,
-    unsigned char *__restrict__ arg8, int *__restrict__ overflow, int slices) {
+    unsigned char *__restrict__ arg8, int *__restrict__ overflow, int slices,
+    const unsigned *__restrict__ table /* window table (7 x 7 bins, one bin row per wave) or NULL */) {
     typedef typename LaneVec<CPL>::vec vec;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -220,8 +256,37 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
     // and lost both times: a wave that walks the whole RoI (WHOLE_ROI: 0.80 ms, 34 k waves of very
     // unequal length) and 7-wave workgroups whose wave 0 shares it through LDS (+4 %: the barrier
     // and the coarser workgroup slots cost more than the instructions saved).
-    const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);        // wave-uniform values
-    const int batch = __builtin_amdgcn_readfirstlane(g.batch);
+    static_assert(!TAB || (PWS == 7 && !WHOLE_ROI), "the window table describes 7 x 7 bins, one bin row per entry");
+    int batch, t_hs = 0, t_he = 0;
+    unsigned t_ws0 = 0u, t_ws1 = 0u, t_we0 = 0u, t_we1 = 0u;
+    int my_ws = 0, my_we = 0, my_hs = 0, my_he = 0;
+    constexpr bool use_table = TAB;
+    if constexpr (use_table) {
+        // (uniform address: two scalar loads)
+        const unsigned *e = table + (size_t)item * WIN_ENTRY_WORDS;
+        batch = (int)e[0];
+        t_hs = (int)(e[1] & 0xffu);
+        t_he = (int)((e[1] >> 8) & 0xffu);
+        t_ws0 = e[2];  t_ws1 = e[3];  t_we0 = e[4];  t_we1 = e[5];
+    } else {
+        const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);        // wave-uniform values
+        batch = __builtin_amdgcn_readfirstlane(g.batch);
+        // windows of the bin columns and rows: lane p computes bin column p and bin row p once (a lane's
+        // own copy per bin cost ~20 VALU instructions per bin), read back with v_readlane; PW, PH <= 64
+        const int pme = (lane < PW) ? lane : 0;
+        my_ws = win_start(pme, g.bin_w, g.sw, W, rounding);
+        my_we = win_end(pme, g.bin_w, g.sw, W, rounding);
+        const int phme = (lane < PH) ? lane : 0;
+        my_hs = win_start(phme, g.bin_h, g.sh, H, rounding);
+        my_he = win_end(phme, g.bin_h, g.sh, H, rounding);
+        const unsigned long long wide = __ballot(lane < PW && my_we - my_ws > ARG8_MAX_WIN_W);    // (every lane votes)
+        const unsigned long long tall = __ballot(lane < PH && lane >= ph_first && lane < ph_last && my_he - my_hs > ARG8_MAX_WIN_H);
+        const unsigned long long cols = __ballot(lane < PW && my_we > my_ws);
+        const unsigned long long rows_live = __ballot(lane < PH && lane >= ph_first && lane < ph_last && my_he > my_hs);
+        const bool bad0 = batch < 0 || batch >= N;
+        if (overflow && !bad0 && lane == 0 && ((wide != 0ull && rows_live != 0ull) || (tall != 0ull && cols != 0ull)))
+            atomicOr(overflow, 1);
+    }
     const bool bad = batch < 0 || batch >= N;
     const int c0 = (slice * 64 + lane) * CPL;
     const bool lane_ok = c0 < C;
@@ -229,23 +294,10 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
     const int cell_bytes = C * 4;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(bottom + (size_t)(bad ? 0 : batch) * H * W * C), 0, H * W * cell_bytes, 0x00020000);
-    // windows of the bin columns and rows: lane p computes bin column p and bin row p once (a lane's
-    // own copy per bin cost ~20 VALU instructions per bin), read back with v_readlane; PW, PH <= 64
-    const int pme = (lane < PW) ? lane : 0;
-    const int my_ws = win_start(pme, g.bin_w, g.sw, W, rounding);
-    const int my_we = win_end(pme, g.bin_w, g.sw, W, rounding);
-    const int phme = (lane < PH) ? lane : 0;
-    const int my_hs = win_start(phme, g.bin_h, g.sh, H, rounding);
-    const int my_he = win_end(phme, g.bin_h, g.sh, H, rounding);
-    const unsigned long long wide = __ballot(lane < PW && my_we - my_ws > ARG8_MAX_WIN_W);    // (every lane votes)
-    const unsigned long long tall = __ballot(lane < PH && lane >= ph_first && lane < ph_last && my_he - my_hs > ARG8_MAX_WIN_H);
-    const unsigned long long cols = __ballot(lane < PW && my_we > my_ws);
-    const unsigned long long rows_live = __ballot(lane < PH && lane >= ph_first && lane < ph_last && my_he > my_hs);
-    if (overflow && !bad && lane == 0 && ((wide != 0ull && rows_live != 0ull) || (tall != 0ull && cols != 0ull)))
-        atomicOr(overflow, 1);
 
     for (int ph = ph_first; ph < ph_last; ++ph) {
-    const int hs = __builtin_amdgcn_readlane(my_hs, ph), he = __builtin_amdgcn_readlane(my_he, ph);
+    const int hs = use_table ? t_hs : __builtin_amdgcn_readlane(my_hs, ph);
+    const int he = use_table ? t_he : __builtin_amdgcn_readlane(my_he, ph);
     const bool row_dead = (he <= hs) || bad;
     const size_t o_row = (((size_t)r * PH + ph) * PW) * C + c0;
     // one bin: the reference's scan (h ascending, w ascending, strict >: roi_pooling_op_gpu.cu.cc:66-79)
@@ -323,8 +375,13 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
         int wss[PWS], wes[PWS];
 #pragma unroll
         for (int pw = 0; pw < PWS; ++pw) {
-            wss[pw] = __builtin_amdgcn_readlane(my_ws, pw);
-            wes[pw] = __builtin_amdgcn_readlane(my_we, pw);
+            if (use_table) {
+                wss[pw] = (int)(((pw < 4 ? t_ws0 : t_ws1) >> (8 * (pw & 3))) & 0xffu);
+                wes[pw] = (int)(((pw < 4 ? t_we0 : t_we1) >> (8 * (pw & 3))) & 0xffu);
+            } else {
+                wss[pw] = __builtin_amdgcn_readlane(my_ws, pw);
+                wes[pw] = __builtin_amdgcn_readlane(my_we, pw);
+            }
             const bool empty = row_dead || (wes[pw] <= wss[pw]);
 #pragma unroll
             for (int k = 0; k < CPL; ++k) { res[pw][k] = empty ? 0.0f : -FLT_MAX;  mi[pw][k] = ARG8_EMPTY; }
@@ -738,11 +795,57 @@ extern "C" int wssdl_roi_pool_compact_supported(int H, int W, int C, int pooled_
     return compact_supported(H, W, C, pooled_h, pooled_w) ? 1 : 0;
 }
 
+// windows table: 7 x 7 bins and a shape the wave-uniform kernel takes with 256-channel waves
+static bool window_table_supported(int H, int W, int C, int pooled_h, int pooled_w) {
+    if (!compact_supported(H, W, C, pooled_h, pooled_w) || pooled_h != 7 || pooled_w != 7) return false;
+    if (C % 256 != 0 || H > 255 || W > 255) return false;
+    const int slices = C / 256;
+    return ((slices >= 8 && slices % 8 == 0) || (slices < 8 && 8 % slices == 0)) && (long long)H * W * C * 4 < 0x7fffffffLL;
+}
+
+extern "C" size_t wssdl_roi_pool_forward_windows_bytes(int R, int H, int W, int C, int pooled_h, int pooled_w) {
+    if (R <= 0 || !window_table_supported(H, W, C, pooled_h, pooled_w)) return 0;
+    return (size_t)R * 7 * WIN_ENTRY_WORDS * sizeof(unsigned);
+}
+
+extern "C" int wssdl_roi_pool_forward_windows(const float *rois, int R, int N, int H, int W, int C, int pooled_h,
+                                              int pooled_w, float spatial_scale, int rounding, void *table,
+                                              size_t table_bytes, int32_t *overflow, wssdl_stream_t stream) {
+    if (R < 0 || N < 1 || !window_table_supported(H, W, C, pooled_h, pooled_w)) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (rounding != WSSDL_ROI_ROUND_CUDA && rounding != WSSDL_ROI_ROUND_CPU) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (R == 0) return WSSDL_OK;
+    if (!rois || !table || (reinterpret_cast<uintptr_t>(table) & 31)) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (table_bytes < wssdl_roi_pool_forward_windows_bytes(R, H, W, C, pooled_h, pooled_w)) return WSSDL_ERR_WORKSPACE;
+    hipLaunchKernelGGL(roi_windows_kernel, dim3(cdiv((long long)R * 7, 256)), dim3(256), 0, as_stream(stream), rois, R, N,
+                       H, W, spatial_scale, rounding, static_cast<unsigned *>(table), overflow);
+    return check_launch();
+}
+
+static int forward_compact(const float *bottom, int N, int H, int W, int C, const float *rois, int R, int pooled_h,
+                           int pooled_w, float spatial_scale, int rounding, float *top, uint8_t *argmax8,
+                           int32_t *overflow, const unsigned *table, wssdl_stream_t stream);
+
 extern "C" int wssdl_roi_pool_forward_compact(const float *bottom, int N, int H, int W, int C,
                                               const float *rois, int R, int pooled_h, int pooled_w,
                                               float spatial_scale, int rounding, float *top,
                                               uint8_t *argmax8, int32_t *overflow,
                                               wssdl_stream_t stream) {
+    return forward_compact(bottom, N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top, argmax8,
+                           overflow, nullptr, stream);
+}
+
+extern "C" int wssdl_roi_pool_forward_compact_windows(const float *bottom, int N, int H, int W, int C,
+                                                      const float *rois, int R, int pooled_h, int pooled_w,
+                                                      float spatial_scale, int rounding, const void *table,
+                                                      float *top, uint8_t *argmax8, wssdl_stream_t stream) {
+    if (!table || !window_table_supported(H, W, C, pooled_h, pooled_w)) return WSSDL_ERR_INVALID_ARGUMENT;
+    return forward_compact(bottom, N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top, argmax8,
+                           nullptr, static_cast<const unsigned *>(table), stream);
+}
+
+static int forward_compact(const float *bottom, int N, int H, int W, int C, const float *rois, int R, int pooled_h,
+                           int pooled_w, float spatial_scale, int rounding, float *top, uint8_t *argmax8,
+                           int32_t *overflow, const unsigned *table, wssdl_stream_t stream) {
     if (N < 0 || R < 0 || !compact_supported(H, W, C, pooled_h, pooled_w)) return WSSDL_ERR_INVALID_ARGUMENT;
     if (rounding != WSSDL_ROI_ROUND_CUDA && rounding != WSSDL_ROI_ROUND_CPU)
         return WSSDL_ERR_INVALID_ARGUMENT;
@@ -759,6 +862,7 @@ extern "C" int wssdl_roi_pool_forward_compact(const float *bottom, int N, int H,
     unsigned *a8 = reinterpret_cast<unsigned *>(argmax8);
     int variant = 0;
     if (const char *e = getenv("WSSDL_ROI_FWD_VARIANT")) variant = atoi(e);      // tuning
+    if (table) variant = 0;
     // wave-uniform kernel, 256 (or 128) channels per wave.  Variants: 0 = automatic, 1 = one bin row per
     // wave with a store per bin, 2 = 128-channel waves, 3 = 7 one-row waves per workgroup, 4 = one bin
     // row per wave, 5 = a whole RoI per wave, 9 = the sliced round-1 form
@@ -778,14 +882,22 @@ extern "C" int wssdl_roi_pool_forward_compact(const float *bottom, int N, int H,
             long long blocks = slices >= 8 ? groups * slices : 8 * ((groups + 8 / slices - 1) / (8 / slices));
             if (blocks <= 0x7fffffffLL) {
 #define WSSDL_FWD_ROWS(CPL, RPW, PWS, WHOLE) \
-    hipLaunchKernelGGL((roi_pool_fwd_rows_kernel<CPL, RPW, PWS, WHOLE>), dim3((unsigned)blocks), dim3(64 * RPW), 0, st, bottom, N, \
-                       H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top, argmax8, overflow, slices)
-                if (variant == 3 && cpl == 4) WSSDL_FWD_ROWS(4, 7, 0, false);
+    hipLaunchKernelGGL((roi_pool_fwd_rows_kernel<CPL, RPW, PWS, WHOLE, false>), dim3((unsigned)blocks), dim3(64 * RPW), 0, st, \
+                       bottom, N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top, argmax8, overflow, \
+                       slices, nullptr)
+#define WSSDL_FWD_TAB(CPL) \
+    hipLaunchKernelGGL((roi_pool_fwd_rows_kernel<CPL, 4, 7, false, true>), dim3((unsigned)blocks), dim3(64 * 4), 0, st, \
+                       bottom, N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top, argmax8, overflow, \
+                       slices, table)
+                if (table && cpl == 4 && rpw == 4 && !whole) WSSDL_FWD_TAB(4);
+                else if (table) return WSSDL_ERR_INVALID_ARGUMENT;
+                else if (variant == 3 && cpl == 4) WSSDL_FWD_ROWS(4, 7, 0, false);
                 else if (cpl == 2) { if (whole) WSSDL_FWD_ROWS(2, 4, 7, true); else WSSDL_FWD_ROWS(2, 4, 0, false); }
                 else if (whole) WSSDL_FWD_ROWS(4, 4, 7, true);
                 else if ((variant == 0 || variant == 4) && pooled_w == 7) WSSDL_FWD_ROWS(4, 4, 7, false);
                 else WSSDL_FWD_ROWS(4, 4, 0, false);
 #undef WSSDL_FWD_ROWS
+#undef WSSDL_FWD_TAB
                 return check_launch();
             }
         }

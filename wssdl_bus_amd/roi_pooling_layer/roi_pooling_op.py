@@ -10,6 +10,7 @@ Layouts are the op's: bottom_data [N,H,W,C] f32 (NHWC), bottom_rois [R,5] f32,
 top_data / argmax [R,PH,PW,C].
 """
 import ctypes
+import os
 
 import torch
 
@@ -117,12 +118,30 @@ def roi_pool_compact(data, rois, pooled_height, pooled_width, spatial_scale, rou
     mode = _ROUNDING[cfg.ROI_POOL_ROUNDING if rounding is None else rounding]
     top = torch.empty((R, pooled_height, pooled_width, C), dtype=torch.float32, device=data.device)
     arg8 = torch.empty((R, pooled_height, pooled_width, C), dtype=torch.uint8, device=data.device)
-    with torch.cuda.device(data.device), \
-            _lib.timed("roi_pool_forward", dict(N=N, H=H, W=W, C=C, R=R, argmax_bytes=1)):
-        _lib.check(_lib.lib().wssdl_roi_pool_forward_compact(
-            _lib.ptr(data), N, H, W, C, _lib.ptr(rois), R, int(pooled_height), int(pooled_width),
-            float(spatial_scale), mode, _lib.ptr(top), _lib.ptr(arg8), _lib.ptr(_overflow_flag(data.device)),
-            _lib.stream()), "wssdl_roi_pool_forward_compact")
+    L = _lib.lib()
+    with torch.cuda.device(data.device):
+        nwin = L.wssdl_roi_pool_forward_windows_bytes(R, H, W, C, int(pooled_height), int(pooled_width)) \
+            if os.environ.get("WSSDL_ROI_FWD_VARIANT", "0") == "0" else 0
+        if nwin:
+            # the RoI geometry once per (roi, bin row) into a table, then the pooling kernel reads it with
+            # scalar loads (two launches, timed apart: the second is the kernel the roofline is quoted on)
+            table = torch.empty((nwin,), dtype=torch.uint8, device=data.device)
+            with _lib.timed("roi_pool_forward_windows", dict(R=R)):
+                _lib.check(L.wssdl_roi_pool_forward_windows(
+                    _lib.ptr(rois), R, N, H, W, C, int(pooled_height), int(pooled_width), float(spatial_scale), mode,
+                    _lib.ptr(table), nwin, _lib.ptr(_overflow_flag(data.device)), _lib.stream()),
+                    "wssdl_roi_pool_forward_windows")
+            with _lib.timed("roi_pool_forward", dict(N=N, H=H, W=W, C=C, R=R, argmax_bytes=1)):
+                _lib.check(L.wssdl_roi_pool_forward_compact_windows(
+                    _lib.ptr(data), N, H, W, C, _lib.ptr(rois), R, int(pooled_height), int(pooled_width),
+                    float(spatial_scale), mode, _lib.ptr(table), _lib.ptr(top), _lib.ptr(arg8), _lib.stream()),
+                    "wssdl_roi_pool_forward_compact_windows")
+        else:
+            with _lib.timed("roi_pool_forward", dict(N=N, H=H, W=W, C=C, R=R, argmax_bytes=1)):
+                _lib.check(L.wssdl_roi_pool_forward_compact(
+                    _lib.ptr(data), N, H, W, C, _lib.ptr(rois), R, int(pooled_height), int(pooled_width),
+                    float(spatial_scale), mode, _lib.ptr(top), _lib.ptr(arg8), _lib.ptr(_overflow_flag(data.device)),
+                    _lib.stream()), "wssdl_roi_pool_forward_compact")
     return top, arg8
 
 
