@@ -204,6 +204,19 @@ WSSDL_API int wssdl_roi_candidates(const float *rois, int R, const float *gt_box
                          const int32_t *num_gt_boxes, int n_images, const int32_t *images,
                          int n_sample_images, int append_gt, float *cand, int32_t *num_pos_boxes,
                          wssdl_stream_t stream);
+/* The device-sampled layer as one call: stages 0-3 (candidates, assignment, fg / bg draw, rows +
+ *   targets) launched back to back, the intermediates carved from `workspace`
+ *   (wssdl_proposal_target_device_workspace_bytes).  Outputs have the fixed shape
+ *   n_sample_images * rois_per_image rows (rois_out [.,5], labels [.] f32, the three [., 4*num_classes]);
+ *   an image that runs short of candidates leaves padding rows as described above. */
+WSSDL_API size_t wssdl_proposal_target_device_workspace_bytes(int R, int n_images, int max_gt,
+                                                    int n_sample_images, int rois_per_image, int append_gt);
+WSSDL_API int wssdl_proposal_target_device(
+    const float *rois, int R, const float *gt_boxes, int max_gt, const int32_t *num_gt_boxes, int n_images,
+    const int32_t *images, int n_sample_images, int append_gt, int rois_per_image, int fg_rois_per_image,
+    double fg_thresh, double bg_thresh_hi, double bg_thresh_lo, uint64_t seed, int num_classes,
+    const float *inside_weights_host, float *rois_out, float *labels, float *bbox_targets, float *inside_w,
+    float *outside_w, void *workspace, size_t workspace_bytes, wssdl_stream_t stream);
 WSSDL_API int wssdl_roi_sample_device(const float *cand, const double *max_overlap, int Rc,
                             const int32_t *images, int n_sample_images, int rois_per_image,
                             int fg_rois_per_image, double fg_thresh, double bg_thresh_hi,

@@ -328,3 +328,68 @@ extern "C" int wssdl_roi_candidates(const float *rois, int R, const float *gt_bo
                        append_gt, cand, num_pos_boxes);
     return check_launch();
 }
+
+// ------------------------------------------------ the device-sampled layer as one call ---
+// proposal_target_layer_tf_bus.py:15-97 / :99-160 for the supervised images with the device sampler:
+// candidates (rois + every gt slot, :44-50) -> IoU arg-max assignment (:236-240) -> fg / bg draw
+// (:243-261) -> rows, labels, targets, weights (:263-280, :187-226) as four launches behind ONE entry
+// point, the intermediates carved from the caller's workspace (four separate calls from Python cost
+// more host time than the kernels run).  The output has the fixed shape
+// n_sample_images * rois_per_image rows; an image that runs short leaves rows (-1,0,0,0,0) with
+// label -1 and zero weights.
+namespace wssdl {
+struct PtWs {
+    float *cand;
+    double *max_ov;
+    int *assign, *num_pos, *keep, *counts;
+    unsigned char *is_fg;
+};
+static size_t carve_pt(void *ws, int Rc, int n_images, int n_keep, int S, PtWs *out) {
+    Carver c(ws);
+    PtWs w;
+    w.cand = c.take<float>((size_t)Rc * 5);
+    w.max_ov = c.take<double>((size_t)Rc);
+    w.assign = c.take<int>((size_t)Rc);
+    w.num_pos = c.take<int>((size_t)n_images);
+    w.keep = c.take<int>((size_t)n_keep);
+    w.counts = c.take<int>((size_t)S * 2);
+    w.is_fg = c.take<unsigned char>((size_t)n_keep);
+    if (out) *out = w;
+    return c.off;
+}
+}  // namespace wssdl
+
+extern "C" size_t wssdl_proposal_target_device_workspace_bytes(int R, int n_images, int max_gt, int n_sample_images,
+                                                               int rois_per_image, int append_gt) {
+    if (R < 0 || n_images < 1 || max_gt < 1 || n_sample_images < 0 || rois_per_image < 1) return 0;
+    const int Rc = R + (append_gt ? n_sample_images * max_gt : 0);
+    return wssdl::carve_pt(nullptr, Rc, n_images, n_sample_images * rois_per_image, n_sample_images, nullptr) + 256;
+}
+
+extern "C" int wssdl_proposal_target_device(
+    const float *rois, int R, const float *gt_boxes, int max_gt, const int32_t *num_gt_boxes, int n_images,
+    const int32_t *images, int n_sample_images, int append_gt, int rois_per_image, int fg_rois_per_image,
+    double fg_thresh, double bg_thresh_hi, double bg_thresh_lo, uint64_t seed, int num_classes,
+    const float *inside_weights_host, float *rois_out, float *labels, float *bbox_targets, float *inside_w,
+    float *outside_w, void *workspace, size_t workspace_bytes, wssdl_stream_t stream) {
+    if (R < 0 || n_images < 1 || max_gt < 1 || n_sample_images < 0 || rois_per_image < 1 || num_classes < 1)
+        return WSSDL_ERR_INVALID_ARGUMENT;
+    if (n_sample_images == 0) return WSSDL_OK;
+    if (!workspace) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (workspace_bytes < wssdl_proposal_target_device_workspace_bytes(R, n_images, max_gt, n_sample_images,
+                                                                       rois_per_image, append_gt))
+        return WSSDL_ERR_WORKSPACE;
+    const int Rc = R + (append_gt ? n_sample_images * max_gt : 0);
+    const int n_keep = n_sample_images * rois_per_image;
+    wssdl::PtWs w;
+    wssdl::carve_pt(workspace, Rc, n_images, n_keep, n_sample_images, &w);
+    int rc = wssdl_roi_candidates(rois, R, gt_boxes, max_gt, num_gt_boxes, n_images, images, n_sample_images, append_gt,
+                                  w.cand, w.num_pos, stream);
+    if (rc) return rc;
+    if ((rc = wssdl_roi_gt_assign(w.cand, Rc, gt_boxes, max_gt, w.num_pos, n_images, w.max_ov, w.assign, stream))) return rc;
+    if ((rc = wssdl_roi_sample_device(w.cand, w.max_ov, Rc, images, n_sample_images, rois_per_image, fg_rois_per_image,
+                                      fg_thresh, bg_thresh_hi, bg_thresh_lo, seed, w.keep, w.is_fg, w.counts, stream)))
+        return rc;
+    return wssdl_roi_targets(w.cand, w.keep, w.is_fg, n_keep, w.assign, gt_boxes, max_gt, num_classes,
+                             inside_weights_host, rois_out, labels, bbox_targets, inside_w, outside_w, stream);
+}

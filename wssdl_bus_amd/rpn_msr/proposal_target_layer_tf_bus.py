@@ -78,46 +78,26 @@ def _supervised_device(rois, gt_dev, ng_dev, images, append_gt, num_classes):
         with torch.cuda.device(dev):
             images_dev = _images_tensor(images, dev)
             R = int(rois.shape[0])
-            # every gt slot of the supervised images is appended (:44-50); slots past the image's
-            # positives carry batch index -1 and can never be drawn
-            Rc = R + (S * max_gt if append_gt else 0)
-            cand = torch.empty((Rc, 5), dtype=torch.float32, device=dev)
-            num_pos_dev = torch.empty((n_img,), dtype=torch.int32, device=dev)
-            _lib.check(L.wssdl_roi_candidates(_lib.ptr(rois), R, _lib.ptr(gt_dev), max_gt,
-                                              _lib.ptr(ng_dev), n_img, _lib.ptr(images_dev), S,
-                                              int(bool(append_gt)), _lib.ptr(cand), _lib.ptr(num_pos_dev),
-                                              _lib.stream()), "wssdl_roi_candidates")
-            Rc = cand.shape[0]
-            max_ov = torch.empty((Rc,), dtype=torch.float64, device=dev)
-            assign = torch.empty((Rc,), dtype=torch.int32, device=dev)
-            _lib.check(L.wssdl_roi_gt_assign(_lib.ptr(cand), Rc, _lib.ptr(gt_dev), max_gt,
-                                             _lib.ptr(num_pos_dev), n_img, _lib.ptr(max_ov),
-                                             _lib.ptr(assign), _lib.stream()), "wssdl_roi_gt_assign")
-            keep = torch.empty((S, rpi), dtype=torch.int32, device=dev)
-            is_fg = torch.empty((S, rpi), dtype=torch.uint8, device=dev)
-            counts = torch.empty((S, 2), dtype=torch.int32, device=dev)
+            # one C call: candidates (every gt slot of the supervised images is appended, :44-50; slots
+            # past the image's positives carry batch index -1 and can never be drawn) -> assignment ->
+            # fg / bg draw -> rows and targets.  Fixed shape, no read-back: an image that runs short of
+            # candidates leaves rows (-1,0,0,0,0) with label -1 and zero weights, which RoI pooling, the
+            # losses and the MIL selection all ignore
             _device_calls[0] += 1
             seed = (int(cfg.DEVICE_RNG_SEED) * 0x9E3779B1 + 0x51ED27 * _device_calls[0]) & 0xFFFFFFFFFFFFFFFF
-            _lib.check(L.wssdl_roi_sample_device(
-                _lib.ptr(cand), _lib.ptr(max_ov), Rc, _lib.ptr(images_dev), S, rpi, fg_rpi,
-                float(cfg.TRAIN.FG_THRESH), float(cfg.TRAIN.BG_THRESH_HI),
-                float(cfg.TRAIN.BG_THRESH_LO), seed, _lib.ptr(keep), _lib.ptr(is_fg),
-                _lib.ptr(counts), _lib.stream()), "wssdl_roi_sample_device")
-            # fixed shape, no read-back: an image that runs short of candidates leaves -1 slots in
-            # `keep`; wssdl_roi_targets turns them into rows (-1,0,0,0,0) with label -1 and zero
-            # weights, which RoI pooling, the losses and the MIL selection all ignore
-            keep_flat, fg_flat = keep.reshape(-1), is_fg.reshape(-1)
             n_keep = S * rpi
+            nws = L.wssdl_proposal_target_device_workspace_bytes(R, n_img, max_gt, S, rpi, int(bool(append_gt)))
+            ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
             out_rois = torch.empty((n_keep, 5), dtype=torch.float32, device=dev)
             labels = torch.empty((n_keep, 1), dtype=torch.float32, device=dev)
-            tg = torch.empty((n_keep, 4 * num_classes), dtype=torch.float32, device=dev)
-            inw = torch.empty_like(tg)
-            outw = torch.empty_like(tg)
-            _lib.check(L.wssdl_roi_targets(
-                _lib.ptr(cand), _lib.ptr(keep_flat), _lib.ptr(fg_flat), n_keep, _lib.ptr(assign),
-                _lib.ptr(gt_dev), max_gt, int(num_classes), _lib.host_ptr(iw),
-                _lib.ptr(out_rois), _lib.ptr(labels), _lib.ptr(tg), _lib.ptr(inw), _lib.ptr(outw),
-                _lib.stream()), "wssdl_roi_targets")
+            tgs = torch.empty((3, n_keep, 4 * num_classes), dtype=torch.float32, device=dev)
+            tg, inw, outw = tgs[0], tgs[1], tgs[2]
+            _lib.check(L.wssdl_proposal_target_device(
+                _lib.ptr(rois), R, _lib.ptr(gt_dev), max_gt, _lib.ptr(ng_dev), n_img, _lib.ptr(images_dev), S,
+                int(bool(append_gt)), rpi, fg_rpi, float(cfg.TRAIN.FG_THRESH), float(cfg.TRAIN.BG_THRESH_HI),
+                float(cfg.TRAIN.BG_THRESH_LO), seed, int(num_classes), _lib.host_ptr(iw), _lib.ptr(out_rois),
+                _lib.ptr(labels), _lib.ptr(tg), _lib.ptr(inw), _lib.ptr(outw), _lib.ptr(ws), nws, _lib.stream()),
+                "wssdl_proposal_target_device")
         return [out_rois, labels, tg, inw, outw]
 
 
