@@ -35,7 +35,8 @@ def _rois_for(rs, R, N, H, W):
 
 
 @pytest.mark.parametrize("shape", [(2, 38, 63, 256), (3, 38, 63, 1024), (1, 63, 100, 1024), (1, 37, 62, 512),
-                                   (2, 38, 63, 96), (5, 20, 30, 64)])
+                                   (2, 38, 63, 96), (5, 20, 30, 64), (1, 20, 30, 2048), (2, 12, 17, 4096),
+                                   (1, 25, 40, 768)])
 @pytest.mark.parametrize("mode", ["cuda", "cpu"])
 def test_compact_pair_vs_oracle(torch_cuda, shape, mode):
     torch = torch_cuda
