@@ -150,7 +150,8 @@ WSSDL_API int wssdl_proposal_compact(const float *rois_padded, const int32_t *ro
  *   counts     [n_images, 4] i32: (#inside, #fg, #bg, 0)
  * Stage 2a wssdl_anchor_subsample_device: random sub-sampling on the device
  *   (counter-based hash of (seed, image, anchor); same distribution as
- *   npr.choice(replace=False), not the same stream).  In place on labels_pre.
+ *   npr.choice(replace=False), not the same stream).  In place on labels_pre.  Given stage 1's
+ *   counts the fg and the bg draw of an image run side by side (the bg quota only needs #fg).
  * Stage 2b (reference RNG) happens on the host: see
  *   wssdl_bus_amd/rpn_msr/anchor_target_layer_tf_bus.py.
  * Stage 3  wssdl_anchor_targets: final labels -> the four output blobs
@@ -166,6 +167,7 @@ WSSDL_API int wssdl_anchor_labels(const float *gt_boxes, int max_gt, const int32
                         void *workspace, size_t workspace_bytes, wssdl_stream_t stream);
 WSSDL_API int wssdl_anchor_subsample_device(int8_t *labels, int n_images, int total_anchors,
                                   int rpn_batchsize, double fg_fraction, uint64_t seed,
+                                  const int32_t *counts /* of stage 1, or NULL: fg then bg in sequence */,
                                   wssdl_stream_t stream);
 WSSDL_API int wssdl_anchor_targets(const int8_t *labels, const int32_t *argmax_gt, const float *gt_boxes,
                          int max_gt, int n_images, int n_out, int H, int W,

@@ -323,6 +323,19 @@ def test_anchor_target_device_sampling_invariants(torch_cuda):
                 assert np.allclose(w[w > 0], 1.0 / (n_fg + n_bg))
             if (pre == 0).sum() > 256:      # two calls draw different subsets
                 assert not torch.equal(outs[0][0], outs[1][0])
+            # the side-by-side form (fg and bg drawn by two workgroups, given the label stage's counts)
+            # draws exactly what the sequential form draws
+            from wssdl_bus_amd import _lib
+            pre_t = torch.from_numpy(np.stack([pre, pre[::-1].copy()])).cuda()          # two "images"
+            cnt = torch.tensor([[0, int((pre == 1).sum()), int((pre == 0).sum()), 0]] * 2, dtype=torch.int32,
+                               device="cuda")
+            for fg_frac, batch in ((0.5, 256), (0.0, 256), (0.5, 40), (1.0, 256)):
+                a, b = pre_t.clone(), pre_t.clone()
+                _lib.check(_lib.lib().wssdl_anchor_subsample_device(_lib.ptr(a), 2, a.shape[1], batch, fg_frac, 77,
+                                                                    _lib.ptr(cnt), _lib.stream()), "subsample")
+                _lib.check(_lib.lib().wssdl_anchor_subsample_device(_lib.ptr(b), 2, b.shape[1], batch, fg_frac, 77,
+                                                                    None, _lib.stream()), "subsample")
+                assert torch.equal(a, b), (name, fg_frac, batch)
     finally:
         cfg.SAMPLING_RNG = "reference"
 

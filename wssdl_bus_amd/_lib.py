@@ -39,7 +39,7 @@ SYMBOLS = {
     "wssdl_anchor_workspace_bytes": (_sz, [_i]),
     "wssdl_anchor_labels": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _d, _d, _i,
                                  _vp, _vp, _vp, _vp, _sz, _vp]),
-    "wssdl_anchor_subsample_device": (_i, [_vp, _i, _i, _i, _d, _u64, _vp]),
+    "wssdl_anchor_subsample_device": (_i, [_vp, _i, _i, _i, _d, _u64, _vp, _vp]),
     "wssdl_anchor_targets": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _d,
                                   _vp, _vp, _vp, _vp, _vp]),
     "wssdl_roi_gt_assign": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),

@@ -254,12 +254,26 @@ __device__ int subsample_one(signed char *lab, int total, int which, int quota,
     return quota;
 }
 
+// With the fg / bg counts of the label stage at hand (gridDim.y == 2) the two draws of an image run in
+// two workgroups side by side: the bg quota RPN_BATCHSIZE - #fg-after-sub-sampling (:212) only needs
+// the NUMBER of fg anchors, min(#fg, num_fg), not which ones survive; each workgroup only rewrites
+// anchors of its own class.  Same result as the sequential form (same keys, same cuts).
 __global__ __launch_bounds__(SS_BLOCK) void anchor_subsample_kernel(signed char *labels, int total,
                                                                     int batchsize, int num_fg,
-                                                                    unsigned long long seed) {
+                                                                    unsigned long long seed,
+                                                                    const int *__restrict__ counts) {
     __shared__ SelectScratch<SS_LIST> sc;
     const int img = blockIdx.x;
     signed char *lab = labels + (size_t)img * total;
+    if (gridDim.y == 2) {
+        if (blockIdx.y == 0) {
+            subsample_one(lab, total, 1, num_fg, seed, img, 0, sc);               // :202-207
+        } else {
+            const int fg_left = min(counts[img * 4 + 1], max(num_fg, 0));
+            subsample_one(lab, total, 0, batchsize - fg_left, seed, img, 1, sc);  // :212-217
+        }
+        return;
+    }
     const int fg_left = subsample_one(lab, total, 1, num_fg, seed, img, 0, sc);   // :202-207
     // num_bg = RPN_BATCHSIZE - #fg after the first sub-sampling, :212
     subsample_one(lab, total, 0, batchsize - fg_left, seed, img, 1, sc);          // :213-217
@@ -420,14 +434,14 @@ extern "C" int wssdl_anchor_labels(const float *gt_boxes, int max_gt, const int3
 
 extern "C" int wssdl_anchor_subsample_device(int8_t *labels, int n_images, int total_anchors,
                                              int rpn_batchsize, double fg_fraction, uint64_t seed,
-                                             wssdl_stream_t stream) {
+                                             const int32_t *counts, wssdl_stream_t stream) {
     if (n_images < 0 || total_anchors < 1 || rpn_batchsize < 0) return WSSDL_ERR_INVALID_ARGUMENT;
     if (n_images == 0) return WSSDL_OK;
     if (!labels) return WSSDL_ERR_INVALID_ARGUMENT;
     const int num_fg = (int)(fg_fraction * (double)rpn_batchsize);      // int(), :202
-    hipLaunchKernelGGL(anchor_subsample_kernel, dim3(n_images), dim3(SS_BLOCK), 0,
+    hipLaunchKernelGGL(anchor_subsample_kernel, dim3(n_images, counts ? 2 : 1), dim3(SS_BLOCK), 0,
                        as_stream(stream), reinterpret_cast<signed char *>(labels), total_anchors,
-                       rpn_batchsize, num_fg, (unsigned long long)seed);
+                       rpn_batchsize, num_fg, (unsigned long long)seed, counts);
     return check_launch();
 }
 

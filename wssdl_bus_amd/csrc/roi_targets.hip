@@ -237,28 +237,35 @@ __global__ __launch_bounds__(RS_BLOCK) void roi_sample_kernel(
     rs_block_exclusive_scan(cb, s_wave, have_bg);
     const int n_fg = min(fg_rois_per_image, have_fg);                 // :243
     const int n_bg = min(rois_per_image - n_fg, have_bg);             // :256-258
-    const unsigned long long t_fg = rs_select(cls, Rc, 1, have_fg, n_fg, seed, sc);
-    const unsigned long long t_bg = rs_select(cls, Rc, 0, have_bg, n_bg, seed ^ 0x5bd1e995ull, sc);
+    // the two draws only share these counts: with gridDim.y == 2 workgroup (s, 0) draws and emits
+    // the fg rows, workgroup (s, 1) the bg rows (and the padding) -- half the latency of the chain
+    const bool do_fg = gridDim.y == 1 || blockIdx.y == 0, do_bg = gridDim.y == 1 || blockIdx.y == 1;
+    unsigned long long t_fg = 0ull, t_bg = 0ull;
+    if (do_fg) t_fg = rs_select(cls, Rc, 1, have_fg, n_fg, seed, sc);
+    if (do_bg) t_bg = rs_select(cls, Rc, 0, have_bg, n_bg, seed ^ 0x5bd1e995ull, sc);
+    const bool emit_fg = do_fg && n_fg > 0, emit_bg = do_bg && n_bg > 0;
     cf = cb = 0;
-    if (n_fg > 0 || n_bg > 0)
+    if (emit_fg || emit_bg)
         for (int i = i0; i < i1; ++i) {
             const int c = cls(i);
-            if (c == 1) cf += (n_fg > 0 && rs_key(seed, cls.img, i) <= t_fg);
-            else if (c == 0) cb += (n_bg > 0 && rs_key(seed ^ 0x5bd1e995ull, cls.img, i) <= t_bg);
+            if (c == 1) cf += (emit_fg && rs_key(seed, cls.img, i) <= t_fg);
+            else if (c == 0) cb += (emit_bg && rs_key(seed ^ 0x5bd1e995ull, cls.img, i) <= t_bg);
         }
     int tot;
     int pf = rs_block_exclusive_scan(cf, s_wave, tot);
     int pb = n_fg + rs_block_exclusive_scan(cb, s_wave, tot);
     int *kp = keep + (size_t)s * rois_per_image;
     unsigned char *fp = is_fg + (size_t)s * rois_per_image;
-    if (n_fg > 0 || n_bg > 0)
+    if (emit_fg || emit_bg)
         for (int i = i0; i < i1; ++i) {
             const int c = cls(i);
-            if (c == 1 && n_fg > 0 && rs_key(seed, cls.img, i) <= t_fg) { kp[pf] = i; fp[pf] = 1; ++pf; }
-            else if (c == 0 && n_bg > 0 && rs_key(seed ^ 0x5bd1e995ull, cls.img, i) <= t_bg) { kp[pb] = i; fp[pb] = 0; ++pb; }
+            if (c == 1 && emit_fg && rs_key(seed, cls.img, i) <= t_fg) { kp[pf] = i; fp[pf] = 1; ++pf; }
+            else if (c == 0 && emit_bg && rs_key(seed ^ 0x5bd1e995ull, cls.img, i) <= t_bg) { kp[pb] = i; fp[pb] = 0; ++pb; }
         }
-    for (int p = n_fg + n_bg + t; p < rois_per_image; p += RS_BLOCK) { kp[p] = -1; fp[p] = 0; }
-    if (t == 0) { counts[2 * s] = n_fg; counts[2 * s + 1] = n_bg; }
+    if (do_bg) {
+        for (int p = n_fg + n_bg + t; p < rois_per_image; p += RS_BLOCK) { kp[p] = -1; fp[p] = 0; }
+        if (t == 0) { counts[2 * s] = n_fg; counts[2 * s + 1] = n_bg; }
+    }
 }
 
 }  // namespace wssdl
@@ -307,7 +314,7 @@ extern "C" int wssdl_roi_sample_device(const float *cand, const double *max_over
     if (n_sample_images == 0) return WSSDL_OK;
     if (!images || !keep || !is_fg || !counts || (Rc > 0 && (!cand || !max_overlap)))
         return WSSDL_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(roi_sample_kernel, dim3(n_sample_images), dim3(RS_BLOCK), 0, as_stream(stream),
+    hipLaunchKernelGGL(roi_sample_kernel, dim3(n_sample_images, 2), dim3(RS_BLOCK), 0, as_stream(stream),
                        cand, max_overlap, Rc, images, rois_per_image, fg_rois_per_image, fg_thresh,
                        bg_thresh_hi, bg_thresh_lo, (unsigned long long)seed, keep, is_fg, counts);
     return check_launch();

@@ -138,7 +138,7 @@ def _run_device(gt_boxes, num_gt_boxes, im_info, n_images, n_out, height, width,
             seed = (int(cfg.DEVICE_RNG_SEED) * 0x9E3779B1 + _device_calls[0]) & 0xFFFFFFFFFFFFFFFF
             _lib.check(_lib.lib().wssdl_anchor_subsample_device(
                 _lib.ptr(labels), n_images, labels.shape[1], int(cfg.TRAIN.RPN_BATCHSIZE),
-                float(cfg.TRAIN.RPN_FG_FRACTION), seed, _lib.stream()),
+                float(cfg.TRAIN.RPN_FG_FRACTION), seed, _lib.ptr(counts), _lib.stream()),
                 "wssdl_anchor_subsample_device")
     else:
         labels = argmax = gt = None
