@@ -15,16 +15,19 @@
 // map size; a window beyond that sets *overflow).  wssdl_roi_argmax_expand turns the codes
 // back into the reference's i32 indices (tests compare those with the oracle bit for bit).
 //
-// Forward : the XCD-sliced kernel of roi_pool.hip, writing 4 + 1 instead of 4 + 4 bytes per
-//           element (the kernel is bound by its store stream).
-// Backward: the tile-owner kernel of roi_pool.hip (4x4-cell x 256-channel tiles of bottom_diff in
-//           LDS, RoIs filtered per tile in RoI order, candidate bins walked in (ph, pw) order, one
-//           lane per channel => the reference's f32 summation order, bit-identical) reading 4 + 1
-//           bytes per visited element.  Bins that straddle tile borders are read by every tile
-//           they touch, so the saving applies to the re-reads too.  The (RoI, tile) record built
-//           by the filter phase additionally carries the window start of each candidate bin row /
-//           column relative to the tile, so decoding a code is two adds and two mask look-ups
-//           (no division by W or C as with the flat index).
+// Forward : roi_pool_fwd_rows_kernel -- one wave per (roi, ph) bin row x 256 channels, scalar window
+//           loops, the row walked through its 7 bins with the shared columns kept in registers, RoI
+//           geometry from the table of roi_windows_kernel; channel slice <-> XCD as in roi_pool.hip.
+//           (roi_pool_fwd_compact_kernel, the round-1 sliced form with the 1-byte store, serves the
+//           shapes the wave-uniform kernel does not take.)
+// Backward: roi_pool_walk.hip (lists built by the prepare step, one wave per (image, tile, 128
+//           channels)).  The kernel in THIS file is the fallback without a workspace: the tile-owner
+//           kernel of roi_pool.hip (4x4-cell x 256-channel tiles of bottom_diff in LDS, RoIs filtered
+//           per tile in RoI order, candidate bins walked in (ph, pw) order, one lane per channel =>
+//           the reference's f32 summation order, bit-identical) reading 4 + 1 bytes per visited
+//           element; its (RoI, tile) record carries the window start of each candidate bin row /
+//           column relative to the tile, so decoding a code is two adds and two mask look-ups (no
+//           division by W or C as with the flat index).
 #include "roi_pool.hip.h"
 
 #include <stdlib.h>
