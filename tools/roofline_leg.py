@@ -28,11 +28,15 @@ KERNEL_SOURCES = ("roi_pool.hip", "roi_pool.hip.h", "roi_pool_compact.hip", "roi
 
 
 def kernel_source_id():
-    """Identifies the kernels a traffic measurement belongs to (the GPU box has no .git)."""
+    """Identifies the kernels a traffic measurement belongs to (the GPU box has no .git): a hash of the
+    RoI-pool sources without their full-line comments and blank lines."""
     h = hashlib.sha1()
     for f in KERNEL_SOURCES:
         with open(os.path.join(ROOT, "wssdl_bus_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+            for line in fh:
+                t = line.strip()
+                if t and not t.startswith(b"//"):
+                    h.update(t + b"\n")
     return h.hexdigest()[:16]
 
 
