@@ -517,8 +517,8 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
 
 // A plan = tile shape, records in flight and the waves per SIMD the launch bounds ask for.
 // WSSDL_ROI_BWD_PLAN (tuning) overrides the default.
-constexpr int WALK_PLANS = 9;
-constexpr int WALK_DEFAULT_PLAN = 1;
+constexpr int WALK_PLANS = 18;
+constexpr int WALK_DEFAULT_PLAN = 11;
 
 static int walk_plan_from_env() {
     if (const char *e = getenv("WSSDL_ROI_BWD_PLAN")) {
@@ -529,7 +529,8 @@ static int walk_plan_from_env() {
 }
 
 static void plan_shape(int plan, int *th, int *tw) {
-    static const int shapes[WALK_PLANS][2] = {{4, 4}, {4, 8}, {8, 8}, {4, 8}, {8, 8}, {4, 4}, {8, 8}, {8, 8}, {8, 8}};
+    static const int shapes[WALK_PLANS][2] = {{4, 4}, {4, 8}, {8, 8}, {4, 8}, {8, 8}, {4, 4}, {8, 8}, {8, 8}, {8, 8},
+                                              {6, 8}, {5, 8}, {6, 6}, {6, 8}, {6, 6}, {6, 7}, {7, 6}, {5, 7}, {7, 7}};
     *th = shapes[plan][0];
     *tw = shapes[plan][1];
 }
@@ -578,9 +579,18 @@ int walk_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, i
     int th, tw;
     plan_shape(plan, &th, &tw);
     int rc;
-    if (th == 4 && tw == 4) rc = prepare_t<4, 4>(rois, R, N, H, W, C, PH, PW, scale, rounding, workspace, workspace_bytes, st);
-    else if (th == 4) rc = prepare_t<4, 8>(rois, R, N, H, W, C, PH, PW, scale, rounding, workspace, workspace_bytes, st);
-    else rc = prepare_t<8, 8>(rois, R, N, H, W, C, PH, PW, scale, rounding, workspace, workspace_bytes, st);
+#define WSSDL_PREP(TH, TW) prepare_t<TH, TW>(rois, R, N, H, W, C, PH, PW, scale, rounding, workspace, workspace_bytes, st)
+    if (th == 4 && tw == 4) rc = WSSDL_PREP(4, 4);
+    else if (th == 4) rc = WSSDL_PREP(4, 8);
+    else if (th == 6 && tw == 8) rc = WSSDL_PREP(6, 8);
+    else if (th == 5 && tw == 8) rc = WSSDL_PREP(5, 8);
+    else if (th == 6 && tw == 6) rc = WSSDL_PREP(6, 6);
+    else if (th == 6 && tw == 7) rc = WSSDL_PREP(6, 7);
+    else if (th == 7 && tw == 6) rc = WSSDL_PREP(7, 6);
+    else if (th == 5 && tw == 7) rc = WSSDL_PREP(5, 7);
+    else if (th == 7 && tw == 7) rc = WSSDL_PREP(7, 7);
+    else rc = WSSDL_PREP(8, 8);
+#undef WSSDL_PREP
     if (rc == WSSDL_OK && plan_out) *plan_out = plan;
     return rc;
 }
@@ -622,6 +632,15 @@ int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, 
         case 6: return WSSDL_WALK(8, 8, 4, 2, 1);       // one channel per lane: 8x8 tiles at 4x8's LDS
         case 7: return WSSDL_WALK(8, 8, 3, 2, 1);
         case 8: return WSSDL_WALK(8, 8, 2, 2, 1);
+        case 9: return WSSDL_WALK(6, 8, 2, 1, 2);       // fewer border re-reads (1.52 against 1.68), 6 waves per CU
+        case 10: return WSSDL_WALK(5, 8, 2, 1, 2);      // 1.58, 7 waves per CU
+        case 11: return WSSDL_WALK(6, 6, 2, 2, 2);      // 1.60, 8 waves per CU
+        case 12: return WSSDL_WALK(6, 8, 3, 1, 2);
+        case 13: return WSSDL_WALK(6, 6, 3, 2, 2);
+        case 14: return WSSDL_WALK(6, 7, 2, 1, 2);
+        case 15: return WSSDL_WALK(7, 6, 2, 1, 2);
+        case 16: return WSSDL_WALK(5, 7, 2, 2, 2);
+        case 17: return WSSDL_WALK(7, 7, 2, 1, 2);
         default: return WSSDL_ERR_INVALID_ARGUMENT;
     }
 #undef WSSDL_WALK
