@@ -26,8 +26,8 @@
 //               the data of the next DEPTH-1 records is in flight while a record is accumulated
 //               (straight-line code: 8 slots, no per-slot branches, out-of-range offsets for the
 //               padding slots of a tile's last record); a lane owns TWO channels (one 2-byte +
-//               one 8-byte load per slot and lane); accumulators live in LDS (8.5 KiB per wave for
-//               4x4-cell tiles), branch-free (misses add 0.0 to a spare cell).  A lane is the
+//               one 8-byte load per slot and lane); accumulators live in LDS (18.5 KiB per wave for
+//               the default 6x6-cell tiles), branch-free (misses add 0.0 to a spare cell).  A lane is the
 //               only writer of its channels: the f32 additions run in exactly the reference's order.
 // The lists are shared by all channel groups, the walk needs no barrier at all, and no workgroup
 // repeats the RoI filter.
