@@ -129,6 +129,33 @@ def test_compact_other_pooled_sizes_and_unsupported_shapes(torch_cuda):
     assert tuple(g.shape) == shape and not bool(g.any())
 
 
+def test_window_table_path_on_a_train_sized_list(torch_cuda):
+    """R >= 1024: the Python layer builds the window table (wssdl_roi_pool_forward_windows) and the
+    pooling kernel reads the RoI geometry from it; smaller lists (the tests above) compute it in the
+    kernel or take the sliced kernel.  Same tensors as the oracle, both roundings."""
+    torch = torch_cuda
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    assert op._WINDOW_TABLE_MIN_ROIS <= 1500
+    rs = np.random.RandomState(17)
+    for shape, mode in (((2, 38, 63, 256), "cuda"), ((3, 37, 62, 512), "cpu")):
+        N, H, W, C = shape
+        f = np.maximum(rs.normal(size=shape), 0).astype(np.float32)
+        rois = _rois_for(rs, 1500, N, H, W)
+        et, ea = c_oracle.roi_pool_forward(f, rois, 7, 7, 1.0 / 16, mode, threads=16)
+        ft, rt = torch.from_numpy(f).cuda(), torch.from_numpy(rois).cuda()
+        assert _lib_windows_bytes(1500, H, W, C) == 1500 * 7 * 32
+        top, arg8 = op.roi_pool_compact(ft, rt, 7, 7, 1.0 / 16, rounding=mode)
+        assert np.array_equal(top.cpu().numpy(), et)
+        arg = op.expand_argmax(arg8, rt, shape, 7, 7, 1.0 / 16, rounding=mode)
+        assert np.array_equal(arg.cpu().numpy(), ea)
+        assert not op.compact_overflowed()
+
+
+def _lib_windows_bytes(R, H, W, C):
+    from wssdl_bus_amd import _lib
+    return _lib.lib().wssdl_roi_pool_forward_windows_bytes(R, H, W, C, 7, 7)
+
+
 def test_compact_overflow_flag_for_rois_far_outside_the_map(torch_cuda):
     torch = torch_cuda
     from wssdl_bus_amd import _lib

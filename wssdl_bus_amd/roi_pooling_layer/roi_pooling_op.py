@@ -110,6 +110,9 @@ def compact_overflowed(device=None):
     return bool(f is not None and int(f.item()) != 0)
 
 
+_WINDOW_TABLE_MIN_ROIS = 1024
+
+
 def roi_pool_compact(data, rois, pooled_height, pooled_width, spatial_scale, rounding=None):
     """GPU tensors in, ``(top_data f32, argmax8 u8)`` out."""
     _check_inputs(data, rois)
@@ -120,8 +123,9 @@ def roi_pool_compact(data, rois, pooled_height, pooled_width, spatial_scale, rou
     arg8 = torch.empty((R, pooled_height, pooled_width, C), dtype=torch.uint8, device=data.device)
     L = _lib.lib()
     with torch.cuda.device(data.device):
+        # (a launch of its own only pays off on a train-sized RoI list)
         nwin = L.wssdl_roi_pool_forward_windows_bytes(R, H, W, C, int(pooled_height), int(pooled_width)) \
-            if os.environ.get("WSSDL_ROI_FWD_VARIANT", "0") == "0" else 0
+            if (R >= _WINDOW_TABLE_MIN_ROIS and os.environ.get("WSSDL_ROI_FWD_VARIANT", "0") == "0") else 0
         if nwin:
             # the RoI geometry once per (roi, bin row) into a table, then the pooling kernel reads it with
             # scalar loads (two launches, timed apart: the second is the kernel the roofline is quoted on)
