@@ -72,7 +72,7 @@ def test_compact_pair_vs_oracle(torch_cuda, shape, mode):
     old = {k: os.environ.get(k) for k in ("WSSDL_ROI_BWDC_VARIANT", "WSSDL_ROI_BWD_PLAN")}
     try:
         # every plan of the list-driven walk (tile shape x records in flight) ...
-        for plan_id in range(18):
+        for plan_id in range(21):
             os.environ["WSSDL_ROI_BWD_PLAN"] = str(plan_id)
             plan = op.roi_pool_grad_prepare(shape, rt, 7, 7, 1.0 / 16, rounding=mode)
             assert plan.plan == plan_id

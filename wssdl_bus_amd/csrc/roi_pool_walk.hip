@@ -516,21 +516,35 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
 }
 
 // A plan = tile shape, records in flight and the waves per SIMD the launch bounds ask for.
-// WSSDL_ROI_BWD_PLAN (tuning) overrides the default.
-constexpr int WALK_PLANS = 18;
-constexpr int WALK_DEFAULT_PLAN = 11;
+// WSSDL_ROI_BWD_PLAN (tuning) overrides the choice below.
+constexpr int WALK_PLANS = 21;
 
-static int walk_plan_from_env() {
+// The tile shape trades border re-reads (large tiles: fewer bytes) against the length of the slot
+// chain one wave walks alone (small tiles: more, shorter chains).  A train-sized launch is
+// bandwidth-bound and wants 6x6; a launch with few waves (few images or channel groups) is bound by
+// its longest chain: 2 images x 256 channels x 4000 RoIs take 0.44 ms with 6x6 tiles, 0.24 with 4x4,
+// 0.12 with 2x2 (tools/bwd_plan_sweep.py).  Rule: the largest of 6x6, 4x4, 2x4, 2x2 that still gives
+// 2048 waves (one per wave slot of the chip at 8 per CU).
+static int walk_plan_auto(int N, int H, int W, int C) {
+    static const int cand[4][3] = {{6, 6, 11}, {4, 4, 5}, {2, 4, 18}, {2, 2, 19}};
+    const long long G = cdiv(C, 128);
+    for (int i = 0; i < 4; ++i)
+        if ((long long)N * cdiv(H, cand[i][0]) * cdiv(W, cand[i][1]) * G >= 2048) return cand[i][2];
+    return cand[3][2];
+}
+
+static int walk_plan_from_env(int N, int H, int W, int C) {
     if (const char *e = getenv("WSSDL_ROI_BWD_PLAN")) {
         const int v = atoi(e);
         if (v >= 0 && v < WALK_PLANS) return v;
     }
-    return WALK_DEFAULT_PLAN;
+    return walk_plan_auto(N, H, W, C);
 }
 
 static void plan_shape(int plan, int *th, int *tw) {
     static const int shapes[WALK_PLANS][2] = {{4, 4}, {4, 8}, {8, 8}, {4, 8}, {8, 8}, {4, 4}, {8, 8}, {8, 8}, {8, 8},
-                                              {6, 8}, {5, 8}, {6, 6}, {6, 8}, {6, 6}, {6, 7}, {7, 6}, {5, 7}, {7, 7}};
+                                              {6, 8}, {5, 8}, {6, 6}, {6, 8}, {6, 6}, {6, 7}, {7, 6}, {5, 7}, {7, 7},
+                                              {2, 4}, {2, 2}, {3, 4}};
     *th = shapes[plan][0];
     *tw = shapes[plan][1];
 }
@@ -543,7 +557,7 @@ bool walk_supported(int R, int N, int H, int W, int C, int PH, int PW) {
 
 size_t walk_workspace_bytes(int R, int N, int H, int W, int PH, int PW) {
     // sized for the smallest tiles (most records), so that every plan fits
-    return carve_walk(nullptr, R, N, cdiv(H, 4), cdiv(W, 4), walk_record_bound(R, N, H, W, PH, PW, 4, 4), nullptr);
+    return carve_walk(nullptr, R, N, cdiv(H, 2), cdiv(W, 2), walk_record_bound(R, N, H, W, PH, PW, 2, 2), nullptr);
 }
 
 template <int TH, int TW>
@@ -575,7 +589,7 @@ static int prepare_t(const float *rois, int R, int N, int H, int W, int C, int P
 
 int walk_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, int PW, float scale, int rounding,
                  void *workspace, size_t workspace_bytes, int *plan_out, hipStream_t st) {
-    const int plan = walk_plan_from_env();
+    const int plan = walk_plan_from_env(N, H, W, C);
     int th, tw;
     plan_shape(plan, &th, &tw);
     int rc;
@@ -589,6 +603,9 @@ int walk_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, i
     else if (th == 7 && tw == 6) rc = WSSDL_PREP(7, 6);
     else if (th == 5 && tw == 7) rc = WSSDL_PREP(5, 7);
     else if (th == 7 && tw == 7) rc = WSSDL_PREP(7, 7);
+    else if (th == 2 && tw == 4) rc = WSSDL_PREP(2, 4);
+    else if (th == 2 && tw == 2) rc = WSSDL_PREP(2, 2);
+    else if (th == 3 && tw == 4) rc = WSSDL_PREP(3, 4);
     else rc = WSSDL_PREP(8, 8);
 #undef WSSDL_PREP
     if (rc == WSSDL_OK && plan_out) *plan_out = plan;
@@ -641,6 +658,9 @@ int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, 
         case 15: return WSSDL_WALK(7, 6, 2, 1, 2);
         case 16: return WSSDL_WALK(5, 7, 2, 2, 2);
         case 17: return WSSDL_WALK(7, 7, 2, 1, 2);
+        case 18: return WSSDL_WALK(2, 4, 3, 4, 2);      // small launches: short slot chains per wave
+        case 19: return WSSDL_WALK(2, 2, 3, 4, 2);
+        case 20: return WSSDL_WALK(3, 4, 3, 4, 2);
         default: return WSSDL_ERR_INVALID_ARGUMENT;
     }
 #undef WSSDL_WALK
