@@ -108,8 +108,11 @@ def main():
         ref_g = roi_pool_grad(feat, rois, arg, diff, 7, 7, 1.0 / 16)
         from wssdl_bus_amd.roi_pooling_layer.roi_pooling_op import roi_pool_grad_prepare
         shape = tuple(feat.shape)
-        for plan_id in os.environ.get("KB_BWD_PLANS", "1").split(","):
-            os.environ["WSSDL_ROI_BWD_PLAN"] = plan_id
+        for plan_id in os.environ.get("KB_BWD_PLANS", "auto").split(","):
+            if plan_id == "auto":                       # the plan the library picks for this launch size
+                os.environ.pop("WSSDL_ROI_BWD_PLAN", None)
+            else:
+                os.environ["WSSDL_ROI_BWD_PLAN"] = plan_id
             plan = roi_pool_grad_prepare(shape, rois, 7, 7, 1.0 / 16)
             g = roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan)
             assert os.environ.get("KB_NO_CHECK") or torch.equal(g, ref_g), plan_id

@@ -536,7 +536,7 @@ static int walk_plan_auto(int N, int H, int W, int C) {
 static int walk_plan_from_env(int N, int H, int W, int C) {
     if (const char *e = getenv("WSSDL_ROI_BWD_PLAN")) {
         const int v = atoi(e);
-        if (v >= 0 && v < WALK_PLANS) return v;
+        if (e[0] >= '0' && e[0] <= '9' && v >= 0 && v < WALK_PLANS) return v;
     }
     return walk_plan_auto(N, H, W, C);
 }
