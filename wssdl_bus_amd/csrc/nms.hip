@@ -857,6 +857,11 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(
                 for (int j = 0; j <= SWEEP_AHEAD; ++j) sh.rowbuf[(c + 1) & 1][j][lane] = rows[j];
                 load_rows(c + 3);
             } else {
+#if defined(WSSDL_SWEEP_ABLATE) && WSSDL_SWEEP_ABLATE == 1
+                // tuning builds only: helpers idle (wrong results; shows the resolver + barrier floor)
+                if (false)
+#endif
+                {
                 // consume word c+1 (issued at iteration c-2; slots beyond the list were zeroed)
                 unsigned long long acc = 0ull;
 #pragma unroll
@@ -880,6 +885,7 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(
                 for (int j = 0; j < SWEEP_LH; ++j) {
                     pend[j] = 0ull;
                     if (off[j] != 0xffffffffu) pend[j] = m[off[j]];
+                }
                 }
             }
         }
