@@ -125,7 +125,7 @@ __global__ __launch_bounds__(MTL_BLOCK) void mtl_forward_kernel(MtlArgs x, doubl
         double ce = 0.0, cnt = 0.0, box = 0.0;
         for (int r = t; r < x.n_rows; r += MTL_BLOCK) {
             const int l = x.labels[r];
-            if (l >= 0) {
+            if (l >= 0 && l < x.K) {       // (a label outside [0, K) is ignored like padding, not read through)
                 const float *sc = x.cls_score + (size_t)r * x.K;
                 float m = sc[0];
                 for (int k = 1; k < x.K; ++k) m = fmaxf(m, sc[k]);
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(MTL_BLOCK) void mtl_backward_kernel(MtlArgs x, cons
             float *gc = g_cls + (size_t)r * x.K;
             float *gb = g_box + (size_t)r * 4 * x.K;
             const int l = (r < x.n_rows) ? x.labels[r] : -1;
-            if (l >= 0) {
+            if (l >= 0 && l < x.K) {
                 const float *sc = x.cls_score + (size_t)r * x.K;
                 float m = sc[0];
                 for (int k = 1; k < x.K; ++k) m = fmaxf(m, sc[k]);
