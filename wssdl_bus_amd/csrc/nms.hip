@@ -982,9 +982,14 @@ int launch_nms_two_pass(const float *boxes, int box_stride_img, const int *n_dev
 
 // ------------------------------------------------------- standalone nms entry ---
 __global__ void nms_prepare_kernel(const float *__restrict__ dets, int n,
-                                   unsigned long long *__restrict__ keys) {
+                                   unsigned long long *__restrict__ keys, int *__restrict__ order,
+                                   int *__restrict__ n_sorted, int *__restrict__ cand_fill) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keys[i] = score_key(dets[(size_t)i * 5 + 4], (unsigned)i);
+    if (i < n) {
+        keys[i] = score_key(dets[(size_t)i * 5 + 4], (unsigned)i);
+        order[i] = -1;                       // (initialisations that used to be three memset launches)
+    }
+    if (i == 0) { n_sorted[0] = 0;  cand_fill[0] = 0; }
 }
 
 __global__ void nms_gather_kernel(const float *__restrict__ dets, const int *__restrict__ order,
@@ -1043,11 +1048,8 @@ extern "C" int wssdl_nms(const float *dets, int n, double thresh, int max_keep, 
     if (workspace_bytes < wssdl_nms_workspace_bytes(n)) return WSSDL_ERR_WORKSPACE;
     NmsWs w;
     carve_nms(workspace, n, &w);
-    if (hipMemsetAsync(w.order, 0xff, sizeof(int) * (size_t)n, st) != hipSuccess ||
-        hipMemsetAsync(w.n_sorted, 0, sizeof(int), st) != hipSuccess ||
-        hipMemsetAsync(w.cand_fill, 0, sizeof(int), st) != hipSuccess)
-        return WSSDL_ERR_LAUNCH;
-    hipLaunchKernelGGL(nms_prepare_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dets, n, w.keys);
+    hipLaunchKernelGGL(nms_prepare_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dets, n, w.keys, w.order,
+                       w.n_sorted, w.cand_fill);
     int rc = check_launch();
     if (rc) return rc;
     rc = launch_rank_topk(w.keys, n, 1, n, w.cand, w.thresh, w.cand_fill, w.order, w.n_sorted, w.mask,

@@ -25,9 +25,20 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(
     const float *__restrict__ prob, const float *__restrict__ pred,
     const float *__restrict__ im_info, int info_stride, int N, int H, int W, BaseAnchors base,
     int A, int stride, float min_size, int from_logits, float *__restrict__ boxes,
-    unsigned long long *__restrict__ keys) {
+    unsigned long long *__restrict__ keys, int *__restrict__ sorted_index, long long n_sorted_index,
+    int *__restrict__ n_sorted, int *__restrict__ cand_fill, float *__restrict__ rois_padded,
+    long long n_rois_floats) {
     const int M = H * W * A;
     const long long total = (long long)N * M;
+    {
+        // the layer's buffers that later kernels count on being initialised (four memset launches folded
+        // into this first kernel): sorted_index = -1, the per-image counters = 0, rois_padded = 0
+        const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const long long nthreads = (long long)gridDim.x * blockDim.x;
+        for (long long i = tid; i < n_sorted_index; i += nthreads) sorted_index[i] = -1;
+        for (long long i = tid; i < n_rois_floats; i += nthreads) rois_padded[i] = 0.0f;
+        if (tid < N) { n_sorted[tid] = 0;  cand_fill[tid] = 0; }
+    }
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
          g += (long long)gridDim.x * blockDim.x) {
         const int n = (int)(g / M);
@@ -177,18 +188,13 @@ static int proposal_layer_impl(int from_logits, const float *rpn_cls_prob, const
     int *sidx = w.sorted_index;
     int *nsorted = w.n_sorted;
 
-    if (hipMemsetAsync(sidx, 0xff, sizeof(int) * (size_t)N * topn, st) != hipSuccess ||
-        hipMemsetAsync(nsorted, 0, sizeof(int) * (size_t)N, st) != hipSuccess ||
-        hipMemsetAsync(w.cand_fill, 0, sizeof(int) * (size_t)N, st) != hipSuccess ||
-        hipMemsetAsync(rois_padded, 0, sizeof(float) * (size_t)N * pitch * 5, st) != hipSuccess)
-        return WSSDL_ERR_LAUNCH;
-
     long long total = (long long)N * M;
     int blocks = cdiv(total, 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(proposal_decode_kernel, dim3(blocks), dim3(256), 0, st, rpn_cls_prob,
                        rpn_bbox_pred, im_info, im_info_stride, N, H, W, base, A, feat_stride,
-                       min_size, from_logits, boxes, w.keys);
+                       min_size, from_logits, boxes, w.keys, sidx, (long long)N * topn, nsorted, w.cand_fill,
+                       rois_padded, (long long)N * pitch * 5);
     if ((rc = check_launch())) return rc;
     if ((rc = launch_rank_topk(w.keys, M, N, topn, w.cand, w.thresh, w.cand_fill, sidx, nsorted, w.mask,
                                sizeof(unsigned long long) * (size_t)N * topn * cdiv(topn, 64), st)))
