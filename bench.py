@@ -39,6 +39,34 @@ if ROOT not in sys.path:
 # the default BLAS path (measured 192 -> 176 ms per step).  Must be set before torch is imported.
 os.environ.setdefault("TORCH_BLAS_PREFER_HIPBLASLT", "1")
 
+
+def seed_miopen_db():
+    """plumbing: the backbone's convolutions run on MIOpen.  Without a search MIOpen's immediate mode picks
+    its solvers by heuristic (163 ms per step); with `torch.backends.cudnn.benchmark` it times the candidates
+    of every convolution once (a 'find': 138-148 ms per step, but ~2.5 minutes of search and kernel builds
+    on a fresh machine).  wssdl_bus_amd/miopen_db/ holds the RESULT of that search for the bench workloads
+    on MI355X -- MIOpen's own user find-db (text: problem -> solvers and their times) and the code objects of
+    the chosen kernels -- so that the search is a look-up.  They are copied to a scratch directory (MIOpen
+    writes to its user db) unless the caller already points MIOpen somewhere.  A db that does not match the
+    installed MIOpen build is ignored by MIOpen, which then searches as on a fresh machine."""
+    if os.environ.get("MIOPEN_USER_DB_PATH") or os.environ.get("MIOPEN_CUSTOM_CACHE_DIR"):
+        return None
+    src = os.path.join(ROOT, "wssdl_bus_amd", "miopen_db")
+    if not os.path.isdir(os.path.join(src, "config")):
+        return None
+    import shutil
+    import tempfile
+    dst = os.path.join(tempfile.gettempdir(), "wssdl_miopen_db_%d_rank%s" % (os.getuid(), os.environ.get("RANK", "0")))
+    try:
+        for sub in ("config", "cache"):
+            if os.path.isdir(os.path.join(src, sub)):
+                shutil.copytree(os.path.join(src, sub), os.path.join(dst, sub), dirs_exist_ok=True)
+    except OSError:
+        return None
+    os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(dst, "config")
+    os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.join(dst, "cache")
+    return dst
+
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured achievable
 
 WORKLOADS = {
@@ -233,8 +261,10 @@ def main():
     ap.add_argument("--sampling-rng", default="device", choices=["device", "reference"],
                     help="anchor sub-sampling RNG: 'device' (no host round trip) or the reference's numpy stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--miopen-benchmark", action="store_true",
-                    help="torch.backends.cudnn.benchmark for the (static-shape) trunk convolutions")
+    ap.add_argument("--no-miopen-benchmark", action="store_true",
+                    help="do not let MIOpen time its candidate solvers for the (static-shape) trunk convolutions "
+                         "(torch.backends.cudnn.benchmark off: heuristic solver choice)")
+    ap.add_argument("--miopen-benchmark", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-fused-rpn-softmax", action="store_true",
                     help="materialise rpn_cls_prob with separate reshape / softmax / reshape ops instead of "
                          "fusing them into the proposal decode kernel (f2, the default)")
@@ -247,6 +277,7 @@ def main():
                          "the backbone and the loss; the per-RoI head then runs on the padded row count")
     args = ap.parse_args()
 
+    miopen_db = None if args.no_miopen_benchmark else seed_miopen_db()      # before MIOpen initialises
     import numpy as np
     import torch
     from wssdl_bus_amd import _lib, synthetic
@@ -257,7 +288,7 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
-    torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
+    torch.backends.cudnn.benchmark = not args.no_miopen_benchmark
     _lib.lib()
     ctx = DistContext()
     if ctx.world_size != args.gpus:
@@ -400,6 +431,7 @@ def main():
                        "parallelism": "image-parallel dp%d, %s grad all-reduce" % (
                            ctx.world_size, "RCCL" if (ctx.backend or "nccl") == "nccl" else ctx.backend),
                        "sampling_rng": args.sampling_rng, "fused_rpn_softmax": bool(cfg.FUSED_RPN_SOFTMAX), "padded_rois": bool(cfg.PADDED_ROIS),
+                       "miopen_find": (not args.no_miopen_benchmark), "miopen_find_db": "wssdl_bus_amd/miopen_db" if miopen_db else None,
                        "roi_pool_argmax_bytes": leg_meta["argmax_bytes"]},
             "roofline": roofline,
             "hot_path": {"gpu_ms_per_step": round(hot_ms, 3),
