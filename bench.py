@@ -47,25 +47,62 @@ def seed_miopen_db():
     on a fresh machine).  wssdl_bus_amd/miopen_db/ holds the RESULT of that search for the bench workloads
     on MI355X -- MIOpen's own user find-db (text: problem -> solvers and their times) and the code objects of
     the chosen kernels -- so that the search is a look-up.  They are copied to a scratch directory (MIOpen
-    writes to its user db) unless the caller already points MIOpen somewhere.  A db that does not match the
-    installed MIOpen build is ignored by MIOpen, which then searches as on a fresh machine."""
+    writes to its user db) unless the caller already points MIOpen somewhere.
+    FAILS CLOSED: the db is named after the MIOpen build that wrote it (gfx950100.HIP.<version>-<hash>); when
+    the MIOpen library this process will load does not carry that very tag, MIOpen would ignore the db and
+    search for ~2.5 minutes on every rank -- so the function returns (None, reason) and main() turns the
+    find mode off (heuristic solver choice).  The scratch copy is a fresh private directory (mkdtemp, 0700),
+    removed at exit.  Returns (scratch dir or None, reason)."""
     if os.environ.get("MIOPEN_USER_DB_PATH") or os.environ.get("MIOPEN_CUSTOM_CACHE_DIR"):
-        return None
+        return None, "caller set MIOPEN_USER_DB_PATH / MIOPEN_CUSTOM_CACHE_DIR"
     src = os.path.join(ROOT, "wssdl_bus_amd", "miopen_db")
-    if not os.path.isdir(os.path.join(src, "config")):
-        return None
+    tags = [f[len("gfx950100."):-len(".ufdb.txt")] for f in (os.listdir(os.path.join(src, "config"))
+            if os.path.isdir(os.path.join(src, "config")) else []) if f.startswith("gfx950100.") and f.endswith(".ufdb.txt")]
+    if not tags:
+        return None, "no find-db shipped"
+    import importlib.util
+    import mmap
+    spec = importlib.util.find_spec("torch")
+    lib = os.path.join(os.path.dirname(spec.origin), "lib", "libMIOpen.so") if spec and spec.origin else ""
+    try:
+        with open(lib, "rb") as fh:
+            mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+            hit = mm.find(tags[0].encode()) >= 0
+            mm.close()
+    except (OSError, ValueError):
+        hit = False
+    if not hit:
+        return None, "shipped find-db is for MIOpen build %s, which %s does not identify as" % (tags[0], lib or "torch's MIOpen")
+    import atexit
     import shutil
     import tempfile
-    dst = os.path.join(tempfile.gettempdir(), "wssdl_miopen_db_%d_rank%s" % (os.getuid(), os.environ.get("RANK", "0")))
+    dst = tempfile.mkdtemp(prefix="wssdl_miopen_db_")           # private (0700), unpredictable name
+    atexit.register(shutil.rmtree, dst, True)
     try:
         for sub in ("config", "cache"):
             if os.path.isdir(os.path.join(src, sub)):
-                shutil.copytree(os.path.join(src, sub), os.path.join(dst, sub), dirs_exist_ok=True)
-    except OSError:
-        return None
+                shutil.copytree(os.path.join(src, sub), os.path.join(dst, sub))
+    except OSError as e:
+        return None, "could not copy the find-db: %s" % e
     os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(dst, "config")
     os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.join(dst, "cache")
-    return dst
+    return dst, "wssdl_bus_amd/miopen_db (%s)" % tags[0]
+
+
+def miopen_db_grew(scratch):
+    """True when MIOpen added find results to the scratch copy, i.e. it had to search (db miss)."""
+    if not scratch:
+        return None
+    src = os.path.join(ROOT, "wssdl_bus_amd", "miopen_db", "config")
+    try:
+        for f in os.listdir(os.path.join(scratch, "config")):
+            a = os.path.join(scratch, "config", f)
+            b = os.path.join(src, f)
+            if not os.path.exists(b) or os.path.getsize(a) != os.path.getsize(b):
+                return True
+    except OSError:
+        return None
+    return False
 
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured achievable
 
@@ -264,7 +301,8 @@ def main():
     ap.add_argument("--no-miopen-benchmark", action="store_true",
                     help="do not let MIOpen time its candidate solvers for the (static-shape) trunk convolutions "
                          "(torch.backends.cudnn.benchmark off: heuristic solver choice)")
-    ap.add_argument("--miopen-benchmark", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--miopen-benchmark", action="store_true",
+                    help="find mode even without a matching shipped find-db (searches: minutes on a fresh machine)")
     ap.add_argument("--no-fused-rpn-softmax", action="store_true",
                     help="materialise rpn_cls_prob with separate reshape / softmax / reshape ops instead of "
                          "fusing them into the proposal decode kernel (f2, the default)")
@@ -277,7 +315,10 @@ def main():
                          "the backbone and the loss; the per-RoI head then runs on the padded row count")
     args = ap.parse_args()
 
-    miopen_db = None if args.no_miopen_benchmark else seed_miopen_db()      # before MIOpen initialises
+    # before MIOpen initialises.  No usable find-db -> no find mode (a search costs minutes per rank)
+    miopen_db, miopen_db_note = (None, "--no-miopen-benchmark") if args.no_miopen_benchmark else seed_miopen_db()
+    if miopen_db is None and not args.miopen_benchmark and not os.environ.get("MIOPEN_USER_DB_PATH"):
+        args.no_miopen_benchmark = True
     import numpy as np
     import torch
     from wssdl_bus_amd import _lib, synthetic
@@ -303,7 +344,7 @@ def main():
     cfg.FUSED_LOSS = not args.no_fused_loss
     cfg.PADDED_ROIS = bool(args.padded_rois)
     seed = ctx.seed(cfg.RNG_SEED)
-    cfg.DEVICE_RNG_SEED = seed              # the device samplers draw a different stream on every rank
+    cfg.DEVICE_RNG_SEED = int(cfg.RNG_SEED)  # base; SolverWrapper adds the rank when data-parallel
     np.random.seed(seed)
     torch.manual_seed(seed)
 
@@ -335,10 +376,12 @@ def main():
             losses["loss"].backward()
             solver._apply()
             return losses
-        with torch.no_grad():                    # test: im_detect-style forward (test_bus.py:146-205)
-            net.eval()
-            return net(blobs["data"], blobs["im_info"], blobs["gt_boxes"], blobs["num_gt_boxes"],
-                       is_training=False, is_ws=False, test_net=True)
+        # test: im_detect (test_bus.py:146-240) + the post-detection step of test_net (:360-401): per-class
+        # score threshold, NMS at cfg.TEST.NMS on the HIP kernel, max_per_image cap (f3)
+        from wssdl_bus_amd.fast_rcnn.test_bus import im_detect, postprocess_detections
+        scores, boxes = im_detect(net, blobs["data"], blobs["im_info"])
+        with _lib.timed("postprocess_detections", dict(R=int(scores.shape[0]), classes=int(scores.shape[1]))):
+            return postprocess_detections(scores, boxes, scores.shape[1], thresh=0.05, max_per_image=300)
 
     net.train()
     for _ in range(args.warmup):
@@ -399,16 +442,36 @@ def main():
         d = leg[dom]
         kernel_key = {"roi_pool_forward": "roi_pool_fwd", "roi_pool_backward": "roi_pool_bwd"}[dom]
         traffic, traffic_src = hbm_traffic(kernel_key, leg_meta)
+        # Three byte counts per launch of the dominant kernel, one duration:
+        #   moved   what THIS implementation has to move at least (1-byte arg-max: 5 B per pooled element):
+        #           the figure `achieved` / `frac` are quoted on;
+        #   8d      SURVEY.md 8(d)'s figure for the reference's layout (f32 top + i32 arg-max, 8 B per
+        #           element): what a launch in the reference's layout would have moved -- `frac_8d`;
+        #   traffic HBM-side bytes from the committed PMC passes of the same launch -- `frac_traffic`.
+        secs = d["avg_ms"] * 1e-3
+        moved = int(d.get("min_moved_bytes", d["alg_bytes_per_launch"]))
+        helpers = {"roi_pool_forward": ("roi_pool_forward_windows",),
+                   "roi_pool_backward": ("roi_pool_backward_prepare",)}[dom]
+        helper_ms = sum(leg[h]["avg_ms"] for h in helpers if h in leg)
         roofline = dict(
-            bound="hbm", kernel=dom, achieved=round(d["GBps"], 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-            frac=round(d["GBps"] / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_src,
+            bound="hbm", kernel=dom, achieved=round(moved / secs / 1e9, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+            frac=round(moved / secs / 1e9 / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_src,
+            frac_moved=round(moved / secs / 1e9 / HBM_PEAK_GBPS, 4),
+            frac_traffic=(round(traffic / secs / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None),
+            frac_8d=round(d["GBps"] / HBM_PEAK_GBPS, 4), achieved_8d=round(d["GBps"], 1),
+            traffic_over_moved=(round(traffic / moved, 3) if traffic else None),
+            moved_bytes_per_launch=moved, alg_bytes_8d_per_launch=int(d["alg_bytes_per_launch"]),
             R=int(rois_fixed.shape[0]), roi_set=roi_tag, launch=leg_meta,
-            avg_launch_ms=round(d["avg_ms"], 4), alg_bytes_per_launch=int(d["alg_bytes_per_launch"]),
+            avg_launch_ms=round(d["avg_ms"], 4), helper_launches_ms=round(helper_ms, 4),
+            frac_moved_with_helpers=round(moved / ((d["avg_ms"] + helper_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             launches=d["calls"], measured_d2d_copy=round(measured_copy_gbps(), 1),
-            note="achieved = algorithmic bytes of SURVEY.md 8(d) (f32 top + i32 argmax layout of the reference) / "
-                 "launch time; the training path moves a 1-byte arg-max instead (min_moved_bytes in fixed_set). "
-                 "RoI-pool parity is pinned by hand-computed cases and two independent oracle restatements, not "
-                 "by reference outputs (TensorFlow op cannot be built here: 'parity unpinned', DESIGN.md section 2)",
+            note="achieved / frac = bytes this implementation must move (f32 top_diff + 1-byte arg-max codes + "
+                 "bottom_diff once) / launch time of the dominant kernel alone; its helper launches (window "
+                 "table / list building, latency-bound chains) are in helper_launches_ms and "
+                 "frac_moved_with_helpers.  frac_8d uses SURVEY.md 8(d)'s bytes for the reference's f32 + i32 "
+                 "layout.  RoI-pool parity is pinned by hand-computed cases and two independent oracle "
+                 "restatements, not by reference outputs (TensorFlow op cannot be built here: 'parity unpinned', "
+                 "DESIGN.md section 2)",
             fixed_set={k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                        for k, v in leg.items()},
             per_kernel={k: dict(avg_ms=round(v["avg_ms"], 4), calls=v["calls"],
@@ -431,7 +494,8 @@ def main():
                        "parallelism": "image-parallel dp%d, %s grad all-reduce" % (
                            ctx.world_size, "RCCL" if (ctx.backend or "nccl") == "nccl" else ctx.backend),
                        "sampling_rng": args.sampling_rng, "fused_rpn_softmax": bool(cfg.FUSED_RPN_SOFTMAX), "padded_rois": bool(cfg.PADDED_ROIS),
-                       "miopen_find": (not args.no_miopen_benchmark), "miopen_find_db": "wssdl_bus_amd/miopen_db" if miopen_db else None,
+                       "miopen_find": (not args.no_miopen_benchmark), "miopen_find_db": miopen_db_note,
+                       "miopen_searched": miopen_db_grew(miopen_db),
                        "roi_pool_argmax_bytes": leg_meta["argmax_bytes"]},
             "roofline": roofline,
             "hot_path": {"gpu_ms_per_step": round(hot_ms, 3),
@@ -448,7 +512,13 @@ def main():
                 "R": int(rois_fixed.shape[0]), "gpu_ms": round(gpu_pool_ms, 3),
                 "cpu_ms": round(cb["cpu_roi_pool_ms"], 1), "ratio": round(cb["cpu_roi_pool_ms"] / gpu_pool_ms, 1)}
             if hot_ms > 0:
-                result["hot_path"]["speedup_vs_cpu_baseline"] = round(cb["cpu_hot_path_ms_per_step"] / hot_ms, 1)
+                # NOT like for like: the CPU layers produced and pooled cb["roi_pool_rois"] RoIs, the GPU
+                # steps pooled whatever NMS left of this run's proposals (roi_pool_same_set is the
+                # same-work figure)
+                gpu_rois = [m.get("R") for m in tl.get("roi_pool_forward", {}).get("metas", [])]
+                result["hot_path"]["cpu_ms_over_gpu_ms_roi_counts_differ"] = {
+                    "ratio": round(cb["cpu_hot_path_ms_per_step"] / hot_ms, 1),
+                    "cpu_rois": cb["roi_pool_rois"], "gpu_rois_per_step": [min(gpu_rois), max(gpu_rois)] if gpu_rois else None}
         print(json.dumps(result))
     ctx.shutdown()
 

@@ -66,6 +66,14 @@ enum wssdl_dataset {
 WSSDL_API const char *wssdl_version(void);
 /* name of the last HIP error seen by this library on the calling thread ("" if none) */
 WSSDL_API const char *wssdl_last_error(void);
+/* Tuning knobs.  The library never reads the environment: a knob is an int the caller sets (process
+ * wide, read at call time).  Keys: "roi_bwd_plan" (plan id of the list-driven RoI-pool backward, -1 =
+ * by launch size), "roi_fwd_variant",
+ * "roi_bwdc_variant", "roi_bwd_cg" (shapes of the compact forward / the fallback backwards, 0 =
+ * automatic), "nms_one_pass" (1: the proposal layer skips the probe pass).  Results do not depend on
+ * any of them.  Unknown key -> WSSDL_ERR_INVALID_ARGUMENT. */
+WSSDL_API int wssdl_set_tuning(const char *key, int value);
+WSSDL_API int wssdl_get_tuning(const char *key, int *value_host);
 
 /* ------------------------------------------------------------------ a1, a2 ---
  * generate_anchors: rpn_msr/generate_anchors.py:37-97.  Host-side (9 boxes);
@@ -292,6 +300,13 @@ WSSDL_API int wssdl_roi_pool_forward_compact_windows(const float *bottom, int N,
  * bottom_diff is bit-identical on every path. */
 WSSDL_API size_t wssdl_roi_pool_backward_workspace_bytes(int R, int N, int H, int W, int pooled_h,
                             int pooled_w);
+/* number of plans wssdl_roi_pool_backward_prepare can choose from ("roi_bwd_plan" = 0 .. count-1) */
+WSSDL_API int wssdl_roi_pool_backward_plan_count(void);
+/* byte offset, inside the workspace, of the int32[4] status block the prepare step fills:
+ * [0] = 64-byte records in use, [1] = error flags (non-zero: the lists do not fit the workspace and
+ * bottom_diff would be short -- cannot happen with wssdl_roi_pool_backward_workspace_bytes; the host
+ * layer checks it with its other deferred flags). */
+WSSDL_API size_t wssdl_roi_pool_backward_status_offset(int R, int N, int H, int W, int pooled_h, int pooled_w);
 WSSDL_API int wssdl_roi_pool_backward_prepare(const float *rois, int R, int N, int H, int W, int C,
                             int pooled_h, int pooled_w, float spatial_scale, int rounding,
                             void *workspace, size_t workspace_bytes, int32_t *plan_host,

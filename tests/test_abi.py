@@ -98,3 +98,28 @@ def test_product_package_does_not_import_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
                 assert "liboracle" not in text, f
+
+
+def test_library_does_not_read_the_environment(lib_path):
+    """Tuning goes through wssdl_set_tuning; the default build has no getenv import and no
+    lab-build (ablation / trace) switches in its sources."""
+    out = subprocess.check_output(["nm", "-D", "--undefined-only", lib_path]).decode()
+    assert not re.search(r"\b(secure_)?getenv\b", out)
+    csrc = os.path.join(ROOT, "wssdl_bus_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            text = open(os.path.join(csrc, f)).read()
+            assert "getenv" not in text and "_ABLATE" not in text and "_TRACE" not in text, f
+
+
+def test_tuning_knobs_are_plain_ints(lib_path):
+    from wssdl_bus_amd import _lib
+    L = _lib.lib()
+    assert _lib.get_tuning("roi_bwd_plan") == -1
+    with _lib.tuned(roi_bwd_plan=11, nms_one_pass=1):
+        assert _lib.get_tuning("roi_bwd_plan") == 11 and _lib.get_tuning("nms_one_pass") == 1
+    assert _lib.get_tuning("roi_bwd_plan") == -1 and _lib.get_tuning("nms_one_pass") == 0
+    assert L.wssdl_set_tuning(b"no_such_knob", 1) == _lib.ERR_INVALID_ARGUMENT
+    assert L.wssdl_roi_pool_backward_plan_count() >= 26
+    off = L.wssdl_roi_pool_backward_status_offset(8512, 8, 38, 63, 7, 7)
+    assert off % 256 == 0 and 0 < off < L.wssdl_roi_pool_backward_workspace_bytes(8512, 8, 38, 63, 7, 7)

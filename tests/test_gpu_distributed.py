@@ -265,3 +265,38 @@ def test_two_ranks_on_one_gpu_real_steps_match_mean_gradient_update():
         assert o["joint_err"] <= 1e-5 and o["alter_err"] <= 1e-5, o
         assert o["alter_step"] == 1 and o["alter_calls"] == [False, True]
         assert o["weak_nograd_params"] > 0 and o["weak_nograd_static"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_py_under_torch_distributed_run_two_ranks():
+    """bench.py ITSELF under the launcher the scaling run uses (`python -m torch.distributed.run
+    --nproc-per-node 2 ... bench.py --gpus 2`), two ranks sharing the one GPU over gloo
+    (WSSDL_DIST_BACKEND; RCCL refuses two ranks on one device).  The launcher starts fresh children
+    before anything touches the GPU; this process only waits for it.  Checks the contract of the one
+    JSON line: n_gpus, whole-job value = ranks x images / max-rank time, roofline present, no
+    cpu_baseline at N > 1."""
+    import json
+    import subprocess
+    env = dict(os.environ, WSSDL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "WSSDL_FORCE_DIST", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "resnet18_sup_b2", "--no-cpu-baseline", "--roofline-iters", "3"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=840)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-2000:] + p.stderr.decode()[-4000:]
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]                      # rank 0 alone prints
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak"
+    assert r["config"]["workload"] == "resnet18_sup_b2" and r["config"]["images_per_gpu"] == 2
+    assert "gloo" in r["config"]["parallelism"] and "dp2" in r["config"]["parallelism"]
+    # whole-job aggregate: 2 ranks x 2 images per step / the (max over ranks) step time
+    assert abs(r["value"] - 2 * 2 / (r["ms_per_step"] * 1e-3)) <= 0.01 * r["value"]
+    assert "cpu_baseline" not in r
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["kernel"] in ("roi_pool_forward", "roi_pool_backward")
+    assert 0 < rf["frac"] < 1 and rf["frac"] == rf["frac_moved"] and rf["frac_8d"] > rf["frac_moved"]
+    assert r["final_loss"] is not None and r["final_loss"] == r["final_loss"]        # not NaN

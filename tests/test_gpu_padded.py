@@ -210,3 +210,79 @@ def test_hot_path_chain_is_graph_capturable(torch_cuda, cfg_guard):
     for a, b in zip(eager, captured):
         assert torch.equal(a, b)
     assert tuple(captured[0].shape) == (128 + 2000, 5)
+
+
+@pytest.mark.parametrize("C,per,relu", [(2048, 16, True), (512, 49, True), (1024, 49, False), (64, 16, True)])
+def test_fused_masked_row_batch_norm_equals_compacted(torch_cuda, C, per, relu):
+    """csrc/plumbing/rowbn.hip with a live-row mask: the live rows (forward, dx) and the parameter
+    gradients equal the unmasked kernels run on the compacted rows; dead rows come out as zeros in
+    both directions whatever they hold; the live-row count is right."""
+    torch = torch_cuda
+    from wssdl_bus_amd.networks import _plumbing
+    g = torch.Generator("cuda").manual_seed(C + per)
+    R = 301
+    mask = (torch.rand((R,), device="cuda", generator=g) > 0.3).to(torch.float32)
+    mask[0], mask[-1] = 0.0, 1.0
+    x = torch.randn((R * per, C), device="cuda", generator=g)
+    x[(mask == 0).repeat_interleave(per)] = 1e6                   # junk in dead rows must not matter
+    dy = torch.randn((R * per, C), device="cuda", generator=g)
+    w = torch.rand((C,), device="cuda", generator=g) + 0.5
+    b = torch.randn((C,), device="cuda", generator=g)
+    if not _plumbing.usable(x):
+        pytest.skip("fused row batch-norm not usable for this shape")
+    live = (mask != 0).repeat_interleave(per)
+    y, stats, count = _plumbing.rowbn_forward(x, w, b, 1e-3, relu, mask)
+    yc, stats_c, _ = _plumbing.rowbn_forward(x[live].contiguous(), w, b, 1e-3, relu)
+    assert float(count) == float(live.sum())
+    assert torch.equal(stats[:2], stats_c[:2]) or torch.allclose(stats, stats_c, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(y[live], yc, rtol=1e-6, atol=1e-6)
+    assert float(y[~live].abs().max()) == 0.0
+    dx, dw, db = _plumbing.rowbn_backward(x, dy, w, stats, relu, mask)
+    dxc, dwc, dbc = _plumbing.rowbn_backward(x[live].contiguous(), dy[live].contiguous(), w, stats_c, relu)
+    assert torch.allclose(dx[live], dxc, rtol=1e-5, atol=1e-6)
+    assert float(dx[~live].abs().max()) == 0.0
+    assert torch.allclose(dw, dwc, rtol=1e-5, atol=1e-4) and torch.allclose(db, dbc, rtol=1e-5, atol=1e-4)
+    # an all-live mask is the unmasked layer
+    ones = torch.ones((R,), device="cuda")
+    y1, s1, c1 = _plumbing.rowbn_forward(x, w, b, 1e-3, relu, ones)
+    y0, s0, _ = _plumbing.rowbn_forward(x, w, b, 1e-3, relu)
+    assert torch.equal(y1, y0) and torch.equal(s1, s0) and float(c1) == R * per
+
+
+def test_short_supervised_image_does_not_leak_into_head_batch_norm(torch_cuda, cfg_guard):
+    """Device sampler, DEFAULT (compacting) mode: a supervised image that runs short of candidates keeps
+    its fixed 128 rows, the missing ones as padding rows (-1, 0, 0, 0, 0).  Those rows must not enter the
+    per-RoI head's batch statistics: the head's outputs for the live rows equal a run on the live rows
+    alone, and the running statistics move identically."""
+    torch = torch_cuda
+    cfg = cfg_guard
+    import copy
+    from wssdl_bus_amd.networks import roi_head
+    from wssdl_bus_amd.networks.roi_head import ResNetHeadNHWC
+    cfg.SAMPLING_RNG = "device"
+    cfg.PADDED_ROIS = False
+    head = ResNetHeadNHWC(18).cuda().train()
+    head2 = copy.deepcopy(head)
+    g = torch.Generator("cuda").manual_seed(9)
+    R, dead = 96, 17
+    pooled = torch.relu(torch.randn((R, 7, 7, 256), device="cuda", generator=g))
+    mask = torch.ones((R,), device="cuda")
+    mask[R - dead:] = 0.0
+    pooled[R - dead:] = 0.0                                       # what RoI pooling writes for batch index -1
+    roi_head.set_roi_mask(mask)
+    try:
+        out = head(pooled)
+    finally:
+        roi_head.set_roi_mask(None)
+    ref = head2(pooled[:R - dead].contiguous())
+    assert torch.allclose(out[:R - dead], ref, rtol=1e-4, atol=1e-5)
+    for (k, a), (_, b) in zip(head.state_dict().items(), head2.state_dict().items()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), k
+    # without the mask the dead rows shift the statistics (this is what the mask is for)
+    head3 = copy.deepcopy(head2)
+    wrong = head3(pooled)
+    assert not torch.allclose(wrong[:R - dead], ref, rtol=1e-3, atol=1e-4)
+    # and the network installs the mask whenever the device sampler is on
+    import inspect
+    from wssdl_bus_amd.networks import Resnet_train_bus
+    assert "SAMPLING_RNG == 'device'" in inspect.getsource(Resnet_train_bus)

@@ -40,6 +40,7 @@ def _rois_for(rs, R, N, H, W):
 @pytest.mark.parametrize("mode", ["cuda", "cpu"])
 def test_compact_pair_vs_oracle(torch_cuda, shape, mode):
     torch = torch_cuda
+    from wssdl_bus_amd import _lib
     from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
     N, H, W, C = shape
     assert op.compact_supported(H, W, C, 7, 7)
@@ -53,12 +54,9 @@ def test_compact_pair_vs_oracle(torch_cuda, shape, mode):
     # allows, shared bin columns in registers), 1 = one bin row per wave with a store per bin, 2 =
     # 128-channel waves, 3 = one RoI (7 one-row waves) per workgroup, 4 = as 0 with the geometry computed
     # in the kernel, 5 = a whole RoI per wave, 9 = the two-rows-per-wave sliced kernel
-    for fwd in ("9", "3", "2", "1", "4", "5", "0"):
-        os.environ["WSSDL_ROI_FWD_VARIANT"] = fwd
-        try:
+    for fwd in (9, 3, 2, 1, 4, 5, 0):
+        with _lib.tuned(roi_fwd_variant=fwd):
             top, arg8 = op.roi_pool_compact(ft, rt, 7, 7, 1.0 / 16, rounding=mode)
-        finally:
-            os.environ.pop("WSSDL_ROI_FWD_VARIANT", None)
         assert arg8.dtype == torch.uint8 and tuple(arg8.shape) == (R, 7, 7, C)
         assert np.array_equal(top.cpu().numpy(), et), fwd
         arg = op.expand_argmax(arg8, rt, shape, 7, 7, 1.0 / 16, rounding=mode)
@@ -69,29 +67,23 @@ def test_compact_pair_vs_oracle(torch_cuda, shape, mode):
     diff = rs.normal(size=et.shape).astype(np.float32)
     want = c_oracle.roi_pool_backward(diff, ea, rois, f.shape, 7, 7, 1.0 / 16)
     dt = torch.from_numpy(diff).cuda()
-    old = {k: os.environ.get(k) for k in ("WSSDL_ROI_BWDC_VARIANT", "WSSDL_ROI_BWD_PLAN")}
-    try:
-        # every plan of the list-driven walk (tile shape x records in flight) ...
-        for plan_id in range(21):
-            os.environ["WSSDL_ROI_BWD_PLAN"] = str(plan_id)
+    # every plan of the list-driven walk (tile shape x records in flight x channels per lane) ...
+    n_plans = _lib.lib().wssdl_roi_pool_backward_plan_count()
+    assert n_plans >= 26
+    for plan_id in range(n_plans):
+        with _lib.tuned(roi_bwd_plan=plan_id):
             plan = op.roi_pool_grad_prepare(shape, rt, 7, 7, 1.0 / 16, rounding=mode)
             assert plan.plan == plan_id
             got = op.roi_pool_grad_compact(shape, rt, arg8, dt, 7, 7, 1.0 / 16, rounding=mode, plan=plan)
-            assert np.array_equal(got.cpu().numpy(), want), (shape, mode, "plan", plan_id)
-            got = op.roi_pool_grad_compact(shape, rt, arg8, 2 * dt, 7, 7, 1.0 / 16, rounding=mode, plan=plan)
-            assert np.array_equal(got.cpu().numpy(), 2 * want)            # a plan serves many backward calls
-        os.environ.pop("WSSDL_ROI_BWD_PLAN")
-        # ... and every shape of the fallback kernel that filters the RoIs itself (no workspace)
-        for variant in ("0", "1", "2", "3", "4", "5"):
-            os.environ["WSSDL_ROI_BWDC_VARIANT"] = variant
+        assert np.array_equal(got.cpu().numpy(), want), (shape, mode, "plan", plan_id)
+        got = op.roi_pool_grad_compact(shape, rt, arg8, 2 * dt, 7, 7, 1.0 / 16, rounding=mode, plan=plan)
+        assert np.array_equal(got.cpu().numpy(), 2 * want)            # a plan serves many backward calls
+        assert not op.flags_raised()
+    # ... and every shape of the fallback kernel that filters the RoIs itself (no workspace)
+    for variant in range(6):
+        with _lib.tuned(roi_bwdc_variant=variant):
             got = op.roi_pool_grad_compact(shape, rt, arg8, dt, 7, 7, 1.0 / 16, rounding=mode, use_workspace=False)
-            assert np.array_equal(got.cpu().numpy(), want), (shape, mode, "fallback", variant)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        assert np.array_equal(got.cpu().numpy(), want), (shape, mode, "fallback", variant)
 
 
 def test_compact_other_pooled_sizes_and_unsupported_shapes(torch_cuda):
@@ -252,3 +244,102 @@ def test_compact_full_size_properties(torch_cuda):
     got = op.roi_pool_grad_compact((1, H, W, C), rois[img0], arg8[img0].contiguous(), d[img0].contiguous(), 7, 7, 1.0 / 16)
     assert np.array_equal(got.cpu().numpy(), want)
     assert not op.compact_overflowed()
+
+
+def roofline_set_parity(torch, images=(0, 4), plans=(None,)):
+    """The RoI-pool pair on the FIXED set bench.py's roofline is quoted on
+    (profiles/roofline_rois_r8512.npy: 4 x 128 sampled rows + 4 x 2000 topped-up proposals), run at
+    full size, against the C oracle image by image: top, expanded arg-max and bottom_diff bit for
+    bit (roi_pooling_op_gpu.cu.cc:20-85,114-190).  Also used by tools/roofline_leg.py --check."""
+    from wssdl_bus_amd import _lib
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rois_np = np.load(os.path.join(root, "profiles", "roofline_rois_r8512.npy"))
+    N, H, W, C = int(rois_np[:, 0].max()) + 1, 38, 63, 1024
+    R = rois_np.shape[0]
+    assert (N, R) == (8, 8512)
+    gen = torch.Generator("cuda").manual_seed(3)
+    f = torch.relu(torch.randn((N, H, W, C), device="cuda", generator=gen))
+    rois = torch.from_numpy(rois_np).cuda()
+    top, arg8 = op.roi_pool_compact(f, rois, 7, 7, 1.0 / 16)
+    arg = op.expand_argmax(arg8, rois, (N, H, W, C), 7, 7, 1.0 / 16)
+    d = torch.randn(top.shape, device="cuda", generator=gen)
+    grads = []
+    for p in plans:
+        with _lib.tuned(roi_bwd_plan=-1 if p is None else p):
+            plan = op.roi_pool_grad_prepare((N, H, W, C), rois, 7, 7, 1.0 / 16)
+            grads.append((plan, op.roi_pool_grad_compact((N, H, W, C), rois, arg8, d, 7, 7, 1.0 / 16, plan=plan)))
+    assert not op.flags_raised()          # no window overflow, lists within their workspace
+    # the prepare's record count against the bound the workspace was sized with
+    off = _lib.lib().wssdl_roi_pool_backward_status_offset(R, N, H, W, 7, 7)
+    status = grads[0][0].workspace[off:off + 16].view(torch.int32).cpu().numpy()
+    assert status[1] == 0 and 0 < status[0] * 64 < grads[0][0].nbytes
+    checked = {}
+    for n in images:
+        idx = np.where(rois_np[:, 0] == n)[0]
+        sub = rois_np[idx].copy()
+        sub[:, 0] = 0
+        fn = f[n:n + 1].cpu().numpy()
+        et, ea = c_oracle.roi_pool_forward(fn, sub, 7, 7, 1.0 / 16, "cuda", threads=16)
+        sl = slice(int(idx[0]), int(idx[-1]) + 1)
+        assert np.array_equal(idx, np.arange(sl.start, sl.stop))            # grouped by image
+        assert np.array_equal(top[sl].cpu().numpy(), et), ("top", n)
+        assert np.array_equal(arg[sl].cpu().numpy(), ea), ("argmax", n)
+        want = c_oracle.roi_pool_backward(d[sl].cpu().numpy(), ea, sub, (1, H, W, C), 7, 7, 1.0 / 16)
+        for plan, g in grads:
+            assert np.array_equal(g[n].cpu().numpy(), want[0]), ("bottom_diff", n, plan.plan)
+        checked[n] = len(idx)
+    return checked, [p.plan for p, _ in grads]
+
+
+def test_roofline_roi_set_matches_oracle(torch_cuda):
+    """Parity ON the timed workload: one supervised image (128 rows) and one weak image (2000 topped-up,
+    heavily overlapping rows) of the fixed roofline set: the plan the library picks, 6x6 tiles with two
+    and three records in flight, and a 64-channel plan."""
+    checked, plans = roofline_set_parity(torch_cuda, images=(0, 4), plans=(None, 11, 13, 23))
+    assert checked == {0: 128, 4: 2000}
+
+
+def test_oversized_roi_flags_and_i32_fallback(torch_cuda):
+    """A RoI reaching far outside the map has bin windows the 1-byte code cannot describe: the compact
+    forward raises its device flag.  'deferred' checking turns that into an error at the next check;
+    'eager' checking re-runs the call on the i32 pair, whose result equals the oracle."""
+    torch = torch_cuda
+    from wssdl_bus_amd import _lib
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    rs = np.random.RandomState(11)
+    N, H, W, C = 2, 38, 63, 256
+    f_np = np.maximum(rs.normal(size=(N, H, W, C)), 0).astype(np.float32)
+    rois_np = _rois_for(rs, 64, N, H, W)
+    rois_np[5] = [1, -9000.0, -7000.0, 9000.0, 8000.0]            # bins of ~160 x 130 cells, clipped to the map
+    et, ea = c_oracle.roi_pool_forward(f_np, rois_np, 7, 7, 1.0 / 16, "cuda", threads=8)
+    w_np = rs.normal(size=et.shape).astype(np.float32)
+    want = c_oracle.roi_pool_backward(w_np, ea, rois_np, f_np.shape, 7, 7, 1.0 / 16)
+    rois, w = torch.from_numpy(rois_np).cuda(), torch.from_numpy(w_np).cuda()
+    assert not op.flags_raised()
+    old = cfg.ROI_POOL_FLAG_CHECK
+    try:
+        cfg.ROI_POOL_FLAG_CHECK = "deferred"
+        f = torch.from_numpy(f_np).cuda().requires_grad_(True)
+        top, _ = op.roi_pool_autograd(f, rois, 7, 7, 1.0 / 16, return_argmax=False)
+        with pytest.raises(_lib.HipCallError, match="15 x 16"):
+            op.check_flags()
+        assert not op.flags_raised()                              # cleared by the check
+        cfg.ROI_POOL_FLAG_CHECK = "eager"
+        f = torch.from_numpy(f_np).cuda().requires_grad_(True)
+        top, arg = op.roi_pool_autograd(f, rois, 7, 7, 1.0 / 16)
+        assert arg.dtype == torch.int32
+        assert np.array_equal(top.detach().cpu().numpy(), et) and np.array_equal(arg.cpu().numpy(), ea)
+        (top * w).sum().backward()
+        assert np.array_equal(f.grad.cpu().numpy(), want)
+        op.check_flags()                                          # nothing left raised
+        # without the far RoI the eager mode stays on the 1-byte pair
+        keep = np.ones(len(rois_np), bool)
+        keep[5] = False
+        f2 = torch.from_numpy(f_np).cuda().requires_grad_(True)
+        top2, arg2 = op.RoiPoolFunction.apply(f2, rois[torch.from_numpy(keep).cuda()].contiguous(), 7, 7, 1.0 / 16, None)
+        assert arg2.dtype == torch.uint8 and np.array_equal(top2.detach().cpu().numpy(), et[keep])
+    finally:
+        cfg.ROI_POOL_FLAG_CHECK = old
+        op.flags_raised()

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Times plans of the list-driven RoI-pool backward (tile shape x records in flight x channels per
+lane) on the FIXED roofline RoI set (profiles/roofline_rois_r8512.npy) and checks every one bit for
+bit against plan 11.
+
+    python3 tools/bwd_fixed_sweep.py --plans 11,13,16 [--iters 20] [--one PLAN]
+
+--one runs a single plan a few times and nothing else: the form to put under `rocprofv3 --pmc ...`
+for the HBM traffic of one variant.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import torch  # noqa: E402
+
+from roofline_leg import load_rois, moved_bytes  # noqa: E402
+from wssdl_bus_amd import _lib  # noqa: E402
+from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op  # noqa: E402
+
+
+def timeit(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--plans", default="11,13,16,5,9,10")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--one", default="")
+    ap.add_argument("--channels", type=int, default=1024)
+    args = ap.parse_args()
+    rois_np, tag = load_rois()
+    N, H, W, C = int(rois_np[:, 0].max()) + 1, 38, 63, args.channels
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(3)
+    feat = torch.relu(torch.randn((N, H, W, C), device=dev, generator=g))
+    rois = torch.from_numpy(rois_np).to(dev)
+    R = rois.shape[0]
+    shape = (N, H, W, C)
+    top, arg8 = op.roi_pool_compact(feat, rois, 7, 7, 1.0 / 16)
+    diff = torch.randn(top.shape, device=dev, generator=g)
+    del top
+    mb = moved_bytes("roi_pool_backward", N, H, W, C, R)
+
+    def run(plan_id):
+        with _lib.tuned(roi_bwd_plan=plan_id):
+            plan = op.roi_pool_grad_prepare(shape, rois, 7, 7, 1.0 / 16)
+        assert plan.plan == plan_id
+        return plan
+
+    if args.one:
+        plan = run(int(args.one))
+        for _ in range(5):
+            op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan)
+        torch.cuda.synchronize()
+        print(json.dumps(dict(one=args.one, R=R, C=C)))
+        return
+
+    ref = op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=run(11))
+    timeit(lambda: op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=run(11)), 10)     # clocks up
+    for p in (int(x) for x in args.plans.split(",")):
+        plan = run(p)
+        got = op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan)
+        same = bool(torch.equal(got, ref))
+        del got
+        ms = timeit(lambda: op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan), args.iters)
+        with _lib.tuned(roi_bwd_plan=p):
+            ms_prep = timeit(lambda: op.roi_pool_grad_prepare(shape, rois, 7, 7, 1.0 / 16), 10)
+        print(json.dumps(dict(plan=p, walk_ms=round(ms, 4), prepare_ms=round(ms_prep, 4), equal_to_plan11=same,
+                              moved_TBps=round(mb / ms / 1e9, 3), frac_moved=round(mb / ms / 1e9 / 8.0, 3))), flush=True)
+        assert same, p
+    assert not op.flags_raised()
+
+
+if __name__ == "__main__":
+    main()

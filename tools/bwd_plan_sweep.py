@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
 
 from kernel_bench import synth_rpn, timeit  # noqa: E402
+from wssdl_bus_amd import _lib  # noqa: E402
 from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op  # noqa: E402
 from wssdl_bus_amd.rpn_msr.proposal_layer_tf_bus import compact_rois, proposal_layer_padded  # noqa: E402
 
@@ -25,7 +26,7 @@ def main():
     ap.add_argument("--images", type=int, default=2)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--keep", type=int, default=0, help="RoIs kept per image (0 = all proposals)")
-    ap.add_argument("--plans", default="auto,11,1,5,0,18,19,20")
+    ap.add_argument("--plans", default="auto,11,5,18,19,23,22,21")
     ap.add_argument("--iters", type=int, default=20)
     args = ap.parse_args()
     N, H, W, C = args.images, 38, 63, args.channels
@@ -40,10 +41,7 @@ def main():
     diff = torch.randn_like(top)
     ref = None
     for p in args.plans.split(","):
-        if p == "auto":
-            os.environ.pop("WSSDL_ROI_BWD_PLAN", None)
-        else:
-            os.environ["WSSDL_ROI_BWD_PLAN"] = p
+        _lib.set_tuning("roi_bwd_plan", -1 if p == "auto" else int(p))
         plan = op.roi_pool_grad_prepare(tuple(feat.shape), rois, 7, 7, 1.0 / 16)
         g = op.roi_pool_grad_compact(tuple(feat.shape), rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan)
         ref = g if ref is None else ref
@@ -53,7 +51,7 @@ def main():
                     args.iters)
         print(json.dumps(dict(plan=p, picked=plan.plan, N=N, C=C, R=int(rois.shape[0]), walk_ms=round(ms, 4),
                               prepare_ms=round(ms_prep, 4))))
-    os.environ.pop("WSSDL_ROI_BWD_PLAN", None)
+    _lib.set_tuning("roi_bwd_plan", -1)
 
 
 if __name__ == "__main__":

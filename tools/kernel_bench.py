@@ -15,6 +15,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+from wssdl_bus_amd import _lib  # noqa: E402
 from wssdl_bus_amd.fast_rcnn.config import cfg  # noqa: E402
 from wssdl_bus_amd.roi_pooling_layer.roi_pooling_op import (roi_pool, roi_pool_grad, roi_pool_compact,  # noqa: E402
                                                             roi_pool_grad_compact, compact_supported)
@@ -97,22 +98,20 @@ def main():
         top_c, arg8 = roi_pool_compact(feat, rois, 7, 7, 1.0 / 16)
         assert os.environ.get("KB_NO_CHECK") or torch.equal(top_c, top)
         for fv in os.environ.get("KB_FWD_VARIANTS", "0").split(","):
-            os.environ["WSSDL_ROI_FWD_VARIANT"] = fv
+            _lib.set_tuning("roi_fwd_variant", int(fv))
             t2, a2 = roi_pool_compact(feat, rois, 7, 7, 1.0 / 16)
             assert os.environ.get("KB_NO_CHECK") or (torch.equal(t2, top) and torch.equal(a2, arg8))
             ms = timeit(lambda: roi_pool_compact(feat, rois, 7, 7, 1.0 / 16), args.iters, warmup=5)
             byt = N * H * W * C * 4 + R * 20 + R * 49 * C * 8
             out.append(dict(op="roi_pool_forward_compact[v%s]" % fv, ms=ms, R=R, C=C, alg_bytes=byt, GBps=byt / ms / 1e6,
                             moved_bytes=N * H * W * C * 4 + R * 20 + R * 49 * C * 5))
-        os.environ.pop("WSSDL_ROI_FWD_VARIANT", None)
+        _lib.set_tuning("roi_fwd_variant", 0)
         ref_g = roi_pool_grad(feat, rois, arg, diff, 7, 7, 1.0 / 16)
         from wssdl_bus_amd.roi_pooling_layer.roi_pooling_op import roi_pool_grad_prepare
         shape = tuple(feat.shape)
         for plan_id in os.environ.get("KB_BWD_PLANS", "auto").split(","):
-            if plan_id == "auto":                       # the plan the library picks for this launch size
-                os.environ.pop("WSSDL_ROI_BWD_PLAN", None)
-            else:
-                os.environ["WSSDL_ROI_BWD_PLAN"] = plan_id
+            # "auto" = the plan the library picks for this launch size
+            _lib.set_tuning("roi_bwd_plan", -1 if plan_id == "auto" else int(plan_id))
             plan = roi_pool_grad_prepare(shape, rois, 7, 7, 1.0 / 16)
             g = roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan)
             assert os.environ.get("KB_NO_CHECK") or torch.equal(g, ref_g), plan_id
@@ -122,7 +121,7 @@ def main():
             byt = R * 49 * C * 8 + N * H * W * C * 4
             out.append(dict(op="roi_pool_backward_compact[plan %s]" % plan_id, ms=ms, prepare_ms=ms_p, R=R, C=C,
                             alg_bytes=byt, GBps=byt / ms / 1e6, GBps_with_prepare=byt / (ms + ms_p) / 1e6))
-        os.environ.pop("WSSDL_ROI_BWD_PLAN", None)
+        _lib.set_tuning("roi_bwd_plan", -1)
         ms = timeit(lambda: roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, use_workspace=False),
                     args.iters, warmup=5)
         out.append(dict(op="roi_pool_backward_compact[no lists]", ms=ms, R=R, C=C, alg_bytes=byt, GBps=byt / ms / 1e6))

@@ -120,9 +120,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--check", action="store_true",
+                    help="before timing: the pair's outputs on this RoI set against the C oracle, bit for bit "
+                         "(one supervised and one weak image; tests/test_gpu_roi_compact.py)")
     args = ap.parse_args()
     import torch
     assert torch.cuda.is_available()
+    if args.check:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_gpu_roi_compact import roofline_set_parity
+        checked, plans = roofline_set_parity(torch)
+        print(json.dumps(dict(check="top, argmax, bottom_diff == C oracle", rois_per_image=checked, plans=plans)))
     rois, tag = load_rois()
     N = int(rois[:, 0].max()) + 1
     ops, meta = run(rois, N, 38, 63, 1024, args.iters, args.warmup)

@@ -24,6 +24,8 @@ _sz, _u64 = ctypes.c_size_t, ctypes.c_uint64
 SYMBOLS = {
     "wssdl_version": (ctypes.c_char_p, []),
     "wssdl_last_error": (ctypes.c_char_p, []),
+    "wssdl_set_tuning": (_i, [ctypes.c_char_p, _i]),
+    "wssdl_get_tuning": (_i, [ctypes.c_char_p, _vp]),
     "wssdl_generate_anchors_host": (_i, [_i, _vp, _i, _vp, _i, _vp]),
     "wssdl_shifted_anchors": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "wssdl_bbox_overlaps": (_i, [_vp, _i64, _i, _vp, _i64, _i, _vp, _vp]),
@@ -58,6 +60,8 @@ SYMBOLS = {
     "wssdl_roi_pool_forward_windows": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp]),
     "wssdl_roi_pool_forward_compact_windows": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "wssdl_roi_pool_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "wssdl_roi_pool_backward_plan_count": (_i, []),
+    "wssdl_roi_pool_backward_status_offset": (_sz, [_i, _i, _i, _i, _i, _i]),
     "wssdl_roi_pool_backward_prepare": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp]),
     "wssdl_roi_pool_backward_compact": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _i,
                                              _vp]),
@@ -113,6 +117,35 @@ def check(rc, what):
         err = lib().wssdl_last_error().decode()
         raise HipCallError("%s failed: %s%s" % (what, _STATUS.get(rc, "status %d" % rc),
                                                 (" (%s)" % err) if err else ""))
+
+
+def set_tuning(key, value):
+    """wssdl_set_tuning: the library's knobs are set here, never through the environment."""
+    check(lib().wssdl_set_tuning(key.encode(), int(value)), "wssdl_set_tuning(%s)" % key)
+
+
+def get_tuning(key):
+    v = ctypes.c_int(0)
+    check(lib().wssdl_get_tuning(key.encode(), ctypes.byref(v)), "wssdl_get_tuning(%s)" % key)
+    return int(v.value)
+
+
+class tuned(object):
+    """with tuned(roi_bwd_plan=11): ...   -- sets knobs and restores them."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: get_tuning(k) for k in self.kv}
+        for k, v in self.kv.items():
+            set_tuning(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_tuning(k, v)
+        return False
 
 
 def ptr(t):

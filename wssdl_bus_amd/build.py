@@ -39,8 +39,7 @@ def is_stale():
 def build(force=False, verbose=True):
     if not force and not is_stale():
         return OUT
-    extra = os.environ.get("WSSDL_HIPCC_EXTRA", "").split()     # e.g. -DWSSDL_SWEEP_BLOCK=512 (tuning)
-    cmd = [hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp"]
+    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp"]
     if verbose:
         print("[wssdl_bus_amd] " + " ".join(cmd))
     subprocess.check_call(cmd)

@@ -9,6 +9,36 @@ static thread_local hipError_t g_last_error = hipSuccess;
 void set_last_error(hipError_t e) { g_last_error = e; }
 }  // namespace wssdl
 
+namespace wssdl {
+static Tuning g_tuning;
+Tuning &tuning() { return g_tuning; }
+
+static int *tuning_field(const char *key) {
+    if (!key) return nullptr;
+    Tuning &t = g_tuning;
+    if (!strcmp(key, "roi_bwd_plan")) return &t.roi_bwd_plan;
+    if (!strcmp(key, "roi_fwd_variant")) return &t.roi_fwd_variant;
+    if (!strcmp(key, "roi_bwdc_variant")) return &t.roi_bwdc_variant;
+    if (!strcmp(key, "roi_bwd_cg")) return &t.roi_bwd_cg;
+    if (!strcmp(key, "nms_one_pass")) return &t.nms_one_pass;
+    return nullptr;
+}
+}  // namespace wssdl
+
+extern "C" int wssdl_set_tuning(const char *key, int value) {
+    int *f = wssdl::tuning_field(key);
+    if (!f) return WSSDL_ERR_INVALID_ARGUMENT;
+    *f = value;
+    return WSSDL_OK;
+}
+
+extern "C" int wssdl_get_tuning(const char *key, int *value_host) {
+    int *f = wssdl::tuning_field(key);
+    if (!f || !value_host) return WSSDL_ERR_INVALID_ARGUMENT;
+    *value_host = *f;
+    return WSSDL_OK;
+}
+
 extern "C" const char *wssdl_version(void) { return "wssdl_bus_hip 0.1 (gfx950)"; }
 
 extern "C" const char *wssdl_last_error(void) {

@@ -40,6 +40,17 @@ inline int load_base_anchors(const double *host, int A, BaseAnchors *out) {
     return WSSDL_OK;
 }
 
+// Tuning knobs (wssdl_set_tuning): plain ints read at call time; nothing in the library reads the
+// environment.  Defaults = automatic choices.
+struct Tuning {
+    int roi_bwd_plan = -1;      // plan id of the list-driven RoI-pool backward (-1: by launch size)
+    int roi_fwd_variant = 0;    // shape of the compact RoI-pool forward (0: automatic)
+    int roi_bwdc_variant = 0;   // shape of the tile-owner fallback backward
+    int roi_bwd_cg = 0;         // channels per workgroup of the fallback backwards (0: automatic)
+    int nms_one_pass = 0;       // 1: the proposal layer never uses the probe pass
+};
+Tuning &tuning();
+
 // workspace carving: 256-byte aligned slices
 struct Carver {
     char *base;

@@ -301,10 +301,7 @@ __device__ __forceinline__ float box_area_ref(float x1, float y1, float x2, floa
 }
 
 // ---- shared by the mask kernel and the sweeps (the sweep section explains them) ----
-#ifndef WSSDL_SWEEP_BLOCK
-#define WSSDL_SWEEP_BLOCK 1024
-#endif
-constexpr int SWEEP_BLOCK = WSSDL_SWEEP_BLOCK;
+constexpr int SWEEP_BLOCK = 1024;
 constexpr size_t SWEEP_LDS_LIMIT = 60 * 1024;     // kept list in LDS up to ~15k entries
 constexpr int SWEEP_LH = 7;
 constexpr int SWEEP_FIRST_HELPER = 6;                                   // wave index
@@ -857,10 +854,6 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(
                 for (int j = 0; j <= SWEEP_AHEAD; ++j) sh.rowbuf[(c + 1) & 1][j][lane] = rows[j];
                 load_rows(c + 3);
             } else {
-#if defined(WSSDL_SWEEP_ABLATE) && WSSDL_SWEEP_ABLATE == 1
-                // tuning builds only: helpers idle (wrong results; shows the resolver + barrier floor)
-                if (false)
-#endif
                 {
                 // consume word c+1 (issued at iteration c-2; slots beyond the list were zeroed)
                 unsigned long long acc = 0ull;

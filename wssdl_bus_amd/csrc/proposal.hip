@@ -205,7 +205,7 @@ static int proposal_layer_impl(int from_logits, const float *rpn_cls_prob, const
     // w.cand is free once the ranking is done: it receives the transposed diagonal blocks
     // mask + sweep (two passes when a probe over the first candidates can settle an image, nms.hip);
     // the sweep writes (batch_idx, box) rows straight into rois_padded and stops after `pitch` kept boxes
-    const bool one_pass = getenv("WSSDL_NMS_ONE_PASS") != nullptr;       // tuning / A-B comparisons
+    const bool one_pass = tuning().nms_one_pass != 0;       // tuning / A-B comparisons
     if ((rc = launch_nms_two_pass(w.sorted_boxes, topn * 4, nsorted, topn, N, nms_thresh, w.mask, w.cand, w.summ, pitch,
                                   nullptr, 0, nullptr, roi_counts, rois_padded, pitch <= topn ? w.kept : nullptr,
                                   one_pass ? nullptr : w.done, st)))

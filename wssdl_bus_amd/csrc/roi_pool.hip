@@ -581,8 +581,8 @@ extern "C" int wssdl_roi_pool_backward(const float *top_diff, const int32_t *arg
     int cg = C > 128 ? 256 : (C > 64 ? 128 : 64);
     const long long tiles = (long long)cdiv(H, 4) * cdiv(W, 8);       // counted in 4x8 tiles
     while (cg > 64 && (long long)N * cdiv(C, cg) * tiles < BWD_MIN_WORKGROUPS) cg >>= 1;
-    if (const char *e = getenv("WSSDL_ROI_BWD_CG")) {       // tuning override
-        const int v = atoi(e);
+    {       // tuning override
+        const int v = tuning().roi_bwd_cg;
         if (v == 64 || v == 128 || v == 256) cg = v;
     }
     if (cg == 256)

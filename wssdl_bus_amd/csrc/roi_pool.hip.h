@@ -93,6 +93,8 @@ __device__ __forceinline__ void touch_axis(int t0, int t1, int rs, int re, float
 
 
 // list-driven backward of the training path (roi_pool_walk.hip)
+int walk_plan_count();
+size_t walk_flags_offset(int R, int N, int H, int W, int PH, int PW);
 bool walk_supported(int R, int N, int H, int W, int C, int PH, int PW);
 size_t walk_workspace_bytes(int R, int N, int H, int W, int PH, int PW);
 int walk_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, int PW, float scale, int rounding,

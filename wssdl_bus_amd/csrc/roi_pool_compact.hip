@@ -30,44 +30,7 @@
 //           division by W or C as with the flat index).
 #include "roi_pool.hip.h"
 
-#include <stdlib.h>
-
 namespace wssdl {
-
-// tuning builds only (-DWSSDL_BWDC_ABLATE=n via WSSDL_HIPCC_EXTRA): 1 = walk without loads,
-// 2 = loads without decode / accumulation, 3 = filter phase only, 4 = no LDS accumulation
-#ifndef WSSDL_BWDC_ABLATE
-#define WSSDL_BWDC_ABLATE 0
-#endif
-
-// tuning builds only: -DWSSDL_FWDC_ABLATE=1 forward without its stores, =2 without its loads,
-// =3 stores only (row-loop kernel), =4 loads + one v_max per value (no arg-max tracking),
-// =5 neither loads nor stores
-#ifndef WSSDL_FWDC_ABLATE
-#define WSSDL_FWDC_ABLATE 0
-#endif
-#define WSSDL_FWDC_NOLOAD (WSSDL_FWDC_ABLATE == 2 || WSSDL_FWDC_ABLATE == 5)
-#define WSSDL_FWDC_NOSTORE (WSSDL_FWDC_ABLATE == 1 || WSSDL_FWDC_ABLATE == 5)
-
-// tuning builds only (-DWSSDL_BWDC_TRACE=1): every workgroup of the backward records
-// (start, end) of s_memrealtime (100 MHz) and its record / bin counts into a buffer set with
-// wssdl_debug_set_trace (tools/bwd_trace.py)
-#ifndef WSSDL_BWDC_TRACE
-#define WSSDL_BWDC_TRACE 0
-#endif
-#if WSSDL_BWDC_TRACE
-extern unsigned long long *g_walk_trace;
-static unsigned long long *g_trace = nullptr;
-extern "C" __attribute__((visibility("default"))) void wssdl_debug_set_trace(void *p) {
-    g_trace = static_cast<unsigned long long *>(p);
-    g_walk_trace = g_trace;
-}
-#define WSSDL_TRACE_PARAM , unsigned long long *__restrict__ trace
-#define WSSDL_TRACE_ARG , g_trace
-#else
-#define WSSDL_TRACE_PARAM
-#define WSSDL_TRACE_ARG
-#endif
 
 constexpr unsigned ARG8_EMPTY = 0xffu;
 constexpr int ARG8_MAX_WIN_H = 15;    // dh <= 14: the code 0xff = (15, 15) can never be produced
@@ -129,11 +92,7 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_compact_kernel(
                     for (int j = 0; j < BATCH; ++j) {
                         const int wj = min(w + j, we - 1);
                         code[j] = rcode | (unsigned)(wj - ws);
-#if WSSDL_FWDC_ABLATE == 2
-                        v[j] = (float4v)((float)(wj + h));
-#else
                         v[j] = *reinterpret_cast<const float4v *>(img + row_base + wj * C);
-#endif
                     }
 #pragma unroll
                     for (int j = 0; j < BATCH; ++j) {
@@ -145,12 +104,8 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_compact_kernel(
                 }
             }
         }
-#if WSSDL_FWDC_ABLATE == 1
-        if (mv.x == 12345.678f && m0 == 77u) top[o] = mv.y + mv.z + mv.w + (float)(m1 + m2 + m3);
-#else
         __builtin_nontemporal_store(mv, reinterpret_cast<float4v *>(top + o));
         __builtin_nontemporal_store(m0 | (m1 << 8) | (m2 << 16) | (m3 << 24), arg8 + (o >> 2));
-#endif
     }
 }
 
@@ -204,11 +159,7 @@ template <>
 struct LaneVec<4> {
     typedef float4v vec;
     static __device__ __forceinline__ vec load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-#if WSSDL_FWDC_NOLOAD
-        return (vec)((float)(soff & 1023));
-#else
         return __builtin_bit_cast(vec, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-#endif
     }
 };
 typedef float float2w __attribute__((ext_vector_type(2)));
@@ -308,9 +259,6 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
         const bool empty = row_dead || (we <= ws);
 #pragma unroll
         for (int k = 0; k < CPL; ++k) { mv[k] = empty ? 0.0f : -FLT_MAX;  mi[k] = ARG8_EMPTY; }
-#if WSSDL_FWDC_ABLATE == 3
-        if (true) return;
-#endif
         if (empty) return;
         for (int h = hs; h < he; ++h) {
             const int so_row = h * W * cell_bytes;
@@ -320,37 +268,22 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
                 const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
                 const vec v1 = LaneVec<CPL>::load(rs, voff, so_row + (w + 1) * cell_bytes);
                 const unsigned code0 = rcode | (unsigned)(w - ws), code1 = code0 + 1u;
-#if WSSDL_FWDC_ABLATE == 4
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) { mv[k] = fmaxf(mv[k], fmaxf(v0[k], v1[k]));  mi[k] = code1; }
-#else
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) if (v0[k] > mv[k]) { mv[k] = v0[k];  mi[k] = code0; }
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) if (v1[k] > mv[k]) { mv[k] = v1[k];  mi[k] = code1; }
-#endif
             }
             if (w < we) {
                 const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
                 const unsigned code0 = rcode | (unsigned)(w - ws);
-#if WSSDL_FWDC_ABLATE == 4
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) { mv[k] = fmaxf(mv[k], v0[k]);  mi[k] = code0; }
-#else
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) if (v0[k] > mv[k]) { mv[k] = v0[k];  mi[k] = code0; }
-#endif
             }
         }
     };
     auto store_bin = [&](int pw, const vec &mv, unsigned codes) {
         const size_t o = o_row + (size_t)pw * C;
-#if WSSDL_FWDC_NOSTORE
-        if (mv[0] == 12345.678f && codes == 77u) top[o] = mv[1] + (float)codes;
-        if (false)
-#else
         if (lane_ok)
-#endif
         {
             __builtin_nontemporal_store(mv, reinterpret_cast<vec *>(top + o));
             if (CPL == 4) __builtin_nontemporal_store(codes, reinterpret_cast<unsigned *>(arg8 + o));
@@ -393,7 +326,6 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
 #pragma unroll
             for (int k = 0; k < CPL; ++k) if (v[k] > mv[k]) { mv[k] = v[k];  m[k] = code; }
         };
-#if WSSDL_FWDC_ABLATE != 3
         if (!row_dead) {
             for (int h = hs; h < he; ++h) {
                 const int so_row = h * W * cell_bytes;
@@ -423,7 +355,6 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
                 }
             }
         }
-#endif
 #pragma unroll
         for (int pw = 0; pw < PWS; ++pw) store_bin(pw, res[pw], pack(mi[pw]));
     } else {
@@ -497,13 +428,8 @@ __device__ __forceinline__ void visit_rows_c(const WalkCtxC &x, __amdgpu_buffer_
 #pragma unroll
         for (int j = 0; j < PWN; ++j) {
             const int bin = q * PW + j;
-#if WSSDL_BWDC_ABLATE == 1
-            a[q][j] = (unsigned)(x.tc * 7 + bin + so8) & 0x33u;
-            td[q][j] = 1.0f;
-#else
             a[q][j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(ra, x.voff8, so8 + bin * C, 0);
             td[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, x.voff, so + bin * C * 4, 0));
-#endif
         }
     // keep every loaded value live here: otherwise the compiler sinks the top_diff loads into
     // the (rare) hit branch and serialises them
@@ -511,9 +437,6 @@ __device__ __forceinline__ void visit_rows_c(const WalkCtxC &x, __amdgpu_buffer_
     for (int q = 0; q < NROWS; ++q)
 #pragma unroll
         for (int j = 0; j < PWN; ++j) asm volatile("" : "+v"(a[q][j]), "+v"(td[q][j]));
-#if WSSDL_BWDC_ABLATE == 2
-    return;
-#endif
 #pragma unroll
     for (int q = 0; q < NROWS; ++q) {
         const int sh4 = 4 * (row0 + q), sh8 = 8 * (row0 + q);
@@ -529,15 +452,10 @@ __device__ __forceinline__ void visit_rows_c(const WalkCtxC &x, __amdgpu_buffer_
             // outside the tile would index (th, tw in [-16, 30]; shifts use the low 5 bits)
             const unsigned bits = (rm >> (th & 31)) & (cmk >> (tw & 31)) & 1u;
             const bool ok = (bits != 0u) & (code != ARG8_EMPTY) & x.lane_ok;
-#if WSSDL_BWDC_ABLATE == 4
-            float v = ok ? td[q][j] : 0.0f;
-            asm volatile("" :: "v"(v), "v"(th * TW + tw));
-#else
             if (ok) {
                 float *p = &x.acc[(th * TW + tw) * CG + x.tc];
                 *p = *p + td[q][j];
             }
-#endif
         }
     }
 }
@@ -564,12 +482,8 @@ template <int TH, int TW, int CG, int CHUNK, int MAXB, int MINB>
 __global__ __launch_bounds__(CG, MINB) void roi_pool_bwd_compact_kernel(
     const float *__restrict__ top_diff, const unsigned char *__restrict__ arg8,
     const float *__restrict__ rois, int R, int N, int H, int W, int C, int PH, int PW, float scale,
-    int rounding, float *__restrict__ bottom_diff, int tiles_h, int tiles_w, int cgroups WSSDL_TRACE_PARAM) {
+    int rounding, float *__restrict__ bottom_diff, int tiles_h, int tiles_w, int cgroups) {
     static_assert(TH <= 4 && TW <= 8, "4 mask bits per candidate bin row, 8 per column");
-#if WSSDL_BWDC_TRACE
-    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-    unsigned long long n_rec = 0, n_bins = 0;
-#endif
     static_assert(CHUNK <= 256, "8-bit RoI index inside a filter round");
     static_assert(CHUNK % CG == 0 || CHUNK < CG, "whole filter rounds");
     constexpr int KPT = CHUNK >= CG ? CHUNK / CG : 1;   // RoIs tested per thread per filter round
@@ -678,9 +592,6 @@ __global__ __launch_bounds__(CG, MINB) void roi_pool_bwd_compact_kernel(
 
         // ---- walk the touching RoIs in order; every lane = one channel, so per element the f32
         // additions happen in the reference's order (roi^, ph^, pw^).  The record is wave-uniform.
-#if WSSDL_BWDC_ABLATE == 3
-        cnt = 0;
-#endif
         for (int i = 0; i < cnt; ++i) {
             const unsigned geo = (unsigned)__builtin_amdgcn_readfirstlane((int)list[i].geo);
             const int r = base + (int)(geo >> 24);
@@ -688,10 +599,6 @@ __global__ __launch_bounds__(CG, MINB) void roi_pool_bwd_compact_kernel(
             const int phn = (geo >> 16) & 0xf, pwn = (geo >> 20) & 0xf;
             const size_t rbin0 = (size_t)r * PH * PW;
             if (phn == 0) continue;
-#if WSSDL_BWDC_TRACE
-            n_rec += 1;
-            n_bins += (unsigned)(phn * pwn);
-#endif
             if (phn != (int)TOUCH_GENERIC) {
 #define WSSDL_RFL64(v) (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((v) >> 32)) << 32) | \
                         (unsigned)__builtin_amdgcn_readfirstlane((int)(v)))
@@ -760,12 +667,6 @@ __global__ __launch_bounds__(CG, MINB) void roi_pool_bwd_compact_kernel(
             if (h < H && w < W) img[((size_t)h * W + w) * C + c] = acc[i * CG + tc];
         }
     }
-#if WSSDL_BWDC_TRACE
-    if (trace && tc == 0) {
-        unsigned long long *t = trace + (size_t)blockIdx.x * 4;
-        t[0] = t_start;  t[1] = __builtin_amdgcn_s_memrealtime();  t[2] = n_rec;  t[3] = n_bins;
-    }
-#endif
 }
 
 template <int TH, int TW, int CG, int CHUNK, int MAXB = 8, int MINB = 1>
@@ -778,7 +679,7 @@ static int launch_bwd_c(const float *top_diff, const unsigned char *arg8, const 
     if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL((roi_pool_bwd_compact_kernel<TH, TW, CG, CHUNK, MAXB, MINB>), dim3((unsigned)blocks),
                        dim3(CG), 0, st, top_diff, arg8, rois, R, N, H, W, C, PH, PW, scale, rounding,
-                       bottom_diff, tiles_h, tiles_w, cgroups WSSDL_TRACE_ARG);
+                       bottom_diff, tiles_h, tiles_w, cgroups);
     return check_launch();
 }
 
@@ -863,8 +764,7 @@ static int forward_compact(const float *bottom, int N, int H, int W, int C, cons
     const long long row_blocks = ((long long)R * pooled_h + rows_per_block - 1) / rows_per_block;
     if (row_blocks * 8 > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
     unsigned *a8 = reinterpret_cast<unsigned *>(argmax8);
-    int variant = 0;
-    if (const char *e = getenv("WSSDL_ROI_FWD_VARIANT")) variant = atoi(e);      // tuning
+    int variant = tuning().roi_fwd_variant;
     if (table) variant = 0;
     // wave-uniform kernel, 256 (or 128) channels per wave.  Variants: 0 = automatic, 1 = one bin row per
     // wave with a store per bin, 2 = 128-channel waves, 3 = 7 one-row waves per workgroup, 4 = one bin
@@ -943,6 +843,12 @@ extern "C" size_t wssdl_roi_pool_backward_workspace_bytes(int R, int N, int H, i
     return walk_workspace_bytes(R, N, H, W, pooled_h, pooled_w);
 }
 
+extern "C" int wssdl_roi_pool_backward_plan_count(void) { return walk_plan_count(); }
+
+extern "C" size_t wssdl_roi_pool_backward_status_offset(int R, int N, int H, int W, int pooled_h, int pooled_w) {
+    return walk_flags_offset(R, N, H, W, pooled_h, pooled_w);
+}
+
 extern "C" int wssdl_roi_pool_backward_prepare(const float *rois, int R, int N, int H, int W, int C,
                                                int pooled_h, int pooled_w, float spatial_scale,
                                                int rounding, void *workspace, size_t workspace_bytes,
@@ -977,15 +883,14 @@ extern "C" int wssdl_roi_pool_backward_compact(const float *top_diff, const uint
         return launch_walk(top_diff, argmax8, R, N, H, W, C, pooled_h, pooled_w, bottom_diff, workspace,
                            workspace_bytes, plan, st);
     }
-    int variant = 0;
-    if (const char *e = getenv("WSSDL_ROI_BWDC_VARIANT")) variant = atoi(e);      // tuning: fallback kernel shapes
+    const int variant = tuning().roi_bwdc_variant;      // tuning: fallback kernel shapes
     // fallback: tile-owner kernel with the RoI filter inside (no workspace; any pooled size)
     // channels per workgroup: 256 when that still yields enough workgroups to fill the chip
     int cg = C > 128 ? 256 : (C > 64 ? 128 : 64);
     const long long tiles = (long long)cdiv(H, 4) * cdiv(W, 8);       // counted in 4x8 tiles
     while (cg > 64 && (long long)N * cdiv(C, cg) * tiles < BWD_MIN_WORKGROUPS) cg >>= 1;
-    if (const char *e = getenv("WSSDL_ROI_BWD_CG")) {       // tuning overrides
-        const int v = atoi(e);
+    {       // tuning override
+        const int v = tuning().roi_bwd_cg;
         if (v == 64 || v == 128 || v == 256) cg = v;
     }
 #define WSSDL_BWDC(TH, TW, CGV, CHUNK, MAXB, MINB) \

@@ -31,15 +31,16 @@
 //               only writer of its channels: the f32 additions run in exactly the reference's order.
 // The lists are shared by all channel groups, the walk needs no barrier at all, and no workgroup
 // repeats the RoI filter.
+//
+// Round 3, measured and NOT kept ("gangs"): walking GH x GW neighbouring tiles in one
+// workgroup so that the border bins they share are fetched once.  Co-scheduling alone left the L2 hit
+// rate where it was (13 %); pacing the waves of a gang by RoI segment (barrier or a sliding window)
+// brought the fetched bytes from 3.08 to 2.65-2.75 GB but cost more time than it saved (0.57-1.2 ms
+// against 0.51): lock-step waves cannot keep enough loads in flight, and 8-wave workgroups quantise
+// the launch.  The free-running walk below stays.
 #include "roi_pool.hip.h"
 
-#include <stdlib.h>
-
 namespace wssdl {
-
-#ifndef WSSDL_BWDC_TRACE
-#define WSSDL_BWDC_TRACE 0
-#endif
 
 constexpr unsigned ARG8_EMPTY_W = 0xffu;
 constexpr int WALK_SLOTS = 8;            // slots per record (64 B)
@@ -405,26 +406,14 @@ __device__ __forceinline__ void process_rec(const SlotData<CPL> &d, const SlotRe
     }
 }
 
-#if WSSDL_BWDC_TRACE
-unsigned long long *g_walk_trace = nullptr;
-#define WSSDL_WALK_TRACE_PARAM , unsigned long long *__restrict__ trace
-#define WSSDL_WALK_TRACE_ARG , g_walk_trace
-#else
-#define WSSDL_WALK_TRACE_PARAM
-#define WSSDL_WALK_TRACE_ARG
-#endif
-
 template <int TH, int TW, int DEPTH, int MINW, int CPL>
 __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
     const float *__restrict__ top_diff, const unsigned char *__restrict__ arg8,
     const unsigned *__restrict__ slots, const int *__restrict__ tile_off, const int *__restrict__ tile_slots,
     const int *__restrict__ order, int items, int tiles_w, int tiles, int G, int H, int W, int C,
-    unsigned total_elems, float *__restrict__ bottom_diff WSSDL_WALK_TRACE_PARAM) {
+    unsigned total_elems, float *__restrict__ bottom_diff) {
     static_assert(TH <= 8 && TW <= 8 && DEPTH >= 2 && DEPTH <= 4, "8-bit masks; 2..4 records in flight");
     __shared__ float acc[(TH * TW + 1) * CPL * 64];
-#if WSSDL_BWDC_TRACE
-    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-#endif
     // blockIdx -> (position k in the launch order, channel group g).  Workgroups are dealt
     // round-robin over the 8 XCDs (blockIdx % 8; observed, speed only): with 8 or more channel
     // groups every XCD serves its own groups for all tiles, so the border bins neighbouring tiles
@@ -479,7 +468,6 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
     for (int i = 0; i < nrec; i += DEPTH) {
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
-            constexpr int dummy = 0;  (void)dummy;
             const int x = (j + DEPTH - 1) % DEPTH;
             const unsigned next = fetch_rec(rp, i + j + DEPTH, nrec, lane);
             r[x] = spread_rec(pending, i + j + DEPTH - 1 < nrec, total_elems);
@@ -506,47 +494,75 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
             }
         }
     }
-#if WSSDL_BWDC_TRACE
-    if (trace && lane == 0) {
-        unsigned long long *t = trace + (size_t)blockIdx.x * 4;
-        t[0] = t_start;  t[1] = __builtin_amdgcn_s_memrealtime();  t[2] = (unsigned long long)nrec;
-        t[3] = (unsigned long long)tile_slots[item];
-    }
-#endif
 }
 
-// A plan = tile shape, records in flight and the waves per SIMD the launch bounds ask for.
-// WSSDL_ROI_BWD_PLAN (tuning) overrides the choice below.
-constexpr int WALK_PLANS = 21;
+// A plan = tile shape, records in flight, the waves per SIMD the launch bounds ask for and the
+// channels per lane.  wssdl_set_tuning("roi_bwd_plan", id) overrides the choice of walk_plan_auto.
+struct WalkPlan {
+    int th, tw, depth, minw, cpl;
+};
+
+#define WSSDL_WALK_PLANS(X) \
+    X(0, 4, 4, 2, 5, 2)  \
+    X(1, 4, 8, 2, 2, 2)  \
+    X(2, 8, 8, 3, 1, 2)  \
+    X(3, 4, 8, 3, 2, 2)  \
+    X(4, 8, 8, 4, 1, 2)  \
+    X(5, 4, 4, 3, 4, 2)  \
+    X(6, 8, 8, 4, 2, 1)  /* one channel per lane: 8x8 tiles at 4x8's LDS */ \
+    X(7, 8, 8, 3, 2, 1)  \
+    X(8, 8, 8, 2, 2, 1)  \
+    X(9, 6, 8, 2, 1, 2)  /* fewer border re-reads (1.52 against 1.68), 6 waves per CU */ \
+    X(10, 5, 8, 2, 1, 2) /* 1.58, 7 waves per CU */ \
+    X(11, 6, 6, 2, 2, 2) /* 1.60, 8 waves per CU */ \
+    X(12, 6, 8, 3, 1, 2) \
+    X(13, 6, 6, 3, 2, 2) \
+    X(14, 6, 7, 2, 1, 2) \
+    X(15, 7, 6, 2, 1, 2) \
+    X(16, 5, 7, 2, 2, 2) \
+    X(17, 7, 7, 2, 1, 2) \
+    X(18, 2, 4, 3, 4, 2) /* small launches: short slot chains per wave */ \
+    X(19, 2, 2, 3, 4, 2) \
+    X(20, 3, 4, 3, 4, 2) \
+    X(21, 2, 2, 3, 4, 1) /* small launches, 64-channel waves: twice the waves */ \
+    X(22, 2, 4, 3, 4, 1) \
+    X(23, 4, 4, 3, 4, 1) \
+    X(24, 3, 4, 3, 4, 1) \
+    X(25, 6, 6, 3, 4, 1)
+
+static const WalkPlan kWalkPlans[] = {
+#define WSSDL_X(ID, TH, TW, D, MW, CPL) {TH, TW, D, MW, CPL},
+    WSSDL_WALK_PLANS(WSSDL_X)
+#undef WSSDL_X
+};
+constexpr int WALK_PLANS = sizeof(kWalkPlans) / sizeof(kWalkPlans[0]);
+
+int walk_plan_count() { return WALK_PLANS; }
 
 // The tile shape trades border re-reads (large tiles: fewer bytes) against the length of the slot
 // chain one wave walks alone (small tiles: more, shorter chains).  A train-sized launch is
 // bandwidth-bound and wants 6x6; a launch with few waves (few images or channel groups) is bound by
 // its longest chain: 2 images x 256 channels x 4000 RoIs take 0.44 ms with 6x6 tiles, 0.24 with 4x4,
-// 0.12 with 2x2 (tools/bwd_plan_sweep.py).  Rule: the largest of 6x6, 4x4, 2x4, 2x2 that still gives
-// 2048 waves (one per wave slot of the chip at 8 per CU).
+// 0.12 with 2x2 (tools/bwd_plan_sweep.py).  Rule: the largest of 6x6, 4x4, 2x4, 2x2 with 128-channel
+// waves that still gives 2048 waves (one per wave slot of the chip at 8 per CU); a launch that falls
+// short of that even then halves the channels per wave (64-channel plans: twice the waves, each
+// chain as long but half as wide).
 static int walk_plan_auto(int N, int H, int W, int C) {
     static const int cand[4][3] = {{6, 6, 11}, {4, 4, 5}, {2, 4, 18}, {2, 2, 19}};
     const long long G = cdiv(C, 128);
     for (int i = 0; i < 4; ++i)
         if ((long long)N * cdiv(H, cand[i][0]) * cdiv(W, cand[i][1]) * G >= 2048) return cand[i][2];
-    return cand[3][2];
+    static const int cand64[3][3] = {{4, 4, 23}, {2, 4, 22}, {2, 2, 21}};
+    const long long G64 = cdiv(C, 64);
+    for (int i = 0; i < 3; ++i)
+        if ((long long)N * cdiv(H, cand64[i][0]) * cdiv(W, cand64[i][1]) * G64 >= 2048) return cand64[i][2];
+    return cand64[2][2];
 }
 
-static int walk_plan_from_env(int N, int H, int W, int C) {
-    if (const char *e = getenv("WSSDL_ROI_BWD_PLAN")) {
-        const int v = atoi(e);
-        if (e[0] >= '0' && e[0] <= '9' && v >= 0 && v < WALK_PLANS) return v;
-    }
+static int walk_plan_choice(int N, int H, int W, int C) {
+    const int v = tuning().roi_bwd_plan;
+    if (v >= 0 && v < WALK_PLANS) return v;
     return walk_plan_auto(N, H, W, C);
-}
-
-static void plan_shape(int plan, int *th, int *tw) {
-    static const int shapes[WALK_PLANS][2] = {{4, 4}, {4, 8}, {8, 8}, {4, 8}, {8, 8}, {4, 4}, {8, 8}, {8, 8}, {8, 8},
-                                              {6, 8}, {5, 8}, {6, 6}, {6, 8}, {6, 6}, {6, 7}, {7, 6}, {5, 7}, {7, 7},
-                                              {2, 4}, {2, 2}, {3, 4}};
-    *th = shapes[plan][0];
-    *tw = shapes[plan][1];
 }
 
 bool walk_supported(int R, int N, int H, int W, int C, int PH, int PW) {
@@ -558,6 +574,12 @@ bool walk_supported(int R, int N, int H, int W, int C, int PH, int PW) {
 size_t walk_workspace_bytes(int R, int N, int H, int W, int PH, int PW) {
     // sized for the smallest tiles (most records), so that every plan fits
     return carve_walk(nullptr, R, N, cdiv(H, 2), cdiv(W, 2), walk_record_bound(R, N, H, W, PH, PW, 2, 2), nullptr);
+}
+
+size_t walk_flags_offset(int R, int N, int H, int W, int PH, int PW) {
+    WalkWs ws;
+    carve_walk(reinterpret_cast<void *>(0x1000), R, N, 1, 1, 0, &ws);       // the head of the carving does not depend on the plan
+    return (size_t)(reinterpret_cast<char *>(ws.total) - reinterpret_cast<char *>(0x1000));
 }
 
 template <int TH, int TW>
@@ -589,24 +611,15 @@ static int prepare_t(const float *rois, int R, int N, int H, int W, int C, int P
 
 int walk_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, int PW, float scale, int rounding,
                  void *workspace, size_t workspace_bytes, int *plan_out, hipStream_t st) {
-    const int plan = walk_plan_from_env(N, H, W, C);
-    int th, tw;
-    plan_shape(plan, &th, &tw);
-    int rc;
-#define WSSDL_PREP(TH, TW) prepare_t<TH, TW>(rois, R, N, H, W, C, PH, PW, scale, rounding, workspace, workspace_bytes, st)
-    if (th == 4 && tw == 4) rc = WSSDL_PREP(4, 4);
-    else if (th == 4) rc = WSSDL_PREP(4, 8);
-    else if (th == 6 && tw == 8) rc = WSSDL_PREP(6, 8);
-    else if (th == 5 && tw == 8) rc = WSSDL_PREP(5, 8);
-    else if (th == 6 && tw == 6) rc = WSSDL_PREP(6, 6);
-    else if (th == 6 && tw == 7) rc = WSSDL_PREP(6, 7);
-    else if (th == 7 && tw == 6) rc = WSSDL_PREP(7, 6);
-    else if (th == 5 && tw == 7) rc = WSSDL_PREP(5, 7);
-    else if (th == 7 && tw == 7) rc = WSSDL_PREP(7, 7);
-    else if (th == 2 && tw == 4) rc = WSSDL_PREP(2, 4);
-    else if (th == 2 && tw == 2) rc = WSSDL_PREP(2, 2);
-    else if (th == 3 && tw == 4) rc = WSSDL_PREP(3, 4);
-    else rc = WSSDL_PREP(8, 8);
+    const int plan = walk_plan_choice(N, H, W, C);
+    const WalkPlan &p = kWalkPlans[plan];
+    int rc = WSSDL_ERR_INVALID_ARGUMENT;
+#define WSSDL_PREP(TH, TW) \
+    if (p.th == TH && p.tw == TW) \
+        rc = prepare_t<TH, TW>(rois, R, N, H, W, C, PH, PW, scale, rounding, workspace, workspace_bytes, st);
+    WSSDL_PREP(2, 2) WSSDL_PREP(2, 4) WSSDL_PREP(3, 4) WSSDL_PREP(4, 4) WSSDL_PREP(4, 8) WSSDL_PREP(5, 7)
+    WSSDL_PREP(5, 8) WSSDL_PREP(6, 6) WSSDL_PREP(6, 7) WSSDL_PREP(6, 8) WSSDL_PREP(7, 6) WSSDL_PREP(7, 7)
+    WSSDL_PREP(8, 8)
 #undef WSSDL_PREP
     if (rc == WSSDL_OK && plan_out) *plan_out = plan;
     return rc;
@@ -630,40 +643,20 @@ static int launch_walk_t(const float *top_diff, const unsigned char *arg8, int R
     if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<TH, TW, DEPTH, MINW, CPL>), dim3((unsigned)blocks), dim3(64), 0, st,
                        top_diff, arg8, reinterpret_cast<const unsigned *>(ws.slots), ws.tile_off, ws.tile_slots,
-                       ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff WSSDL_WALK_TRACE_ARG);
+                       ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff);
     return check_launch();
 }
 
 int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH,
                 int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, hipStream_t st) {
-#define WSSDL_WALK(TH, TW, DEPTH, MINW, CPL) \
-    launch_walk_t<TH, TW, DEPTH, MINW, CPL>(top_diff, arg8, R, N, H, W, C, PH, PW, bottom_diff, workspace, \
-                                            workspace_bytes, st)
     switch (plan) {
-        case 0: return WSSDL_WALK(4, 4, 2, 5, 2);
-        case 1: return WSSDL_WALK(4, 8, 2, 2, 2);
-        case 2: return WSSDL_WALK(8, 8, 3, 1, 2);
-        case 3: return WSSDL_WALK(4, 8, 3, 2, 2);
-        case 4: return WSSDL_WALK(8, 8, 4, 1, 2);
-        case 5: return WSSDL_WALK(4, 4, 3, 4, 2);
-        case 6: return WSSDL_WALK(8, 8, 4, 2, 1);       // one channel per lane: 8x8 tiles at 4x8's LDS
-        case 7: return WSSDL_WALK(8, 8, 3, 2, 1);
-        case 8: return WSSDL_WALK(8, 8, 2, 2, 1);
-        case 9: return WSSDL_WALK(6, 8, 2, 1, 2);       // fewer border re-reads (1.52 against 1.68), 6 waves per CU
-        case 10: return WSSDL_WALK(5, 8, 2, 1, 2);      // 1.58, 7 waves per CU
-        case 11: return WSSDL_WALK(6, 6, 2, 2, 2);      // 1.60, 8 waves per CU
-        case 12: return WSSDL_WALK(6, 8, 3, 1, 2);
-        case 13: return WSSDL_WALK(6, 6, 3, 2, 2);
-        case 14: return WSSDL_WALK(6, 7, 2, 1, 2);
-        case 15: return WSSDL_WALK(7, 6, 2, 1, 2);
-        case 16: return WSSDL_WALK(5, 7, 2, 2, 2);
-        case 17: return WSSDL_WALK(7, 7, 2, 1, 2);
-        case 18: return WSSDL_WALK(2, 4, 3, 4, 2);      // small launches: short slot chains per wave
-        case 19: return WSSDL_WALK(2, 2, 3, 4, 2);
-        case 20: return WSSDL_WALK(3, 4, 3, 4, 2);
+#define WSSDL_X(ID, TH, TW, D, MW, CPL) \
+        case ID: return launch_walk_t<TH, TW, D, MW, CPL>(top_diff, arg8, R, N, H, W, C, PH, PW, bottom_diff, workspace, \
+                                                         workspace_bytes, st);
+        WSSDL_WALK_PLANS(WSSDL_X)
+#undef WSSDL_X
         default: return WSSDL_ERR_INVALID_ARGUMENT;
     }
-#undef WSSDL_WALK
 }
 
 }  // namespace wssdl

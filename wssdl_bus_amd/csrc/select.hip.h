@@ -28,10 +28,6 @@ struct SelectScratch {
 
 __device__ __forceinline__ void select_hist_add(int *hist, bool valid, int digit) {
     // wave-aggregated histogram update
-#if WSSDL_SELECT_PLAIN_ATOMICS
-    if (valid) atomicAdd(&hist[digit], 1);
-    return;
-#endif
     unsigned long long active = __ballot(valid);
     const int lane = threadIdx.x & 63;
 #pragma unroll 1

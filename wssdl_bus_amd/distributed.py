@@ -68,6 +68,7 @@ class DistContext(object):
             handles.append(self._launch(bucket))
         for h in handles:
             self._write_back(*h)
+        self.poll_patterns()
 
     _flag_cache = {}
 
@@ -88,16 +89,36 @@ class DistContext(object):
         parts.append(self._flags(had, ps[0]))
         flat = torch.cat(parts)
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-        return flat, work, list(ps)
+        return flat, work, list(ps), tuple(had)
 
-    def _write_back(self, flat, work, ps):
+    # Which parameters of a bucket had a gradient on ANY rank decides `grad = None`, a host decision.
+    # All ranks run the same kind of step (combined / supervised / weak) in lock-step, so that pattern
+    # is a function of the local has-grad pattern: it is read back ONCE per (bucket, local pattern) --
+    # the first step of each kind -- and cached.  Later steps compare the reduced flags with the cached
+    # pattern ON THE DEVICE and add the differences to a counter that poll_patterns() looks at without
+    # synchronising (the copy of the previous poll, once its event has completed): a rank whose
+    # pattern ever departs raises one step later instead of training on.
+    _any_cache = {}
+
+    def _write_back(self, flat, work, ps, had=None):
         work.wait()
-        any_grad = flat[flat.numel() - len(ps):].cpu().tolist()    # tiny; after the wait anyway
+        flags = flat[flat.numel() - len(ps):]
+        key = (tuple(id(p) for p in ps), had)
+        any_grad = DistContext._any_cache.get(key) if had is not None else None
+        if any_grad is None:
+            any_grad = tuple(a > 0 for a in flags.cpu().tolist())     # first step of this kind only
+            if had is not None:
+                DistContext._any_cache[key] = any_grad
+        else:
+            diff = ((flags > 0).to(flat.dtype) - self._flags(any_grad, flat)).abs().sum()
+            if getattr(self, "_mismatch", None) is None:
+                self._mismatch = torch.zeros((), dtype=flat.dtype, device=flat.device)
+            self._mismatch.add_(diff)
         flat.div_(self.world_size)
         off = 0
         for p, a in zip(ps, any_grad):
             n = p.numel()
-            if a > 0:
+            if a:
                 g = flat[off:off + n].view_as(p)
                 if p.grad is None:
                     p.grad = g.clone()
@@ -106,6 +127,28 @@ class DistContext(object):
             else:
                 p.grad = None
             off += n
+
+    def poll_patterns(self):
+        """Sync-free look at the has-grad mismatch counter (see _write_back)."""
+        m = getattr(self, "_mismatch", None)
+        if m is None:
+            return
+        ev = getattr(self, "_mismatch_event", None)
+        if ev is not None and (not m.is_cuda or ev.query()):
+            self._mismatch_event = None
+            if float(self._mismatch_host) != 0.0:
+                raise RuntimeError("data-parallel has-grad pattern changed between steps of one kind: "
+                                   "ranks disagree on which parameters received a gradient")
+        if getattr(self, "_mismatch_event", None) is None:
+            if m.is_cuda:
+                if getattr(self, "_mismatch_host", None) is None:
+                    self._mismatch_host = torch.zeros((), dtype=m.dtype).pin_memory()
+                self._mismatch_host.copy_(m, non_blocking=True)
+                self._mismatch_event = torch.cuda.Event()
+                self._mismatch_event.record()
+            else:
+                self._mismatch_host = m.clone()
+                self._mismatch_event = True
 
     def overlap(self, params):
         """Bucketed all-reduce overlapped with backward: see GradOverlap."""
@@ -186,8 +229,8 @@ class GradOverlap(object):
             self.next_to_launch += 1
 
     def _launch(self, b):
-        flat, work, _ = self.ctx._launch(self.buckets[b])
-        self.launched[b] = (flat, work)
+        flat, work, _, had = self.ctx._launch(self.buckets[b])
+        self.launched[b] = (flat, work, had)
 
     def finish(self):
         """Call after backward, before optimizer.step()."""
@@ -196,8 +239,9 @@ class GradOverlap(object):
         for b in range(self.next_to_launch, len(self.buckets)):
             self._launch(b)
         for b, ps in enumerate(self.buckets):
-            flat, work = self.launched[b]
-            self.ctx._write_back(flat, work, ps)
+            flat, work, had = self.launched[b]
+            self.ctx._write_back(flat, work, ps, had)
+        self.ctx.poll_patterns()
         self._reset()
 
     def remove(self):

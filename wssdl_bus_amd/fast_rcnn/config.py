@@ -82,6 +82,11 @@ __C.ROI_POOL_ROUNDING = "cuda"
 # training path: the autograd pair hands a 1-byte arg-max from RoiPool to RoiPoolGrad when the
 # library supports the shape (include/wssdl_bus_hip.h); False = the reference's i32 layout
 __C.ROI_POOL_COMPACT_ARGMAX = True
+# how the compact pair's device-side error flags (a RoI whose bin windows the 1-byte code cannot describe;
+# backward lists that do not fit) are consumed: 'deferred' = no read-back, the train step polls them
+# before every optimiser step and raises (roi_pooling_op.poll_flags); 'eager' = RoiPoolFunction reads
+# the forward flag after every call and re-runs an overflowing call on the i32 pair, which takes any RoI
+__C.ROI_POOL_FLAG_CHECK = "deferred"
 # True: the proposal layer hands out a fixed-shape blob [N * post_nms_topN, 5] (unused rows carry batch
 # index -1) and nothing between the backbone and the loss copies to the host: the hot path can be
 # captured in a hipGraph.  The per-RoI head then runs on the padded row count (batch-norm masked to the

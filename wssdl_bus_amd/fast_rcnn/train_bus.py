@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from ..mil import core as mil_core
+from ..roi_pooling_layer import roi_pooling_op
 from .config import cfg
 
 
@@ -148,8 +149,12 @@ class SolverWrapper(object):
         self.optimizer_ws = None                  # created by the first alternating iteration
         self.global_step = 0
         self.dist = dist_ctx
-        if dist_ctx is not None:                 # seed per rank = RNG_SEED + rank,
-            cfg.DEVICE_RNG_SEED = dist_ctx.seed(cfg.RNG_SEED)   # for the device samplers too
+        if dist_ctx is not None and dist_ctx.enabled:
+            # seed per rank = seed + rank, for the device samplers too; a single
+            # process keeps the DEVICE_RNG_SEED its caller set
+            if getattr(dist_ctx, "_device_seed_base", None) is None:
+                dist_ctx._device_seed_base = int(cfg.DEVICE_RNG_SEED)      # a second solver on this context
+            cfg.DEVICE_RNG_SEED = dist_ctx.seed(dist_ctx._device_seed_base)   # does not add the rank again
         # data parallel: bucketed gradient all-reduce overlapped with backward
         self.overlap = dist_ctx.overlap(self.params) if (dist_ctx is not None and dist_ctx.enabled) else None
 
@@ -165,6 +170,7 @@ class SolverWrapper(object):
             self.overlap.finish()
         elif self.dist is not None:
             self.dist.allreduce_gradients(self.params)
+        roi_pooling_op.poll_flags()               # deferred error flags of the RoI-pool pair: no read-back
         (optimizer or self.optimizer).step()      # parameters whose grad is None are skipped,
         self.optimizer.zero_grad(set_to_none=True)  # like apply_gradients with a None gradient
         if count_step:

@@ -86,9 +86,10 @@ class Resnet_train_bus(nn.Module, Network):
                  .proposal_target_layer_joint(n_classes, is_training, name='roi-data'))
         (self.feed('group2/relu', 'roi-data')
              .roi_pool(7, 7, 1.0 / 16, name='roi_pool'))
-        if cfg.PADDED_ROIS and self.training:
-            # fixed-shape RoI blob: rows with batch index -1 are dead; the head's batch statistics
-            # are taken over the live rows only
+        if (cfg.PADDED_ROIS or cfg.SAMPLING_RNG == 'device') and self.training and not test_net:
+            # rows with batch index -1 are dead (padding of the fixed-shape RoI blob, or of a supervised
+            # image the device sampler found short of candidates): the head's batch statistics are taken
+            # over the live rows only, as if the blob had been compacted
             from . import roi_head
             rois_in = self.layers['roi-data'][0] if isinstance(self.layers['roi-data'], tuple) else self.layers['roi-data']
             roi_head.set_roi_mask((rois_in[:, 0] >= 0).to(torch.float32))

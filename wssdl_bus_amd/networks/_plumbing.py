@@ -38,6 +38,12 @@ def lib():
         L.wsplumb_rowbn_backward.restype = _i
         L.wsplumb_rowbn_backward.argtypes = [_vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
                                              _vp, _vp, _sz, _vp]
+        L.wsplumb_rowbn_forward_masked.restype = _i
+        L.wsplumb_rowbn_forward_masked.argtypes = [_vp, _ll, _i, _vp, _vp, _f, _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
+                                                   _vp, _vp, _vp, _vp, _sz, _vp]
+        L.wsplumb_rowbn_backward_masked.restype = _i
+        L.wsplumb_rowbn_backward_masked.argtypes = [_vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i,
+                                                    _vp, _vp, _vp, _vp, _vp, _sz, _vp]
         for name in ("wsplumb_im2col3x3", "wsplumb_col2im3x3"):
             f = getattr(L, name)
             f.restype = _i
@@ -69,20 +75,31 @@ def _workspace(L, M, C, dev):
     return torch.empty((n,), dtype=torch.uint8, device=dev), n
 
 
-def rowbn_forward(x, weight, bias, eps, relu):
+def rowbn_forward(x, weight, bias, eps, relu, mask=None):
+    """mask: [n_rois] f32 on x's device (0 = dead RoI), x = [n_rois * per, C]; returns (y, stats, count)
+    where count is None without a mask, else a [1] tensor holding the number of live rows."""
     L = lib()
     M, C = x.shape
     dev = x.device
     y = torch.empty_like(x)
     stats = torch.empty((5, C), dtype=torch.float32, device=dev)   # mean, var, rstd, scale, shift
+    count = None
     with torch.cuda.device(dev):
         ws, n = _workspace(L, M, C, dev)
-        rc = L.wsplumb_rowbn_forward(_p(x), M, C, _p(weight), _p(bias), float(eps), int(relu), _p(y),
-                                     _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
-                                     _p(stats[4]), _p(ws), n, _stream())
+        if mask is None:
+            rc = L.wsplumb_rowbn_forward(_p(x), M, C, _p(weight), _p(bias), float(eps), int(relu), _p(y),
+                                         _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
+                                         _p(stats[4]), _p(ws), n, _stream())
+        else:
+            n_rois = mask.shape[0]
+            assert M % n_rois == 0 and mask.dtype == torch.float32 and mask.is_contiguous()
+            count = torch.empty((1,), dtype=torch.float32, device=dev)
+            rc = L.wsplumb_rowbn_forward_masked(_p(x), M, C, _p(weight), _p(bias), float(eps), int(relu), _p(mask),
+                                                n_rois, M // n_rois, _p(y), _p(stats[0]), _p(stats[1]), _p(stats[2]),
+                                                _p(stats[3]), _p(stats[4]), _p(count), _p(ws), n, _stream())
     if rc:
         raise RuntimeError("wsplumb_rowbn_forward failed (%d)" % rc)
-    return y, stats
+    return y, stats, count
 
 
 def rowbn_apply(x, scale, shift, relu):
@@ -96,7 +113,7 @@ def rowbn_apply(x, scale, shift, relu):
     return y
 
 
-def rowbn_backward(x, dy, weight, stats, relu):
+def rowbn_backward(x, dy, weight, stats, relu, mask=None):
     L = lib()
     M, C = x.shape
     dev = x.device
@@ -105,9 +122,16 @@ def rowbn_backward(x, dy, weight, stats, relu):
     coef = torch.empty((3, C), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         ws, n = _workspace(L, M, C, dev)
-        rc = L.wsplumb_rowbn_backward(_p(x), _p(dy), M, C, _p(weight), _p(stats[0]), _p(stats[2]),
-                                      _p(stats[3]), _p(stats[4]), int(relu), _p(dx), _p(dwb[0]),
-                                      _p(dwb[1]), _p(coef), _p(ws), n, _stream())
+        if mask is None:
+            rc = L.wsplumb_rowbn_backward(_p(x), _p(dy), M, C, _p(weight), _p(stats[0]), _p(stats[2]),
+                                          _p(stats[3]), _p(stats[4]), int(relu), _p(dx), _p(dwb[0]),
+                                          _p(dwb[1]), _p(coef), _p(ws), n, _stream())
+        else:
+            n_rois = mask.shape[0]
+            rc = L.wsplumb_rowbn_backward_masked(_p(x), _p(dy), M, C, _p(weight), _p(stats[0]), _p(stats[2]),
+                                                 _p(stats[3]), _p(stats[4]), int(relu), _p(mask), n_rois,
+                                                 M // n_rois, _p(dx), _p(dwb[0]), _p(dwb[1]), _p(coef), _p(ws), n,
+                                                 _stream())
     if rc:
         raise RuntimeError("wsplumb_rowbn_backward failed (%d)" % rc)
     return dx, dwb[0], dwb[1]

@@ -28,7 +28,7 @@ class BatchNormAct2d(nn.BatchNorm2d):
                 n, h, w, c = rows.shape
                 r2 = rows.reshape(-1, c)
                 if _plumbing.usable(r2):
-                    y, mean, var = _FusedRowBatchNormFn.apply(r2, self.weight, self.bias, self.eps, bool(relu))
+                    y, mean, var, _ = _FusedRowBatchNormFn.apply(r2, self.weight, self.bias, self.eps, bool(relu))
                     with torch.no_grad():
                         m = r2.shape[0]
                         mom = self.momentum if self.momentum is not None else 0.1

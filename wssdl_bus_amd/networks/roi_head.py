@@ -58,25 +58,37 @@ class _FusedRowBatchNormFn(torch.autograd.Function):
     with separate elementwise ops; the ReLU mask is recomputed from x in the backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, relu):
-        y, stats = _plumbing.rowbn_forward(x, weight, bias, eps, relu)
-        ctx.save_for_backward(x, weight, stats)
+    def forward(ctx, x, weight, bias, eps, relu, roi_mask=None):
+        y, stats, count = _plumbing.rowbn_forward(x, weight, bias, eps, relu, roi_mask)
+        ctx.masked = roi_mask is not None
+        if ctx.masked:
+            ctx.save_for_backward(x, weight, stats, roi_mask)
+        else:
+            ctx.save_for_backward(x, weight, stats)
+            count = stats[0, :1]                       # placeholder (unused without a mask): no extra launch
         ctx.relu = relu
         mean, var = stats[0], stats[1]
-        ctx.mark_non_differentiable(mean, var)
-        return y, mean, var
+        ctx.mark_non_differentiable(mean, var, count)
+        return y, mean, var, count
 
     @staticmethod
-    def backward(ctx, dy, _dmean, _dvar):
-        x, weight, stats = ctx.saved_tensors
-        dx, dw, db = _plumbing.rowbn_backward(x, dy.contiguous(), weight, stats, ctx.relu)
-        return dx, dw, db, None, None
+    def backward(ctx, dy, _dmean, _dvar, _dcount):
+        if ctx.masked:
+            x, weight, stats, roi_mask = ctx.saved_tensors
+        else:
+            (x, weight, stats), roi_mask = ctx.saved_tensors, None
+        dx, dw, db = _plumbing.rowbn_backward(x, dy.contiguous(), weight, stats, ctx.relu, roi_mask)
+        return dx, dw, db, None, None, None
 
 
-# cfg.PADDED_ROIS: the head then sees a fixed number of RoI rows of which only some are live.
+# The head can see RoI rows that are not live: the padding rows of the fixed-shape blob
+# (cfg.PADDED_ROIS) and those of a supervised image that ran short of candidates under the device
+# sampler (cfg.SAMPLING_RNG = 'device': the layer keeps its fixed S*128 rows, batch index -1).
 # The networks set this mask ([R] f32, 1 = live) around the head call; batch statistics are
 # taken over the live rows only and dead rows are zeroed after every normalisation, so that the
-# live rows come out as if the blob had been compacted.  Plain PyTorch ops (no host sync).
+# live rows come out as if the blob had been compacted.  On the GPU this is the masked form of the
+# fused kernels (csrc/plumbing/rowbn.hip: dead rows are not even read); elsewhere plain PyTorch ops.
+# No host sync either way.
 _ROI_MASK = None
 
 
@@ -121,13 +133,17 @@ class RowBatchNorm(nn.Module):
             y = torch.addcmul(shift, x, scale)
             return F.relu(y) if relu else y
         if _ROI_MASK is not None:
-            y, mean, var, n = _masked_row_batch_norm(x, self.weight, self.bias, self.eps, relu, _ROI_MASK)
+            if fused and x.shape[0] % _ROI_MASK.shape[0] == 0:
+                y, mean, var, n = _FusedRowBatchNormFn.apply(x, self.weight, self.bias, self.eps, bool(relu), _ROI_MASK)
+                n = n[0]
+            else:
+                y, mean, var, n = _masked_row_batch_norm(x, self.weight, self.bias, self.eps, relu, _ROI_MASK)
             with torch.no_grad():
                 self.running_mean.lerp_(mean, self.momentum)
                 self.running_var.lerp_(var * (n / (n - 1).clamp_min(1.0)), self.momentum)
             return y
         if fused:
-            y, mean, var = _FusedRowBatchNormFn.apply(x, self.weight, self.bias, self.eps, bool(relu))
+            y, mean, var, _ = _FusedRowBatchNormFn.apply(x, self.weight, self.bias, self.eps, bool(relu))
         else:
             y, mean, var = _RowBatchNormFn.apply(x, self.weight, self.bias, self.eps)
             if relu:

@@ -85,8 +85,6 @@ def roi_pool_grad(bottom_data, bottom_rois, argmax, grad, pooled_height, pooled_
 # supports the shape (include/wssdl_bus_hip.h, "training path").  top_data and the gradient are
 # bit-identical to the i32 pair; `expand_argmax` rebuilds the reference's i32 indices.
 
-_overflow_flags = {}
-
 
 def compact_supported(H, W, C, pooled_height, pooled_width):
     return bool(cfg.ROI_POOL_COMPACT_ARGMAX) and bool(
@@ -94,20 +92,90 @@ def compact_supported(H, W, C, pooled_height, pooled_width):
                                                     int(pooled_width)))
 
 
-def _overflow_flag(dev):
-    f = _overflow_flags.get(dev)
+# Device-side error flags of the compact pair.  The kernels can only raise them; somebody has to
+# read them.  [0] = the forward met a bin window larger than 15 x 16 cells (a RoI reaching far
+# outside the feature map: its 1-byte code cannot say where the maximum was), [1] = the backward's
+# lists did not fit their workspace.  Either one means a wrong gradient, so they are never dropped:
+#   * poll_flags()  -- no synchronisation: looks at the copy started by the previous poll once its
+#                      event has completed, raises if a flag was up, starts the next copy.  The
+#                      train step calls it before every optimiser step (one step of delay).
+#   * check_flags() -- synchronises, raises.  Tests, bench.py after its timed region.
+#   * cfg.ROI_POOL_FLAG_CHECK = 'eager': RoiPoolFunction reads the forward flag right away (one
+#     host read-back per call) and re-runs an overflowing call on the i32 pair, which takes any RoI.
+_OVERFLOW_MSG = ("RoI pooling (1-byte arg-max path): a bin window exceeded 15 x 16 cells -- a RoI reaches far "
+                 "outside the feature map.  Its arg-max and gradient are invalid; clip the RoIs or use the i32 "
+                 "pair (cfg.ROI_POOL_COMPACT_ARGMAX = False or cfg.ROI_POOL_FLAG_CHECK = 'eager').")
+_LISTS_MSG = "RoI pooling backward: the per-tile lists overflowed their workspace; bottom_diff is short."
+
+
+class _DeviceFlags(object):
+    def __init__(self, dev):
+        self.flags = torch.zeros((2,), dtype=torch.int32, device=dev)
+        self.host = torch.zeros((2,), dtype=torch.int32).pin_memory()
+        self.event = None
+
+    @staticmethod
+    def _raise(v):
+        if int(v[0]) != 0:
+            raise _lib.HipCallError(_OVERFLOW_MSG)
+        if int(v[1]) != 0:
+            raise _lib.HipCallError(_LISTS_MSG)
+
+    def read_and_clear(self):
+        v = self.flags.cpu()
+        self.flags.zero_()
+        self.event = None
+        return v
+
+    def poll(self):
+        if self.event is not None and self.event.query():
+            self.event = None
+            self._raise(self.host)
+        if self.event is None:
+            self.host.copy_(self.flags, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+
+
+_device_flags = {}
+
+
+def _flags(dev):
+    f = _device_flags.get(dev)
     if f is None:
-        f = torch.zeros((1,), dtype=torch.int32, device=dev)
-        _overflow_flags[dev] = f
+        f = _device_flags[dev] = _DeviceFlags(dev)
     return f
 
 
+def _overflow_flag(dev):
+    return _flags(dev).flags[0:1]
+
+
+def poll_flags():
+    """Sync-free check of the flags raised up to the previous poll (see above)."""
+    for f in _device_flags.values():
+        f.poll()
+
+
+def check_flags():
+    """Synchronising check: raises HipCallError if any compact RoI-pool call raised a flag."""
+    for f in list(_device_flags.values()):
+        _DeviceFlags._raise(f.read_and_clear())
+
+
+def flags_raised():
+    """True (and the flags are cleared) when any flag is up.  Synchronises; for tests."""
+    up = False
+    for f in list(_device_flags.values()):
+        up = bool(f.read_and_clear().any()) or up
+    return up
+
+
 def compact_overflowed(device=None):
-    """True when any compact forward on `device` met a window larger than 15 x 16 cells (a RoI
-    reaching far outside the feature map).  Synchronises; for tests / debugging."""
+    """True when any compact forward on `device` met a window larger than 15 x 16 cells.  Synchronises."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    f = _overflow_flags.get(dev)
-    return bool(f is not None and int(f.item()) != 0)
+    f = _device_flags.get(dev)
+    return bool(f is not None and int(f.flags[0].item()) != 0)
 
 
 _WINDOW_TABLE_MIN_ROIS = 1024
@@ -125,7 +193,7 @@ def roi_pool_compact(data, rois, pooled_height, pooled_width, spatial_scale, rou
     with torch.cuda.device(data.device):
         # (a launch of its own only pays off on a train-sized RoI list)
         nwin = L.wssdl_roi_pool_forward_windows_bytes(R, H, W, C, int(pooled_height), int(pooled_width)) \
-            if (R >= _WINDOW_TABLE_MIN_ROIS and os.environ.get("WSSDL_ROI_FWD_VARIANT", "0") == "0") else 0
+            if (R >= _WINDOW_TABLE_MIN_ROIS and _lib.get_tuning("roi_fwd_variant") == 0) else 0
         if nwin:
             # the RoI geometry once per (roi, bin row) into a table, then the pooling kernel reads it with
             # scalar loads (two launches, timed apart: the second is the kernel the roofline is quoted on)
@@ -173,6 +241,10 @@ def roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scal
             _lib.check(L.wssdl_roi_pool_backward_prepare(
                 _lib.ptr(rois), R, N, H, W, C, int(pooled_height), int(pooled_width), float(spatial_scale),
                 mode, _lib.ptr(ws), nws, ctypes.byref(plan), _lib.stream()), "wssdl_roi_pool_backward_prepare")
+            if plan.value >= 0:
+                # the status block's error word joins the deferred flags (device-side OR, no read-back)
+                off = L.wssdl_roi_pool_backward_status_offset(R, N, H, W, int(pooled_height), int(pooled_width))
+                _flags(rois.device).flags[1:2].bitwise_or_(ws[off + 4:off + 8].view(torch.int32))
     return BackwardPlan(ws, nws, int(plan.value))
 
 
@@ -227,8 +299,15 @@ class RoiPoolFunction(torch.autograd.Function):
         ctx.compact = data.is_cuda and data.dtype == torch.float32 and rois.dtype == torch.float32 and \
             compact_supported(data.shape[1], data.shape[2], data.shape[3], pooled_height, pooled_width)
         ctx.plan = None
+        top = arg = None
         if ctx.compact:
             top, arg = roi_pool_compact(data, rois, pooled_height, pooled_width, spatial_scale, rounding)
+            if cfg.get('ROI_POOL_FLAG_CHECK', 'deferred') == 'eager' and compact_overflowed(data.device):
+                # a RoI the 1-byte codes cannot describe: this call runs on the i32 pair (any RoI)
+                _flags(data.device).flags[0:1].zero_()
+                ctx.compact = False
+                top = arg = None
+        if ctx.compact:
             if data.requires_grad or bottom_data.requires_grad:
                 # the backward's lists depend on the RoIs only: build them now, behind the forward
                 ctx.plan = roi_pool_grad_prepare(tuple(data.shape), rois, pooled_height, pooled_width,
