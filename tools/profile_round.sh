@@ -1,28 +1,39 @@
 #!/bin/bash
-# Collects the round's evidence on the GPU box into gpurun_out/round/: gpu tests, smoke, the bench
-# line, rocprofv3 kernel-trace stats of the same bench command, and -- on the roofline leg alone
-# (tools/roofline_leg.py: the fixed R = 8512 RoI set bench.py reports its roofline on) -- kernel
-# trace + one PMC pass per counter group.  Usage: bash tools/profile_round.sh [tag]
-TAG=${1:-r02}
+# Collects the round's evidence on the GPU box into gpurun_out/round/: the bench line of every
+# workload, rocprofv3 kernel-trace stats of the SAME commands (find-db warm: the script fails if a
+# MIOpen naive_conv_* kernel -- the find search -- shows up in a trace, or if the profiled run's
+# images/s is more than 5 % below the unprofiled one), the idle-gap analysis of the default
+# workload's timed steps (tools/trace_gaps.py), and -- on the roofline leg alone (tools/roofline_leg.py:
+# the fixed R = 8512 RoI set bench.py reports its roofline on) -- kernel trace + one PMC pass per
+# counter group.  Usage: bash tools/profile_round.sh <tag> bench [workloads...]   (bench lines + traces)
+#                             bash tools/profile_round.sh <tag> leg                   (roofline leg: trace + PMC)
+TAG=${1:-r03}; MODE=${2:-bench}; shift; shift
+WORKLOADS=${@:-resnet50_joint_b8 resnet18_sup_b2 resnet50_alter resnet101_1600_test vgg16_joint}
 OUT=gpurun_out/round
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest_gpu.log 2>&1
-tail -3 $OUT/pytest_gpu.log
-python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1
-tail -1 $OUT/smoke.log
-python bench.py --steps 10 --warmup 3 > $OUT/${TAG}_bench_resnet50_joint_b8.json.log 2>&1
-tail -1 $OUT/${TAG}_bench_resnet50_joint_b8.json.log | cut -c1-900
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_profiled_run.json.log 2>&1
-cp $(ls $OUT/prof_bench/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_resnet50_joint_b8_kernel_stats.csv
-# the roofline leg alone: kernel trace, then PMC passes (separate runs, kernel-trace only)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_leg -- python3 tools/roofline_leg.py --iters 20 > $OUT/${TAG}_roofline_leg.json.log 2>&1
+value() { tail -1 $1 | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['value'])"; }
+if [ "$MODE" = "bench" ]; then
+for w in $WORKLOADS; do
+  timeout -k 10 400 python3 bench.py --workload $w --steps 10 --warmup 3 > $OUT/${TAG}_bench_$w.json.log 2>&1 || { echo "bench $w failed"; tail -5 $OUT/${TAG}_bench_$w.json.log; exit 1; }
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -- python3 bench.py --workload $w --steps 5 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_${w}_profiled_run.json.log 2>&1 || { echo "profiled bench $w failed"; exit 1; }
+  cp $(ls $OUT/prof_$w/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_${w}_kernel_stats.csv
+  if grep -q naive_conv $OUT/${TAG}_bench_${w}_kernel_stats.csv; then echo "naive_conv kernels in the $w trace: find search ran under the profiler"; exit 1; fi
+  a=$(value $OUT/${TAG}_bench_$w.json.log); b=$(value $OUT/${TAG}_bench_${w}_profiled_run.json.log)
+  python3 -c "a,b=$a,$b; print('$w: %.2f images/s, profiled %.2f (%.1f %%)' % (a,b,100*b/a)); assert b >= 0.95*a, 'profiled run more than 5 % slower'" || exit 1
+done
+if [ -d $OUT/prof_resnet50_joint_b8 ]; then
+python3 tools/trace_gaps.py $OUT/prof_resnet50_joint_b8 --steps 5 > $OUT/${TAG}_bench_resnet50_joint_b8_step_gaps.json || exit 1
+fi
+exit 0
+fi
+# the roofline leg alone: parity check on the timed set, kernel trace, then PMC passes (separate runs, kernel-trace only)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_leg -- python3 tools/roofline_leg.py --iters 20 --check > $OUT/${TAG}_roofline_leg.json.log 2>&1 || { echo "leg failed"; exit 1; }
 cp $(ls $OUT/prof_leg/*/*kernel_stats.csv | head -1) $OUT/${TAG}_roofline_leg_kernel_stats.csv
 tail -1 $OUT/${TAG}_roofline_leg.json.log | cut -c1-600
-rocprofv3 -L > $OUT/counters_available.txt 2>&1
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   name=$(echo $pass | tr ' ' '+')
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$name -- python3 tools/roofline_leg.py --iters 5 --warmup 1 > $OUT/pmc_$name.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$name -- python3 tools/roofline_leg.py --iters 5 --warmup 1 > $OUT/pmc_$name.log 2>&1 || { echo "pmc pass $name failed"; exit 1; }
 done
 python3 tools/pmc_summary.py $OUT roi_pool | sort > $OUT/${TAG}_roofline_leg_pmc.txt
 python3 tools/pmc_summary.py $OUT walk | sort >> $OUT/${TAG}_roofline_leg_pmc.txt

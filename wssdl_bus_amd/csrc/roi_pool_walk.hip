@@ -543,20 +543,19 @@ int walk_plan_count() { return WALK_PLANS; }
 // chain one wave walks alone (small tiles: more, shorter chains).  A train-sized launch is
 // bandwidth-bound and wants 6x6; a launch with few waves (few images or channel groups) is bound by
 // its longest chain: 2 images x 256 channels x 4000 RoIs take 0.44 ms with 6x6 tiles, 0.24 with 4x4,
-// 0.12 with 2x2 (tools/bwd_plan_sweep.py).  Rule: the largest of 6x6, 4x4, 2x4, 2x2 with 128-channel
-// waves that still gives 2048 waves (one per wave slot of the chip at 8 per CU); a launch that falls
-// short of that even then halves the channels per wave (64-channel plans: twice the waves, each
-// chain as long but half as wide).
+// 0.12 with 2x2 (tools/bwd_plan_sweep.py).  Rule: walk down the list below -- tile area descending,
+// at equal tiles 128-channel waves before 64-channel ones (twice the waves, each chain as long but
+// half as wide) -- and take the first plan that gives 2048 waves (one per wave slot of the chip at 8
+// per CU).  Measured at the shapes of the other bench workloads (round 3): 3 images x 512 channels x
+// 6000 RoIs 0.27 -> 0.22 ms (4x4 / 64 channels instead of 2x4 / 128), 2 x 256 x 4000 0.12 -> 0.11,
+// 1 x 1024 x 300 0.042 -> 0.040.
 static int walk_plan_auto(int N, int H, int W, int C) {
-    static const int cand[4][3] = {{6, 6, 11}, {4, 4, 5}, {2, 4, 18}, {2, 2, 19}};
-    const long long G = cdiv(C, 128);
-    for (int i = 0; i < 4; ++i)
-        if ((long long)N * cdiv(H, cand[i][0]) * cdiv(W, cand[i][1]) * G >= 2048) return cand[i][2];
-    static const int cand64[3][3] = {{4, 4, 23}, {2, 4, 22}, {2, 2, 21}};
-    const long long G64 = cdiv(C, 64);
-    for (int i = 0; i < 3; ++i)
-        if ((long long)N * cdiv(H, cand64[i][0]) * cdiv(W, cand64[i][1]) * G64 >= 2048) return cand64[i][2];
-    return cand64[2][2];
+    static const int order[] = {11, 5, 23, 18, 22, 19, 21};
+    for (int id : order) {
+        const WalkPlan &p = kWalkPlans[id];
+        if ((long long)N * cdiv(H, p.th) * cdiv(W, p.tw) * cdiv(C, 64 * p.cpl) >= 2048) return id;
+    }
+    return 21;
 }
 
 static int walk_plan_choice(int N, int H, int W, int C) {

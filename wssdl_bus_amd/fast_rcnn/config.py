@@ -33,6 +33,17 @@ __C.TRAIN.WS_MAL_PCT = 0.2209                       # :60
 __C.TRAIN.MAX_GT_PER_IMAGE = 20                     # :92
 __C.TRAIN.SCALES = (600,)                           # :109
 __C.TRAIN.MAX_SIZE = 1000                           # :112
+# augmentation of the host image path (utils/blob.py): rotation needs skimage.transform.rotate, which is
+# absent and unpinned -- the reference's default True is not available here
+__C.TRAIN.USE_ROTATION = False                      # :136 (reference: True)
+__C.TRAIN.ROTATION_MAX_ANGLE = 5                    # :137
+__C.TRAIN.USE_CROPPING = True                       # :140
+__C.TRAIN.CROPPING_MAX_MARGIN = 0.05                # :141
+__C.TRAIN.USE_BRIGHTNESS_ADJUSTMENT = True          # :144
+__C.TRAIN.BRIGHTNESS_ADJUSTMENT_MAX_DELTA = 0.2     # :145
+__C.TRAIN.USE_CONTRAST_ADJUSTMENT = True            # :148
+__C.TRAIN.CONTRAST_ADJUSTMENT_LOWER_FACTOR = 0.2    # :149
+__C.TRAIN.CONTRAST_ADJUSTMENT_UPPER_FACTOR = 1.8    # :150
 __C.TRAIN.IMS_PER_BATCH = 1                         # :115
 __C.TRAIN.BATCH_SIZE = 128                          # :118
 __C.TRAIN.FG_FRACTION = 0.25                        # :121

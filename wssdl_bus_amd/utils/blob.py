@@ -1,8 +1,10 @@
 """Blob helper functions on the GPU (the pinnable half of the reference's host image path).
 
-Reference: code/lib/utils/blob.py:19-32 (im_list_to_blob), :34-79 (prep_im_for_blob),
-roi_data_layer/minibatch_bus.py:269-272 (grey plane stacked x3, flip), datasets/imdb.py:106-121
-(box mirroring).  Same function names and argument meaning; images live on the device.
+Reference: code/lib/utils/blob.py:19-32 (im_list_to_blob), :34-79 (prep_im_for_blob incl. the
+cropping of weak images :43-48), roi_data_layer/minibatch_bus.py:259-318 (_get_image_blob,
+_get_image_blob_joint: grey plane stacked x3, flip, supervised images first then weak ones),
+datasets/imdb.py:106-121 (box mirroring).  Same function names and argument meaning; images live
+on the device.
 
 ``skimage.transform.resize`` (blob.py:74-77) is not reimplemented: the library is absent here and
 its version unpinned, so no oracle could pin it.  prep_im_for_blob therefore
@@ -25,13 +27,26 @@ def _ws(dev):
 
 
 def prep_im_pre_resize(gray, flipped=False, brightness_delta=None, contrast_factor=None,
-                       pixel_means=PIXEL_MEANS):
-    """gray [h,w] u8 (GPU tensor or numpy) -> f32 [h,w,3] GPU tensor: the array the reference hands
+                       pixel_means=PIXEL_MEANS, crop=None):
+    """gray [h,w] u8 (GPU tensor or numpy) -> f32 [h',w',3] GPU tensor: the array the reference hands
     to skimage.transform.resize (blob.py:34-60 after minibatch_bus.py:269-272).  `brightness_delta`
-    / `contrast_factor`: the values of the reference's two np.random.uniform draws, None = off."""
-    g = _lib.to_device(gray, torch.uint8)
+    / `contrast_factor`: the values of the reference's two np.random.uniform draws, None = off.
+    `crop` = (offsets_u, offsets_d, offsets_l, offsets_r) of a weak image (blob.py:43-47): the
+    reference slices the ALREADY FLIPPED image [u:-d, l:-r]; here that is a strided view of the plane
+    (columns [r, w-l) of the unflipped plane when it is flipped) -- no copy, the kernel reads it with
+    its row stride and mirrors inside the view."""
+    g = _lib.to_device(gray, torch.uint8) if not (isinstance(gray, torch.Tensor) and gray.is_cuda
+                                                   and gray.dtype == torch.uint8) else gray
     if g.dim() != 2:
         raise ValueError("expected one grey plane [h, w]")
+    if crop is not None:
+        u, d, l, r = (int(v) for v in crop)
+        if d < 1 or r < 1 or u < 0 or l < 0 or u + d >= g.shape[0] or l + r >= g.shape[1]:
+            raise ValueError("crop offsets out of range")
+        H0, W0 = g.shape
+        g = g[u:H0 - d, r:W0 - l] if flipped else g[u:H0 - d, l:W0 - r]
+    if g.stride(1) != 1:
+        g = g.contiguous()
     h, w = g.shape
     out = torch.empty((h, w, 3), dtype=torch.float32, device=g.device)
     with torch.cuda.device(g.device):
@@ -54,20 +69,31 @@ def torch_bilinear_resize(im, shape):
 
 def prep_im_for_blob(gray, net_name, pixel_means, pixel_stds, target_size, max_size, is_training,
                      is_ws=False, flipped=False, rng=None, resize=None):
-    """blob.py:34-79 for one grey plane.  Returns (im [h',w',3] on the GPU, im_scale).  The two
-    augmentation draws come from `rng` (default: numpy's global stream, like the reference) in the
-    reference's order; rotation and cropping of weak images (blob.py:39-46) need skimage / are a
-    plain slice and are left to the caller."""
+    """blob.py:34-79 for one grey plane.  Returns (im [h',w',3] on the GPU, im_scale).  The draws come
+    from `rng` (default: numpy's global legacy stream, like the reference) in the reference's order:
+    for a weak image (is_ws) the four crop offsets (np.random.random_integers, :43-46), then -- when
+    training -- brightness (:50) and contrast (:55).  Rotation (:39-41) needs
+    skimage.transform.rotate and is not available (cfg.TRAIN.USE_ROTATION must be False)."""
     rng = np.random if rng is None else rng
-    delta = factor = None
+    crop = delta = factor = None
+    if is_ws:
+        if cfg.TRAIN.USE_ROTATION:
+            raise NotImplementedError("rotation needs skimage.transform.rotate (absent, unpinned): "
+                                      "set cfg.TRAIN.USE_ROTATION = False")
+        if cfg.TRAIN.USE_CROPPING:
+            h0, w0 = (int(v) for v in gray.shape)
+            m = cfg.TRAIN.CROPPING_MAX_MARGIN
+            # random_integers(lo, hi) with a float hi == randint(lo, int(hi) + 1) of the legacy stream
+            crop = (int(rng.randint(0, int(m * h0) + 1)), int(rng.randint(1, int(m * h0) + 1)),
+                    int(rng.randint(0, int(m * w0) + 1)), int(rng.randint(1, int(m * w0) + 1)))
     if is_training:
-        if cfg.TRAIN.get("USE_BRIGHTNESS_ADJUSTMENT", True):
-            d = cfg.TRAIN.get("BRIGHTNESS_ADJUSTMENT_MAX_DELTA", 0.2)
+        if cfg.TRAIN.USE_BRIGHTNESS_ADJUSTMENT:
+            d = cfg.TRAIN.BRIGHTNESS_ADJUSTMENT_MAX_DELTA
             delta = rng.uniform(-d, d)
-        if cfg.TRAIN.get("USE_CONTRAST_ADJUSTMENT", True):
-            factor = rng.uniform(cfg.TRAIN.get("CONTRAST_ADJUSTMENT_LOWER_FACTOR", 0.2),
-                                 cfg.TRAIN.get("CONTRAST_ADJUSTMENT_UPPER_FACTOR", 1.8))
-    pre = prep_im_pre_resize(gray, flipped, delta, factor, pixel_means)
+        if cfg.TRAIN.USE_CONTRAST_ADJUSTMENT:
+            factor = rng.uniform(cfg.TRAIN.CONTRAST_ADJUSTMENT_LOWER_FACTOR,
+                                 cfg.TRAIN.CONTRAST_ADJUSTMENT_UPPER_FACTOR)
+    pre = prep_im_pre_resize(gray, flipped, delta, factor, pixel_means, crop=crop)
     h, w = pre.shape[:2]
     im_scale = float(target_size) / float(min(h, w))
     if np.round(im_scale * max(h, w)) > max_size:
@@ -102,6 +128,34 @@ def im_list_to_blob(ims, scale=1.0, divide=False):
                 _lib.ptr(im), int(im.dtype == torch.float64), im.shape[0], im.shape[1], float(scale), int(divide),
                 _lib.ptr(blob), i, len(ims), Hm, Wm, _lib.stream()), "wssdl_image_to_blob")
     return blob
+
+
+def _get_image_blob(planes, flipped, net_name, scale_inds, is_training, is_ws, rng=None, resize=None):
+    """roi_data_layer/minibatch_bus.py:259-283: one list of images, all supervised or all weak."""
+    ims, scales = [], []
+    for i, (g, f) in enumerate(zip(planes, flipped)):
+        im, s = prep_im_for_blob(g, net_name, PIXEL_MEANS, PIXEL_STDS, cfg.TRAIN.SCALES[int(scale_inds[i])],
+                                 cfg.TRAIN.MAX_SIZE, is_training, is_ws=bool(is_ws), flipped=f, rng=rng, resize=resize)
+        ims.append(im)
+        scales.append(s)
+    return im_list_to_blob(ims), scales
+
+
+def _get_image_blob_joint(planes_s, flipped_s, planes_ws, flipped_ws, net_name, scale_inds, is_training,
+                          rng=None, resize=None):
+    """roi_data_layer/minibatch_bus.py:285-318: the combined mini-batch -- the supervised images first
+    (is_ws=False), then the weak ones (is_ws=True: cropped), `scale_inds` indexed in that order, one RNG
+    stream through all of them; zero-padded blob [n_s + n_ws, max_h, max_w, 3] and the im_scales."""
+    ims, scales = [], []
+    k = 0
+    for planes, flips, ws in ((planes_s, flipped_s, False), (planes_ws, flipped_ws, True)):
+        for g, f in zip(planes, flips):
+            im, s = prep_im_for_blob(g, net_name, PIXEL_MEANS, PIXEL_STDS, cfg.TRAIN.SCALES[int(scale_inds[k])],
+                                     cfg.TRAIN.MAX_SIZE, is_training, is_ws=ws, flipped=f, rng=rng, resize=resize)
+            ims.append(im)
+            scales.append(s)
+            k += 1
+    return im_list_to_blob(ims), scales
 
 
 def flip_boxes(boxes, width):
