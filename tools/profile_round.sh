@@ -17,20 +17,19 @@ if [ "$MODE" = "bench" ]; then
 for w in $WORKLOADS; do
   # (1) the bench line as the driver runs it (MIOpen find mode on the shipped find-db)
   timeout -k 10 400 python3 bench.py --workload $w --steps 10 --warmup 3 > $OUT/${TAG}_bench_$w.json.log 2>&1 || { echo "bench $w failed"; tail -5 $OUT/${TAG}_bench_$w.json.log; exit 1; }
-  # (2) + (3) the traced step.  Under rocprofv3 MIOpen's find mode re-runs its search (naive_conv_*
-  # reference kernels, seconds of GPU time) even with the find-db in place, so the traced command uses
-  # MIOpen's heuristic solver choice (--no-miopen-benchmark), and the SAME command runs untraced beside
-  # it: the two must agree within 5 % and the trace must hold no naive_conv_* kernel.
+  # (2) + (3) the traced step.  Under rocprofv3 the find-db path does not reproduce its untraced speed
+  # (VERDICT r2), so the traced command uses MIOpen's heuristic solver choice (--no-miopen-benchmark)
+  # and the SAME command runs untraced beside it: the two must agree within 5 %.  The per-kernel summary
+  # that is kept covers the TIMED STEPS only (tools/trace_gaps.py): MIOpen runs naive_conv_* reference
+  # kernels for every new convolution in the warm-up steps, which dominate a whole-process summary.
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -- python3 bench.py --workload $w --steps 5 --warmup 3 --no-cpu-baseline --no-miopen-benchmark > $OUT/${TAG}_bench_${w}_profiled_run.json.log 2>&1 || { echo "profiled bench $w failed"; exit 1; }
   timeout -k 10 400 python3 bench.py --workload $w --steps 5 --warmup 3 --no-cpu-baseline --no-miopen-benchmark > $OUT/${TAG}_bench_${w}_unprofiled_same_command.json.log 2>&1 || { echo "bench $w (heuristic) failed"; exit 1; }
-  cp $(ls $OUT/prof_$w/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_${w}_kernel_stats.csv
-  if grep -q naive_conv $OUT/${TAG}_bench_${w}_kernel_stats.csv; then echo "naive_conv kernels in the $w trace: a MIOpen search ran under the profiler"; exit 1; fi
+  cp $(ls $OUT/prof_$w/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_${w}_whole_process_kernel_stats.csv
+  mps=1; if [ "$w" = "resnet50_alter" ]; then mps=2; fi
+  python3 tools/trace_gaps.py $OUT/prof_$w --steps 5 --warmup 3 --markers-per-step $mps --stats-csv $OUT/${TAG}_bench_${w}_kernel_stats.csv > $OUT/${TAG}_bench_${w}_step_gaps.json || { echo "timed steps of $w hold naive_conv kernels or the trace is short"; exit 1; }
   a=$(value $OUT/${TAG}_bench_${w}_unprofiled_same_command.json.log); b=$(value $OUT/${TAG}_bench_${w}_profiled_run.json.log)
   python3 -c "a,b=$a,$b; print('$w: untraced %.2f images/s, traced %.2f (%.1f %%)' % (a,b,100*b/a)); assert b >= 0.95*a, 'traced run more than 5 % slower'" || exit 1
 done
-if [ -d $OUT/prof_resnet50_joint_b8 ]; then
-python3 tools/trace_gaps.py $OUT/prof_resnet50_joint_b8 --steps 5 > $OUT/${TAG}_bench_resnet50_joint_b8_step_gaps.json || exit 1
-fi
 exit 0
 fi
 # the roofline leg alone: parity check on the timed set, kernel trace, then PMC passes (separate runs, kernel-trace only)

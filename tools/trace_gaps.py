@@ -3,13 +3,14 @@
 
     python3 tools/trace_gaps.py <dir with *_kernel_trace.csv> [--steps K] [--marker KERNEL_SUBSTRING]
 
-The timed region of bench.py is its last K optimiser steps before the roofline leg.  A step is
-delimited by a marker kernel that runs exactly once per step (default: the proposal decode kernel of
-the hot path); the K intervals between the last K+1 markers *before the leg's first launch* are the
-steps.  Per step: span, sum of kernel durations on the busiest queue overlap-merged across queues
-(busy), idle = span - busy, and the largest gaps with the kernels on either side.  Also asserts what
-VERDICT r2 asked for: no MIOpen `naive_conv_*` kernel in the trace (their presence means the find
-search ran under the profiler and the trace is not the step the bench times).
+A step is delimited by a marker kernel that runs a fixed number of times per step (default: the
+proposal decode kernel of the hot path, once; twice per alternating iteration); the timed steps start
+at marker number warmup * markers_per_step.  Per step: span, kernel time overlap-merged across queues (busy), idle = span - busy, and the
+largest gaps with the kernels on either side; --stats-csv writes the per-kernel totals of the TIMED
+STEPS ONLY.  rocprofv3's own *_kernel_stats.csv covers the whole process, and MIOpen runs its
+naive_conv_* reference kernels for every new convolution during bench.py's warm-up steps (seconds of
+GPU time, 94 % of a whole-process summary) -- they must not appear inside the timed steps, which this
+script asserts.
 """
 import argparse
 import csv
@@ -44,27 +45,27 @@ def merged_busy(rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("root")
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=5, help="timed steps of the traced bench.py run (--steps)")
+    ap.add_argument("--warmup", type=int, default=3, help="its warm-up steps (--warmup)")
     ap.add_argument("--marker", default="proposal_decode")
-    ap.add_argument("--leg-marker", default="roi_windows_kernel")
-    ap.add_argument("--allow-naive-conv", action="store_true")
+    ap.add_argument("--markers-per-step", type=int, default=1, help="2 for the alternating workload")
+    ap.add_argument("--stats-csv", default="", help="write per-kernel totals of the timed steps here")
     args = ap.parse_args()
     rows = load(args.root)
     assert rows, "no kernel trace under %s" % args.root
-    naive = [n for _, _, n in rows if "naive_conv" in n]
     marks = [i for i, r in enumerate(rows) if args.marker in r[2]]
-    assert len(marks) > args.steps, "marker %r found %d times" % (args.marker, len(marks))
-    # the roofline leg launches the pair outside any step: its markers come after the last step's decode
-    marks = marks[-(args.steps + 1):] if len(marks) == args.steps + 1 else marks
-    # keep the last K+1 markers that are followed by another marker within a plausible step
-    steps = []
-    for a, b in zip(marks[:-1], marks[1:]):
-        steps.append(rows[a:b])
-    steps = steps[-args.steps:]
+    mps = args.markers_per_step
+    need = (args.warmup + args.steps) * mps
+    assert len(marks) >= need, "marker %r found %d times, expected >= %d" % (args.marker, len(marks), need)
+    # step i of the timed region = [marker of timed step i, marker of timed step i + 1): one full step
+    # period in steady state; the last timed step has no closing marker and is left out
+    first = args.warmup * mps
+    bounds = [marks[first + i * mps] for i in range(args.steps)]
+    steps = [rows[a:b] for a, b in zip(bounds[:-1], bounds[1:])]
     out = []
+    per_kernel = {}
     for st in steps:
         span = st[-1][1] - st[0][0]
-        # the step's span = first kernel start .. next step's first kernel start
         busy = merged_busy(st)
         gaps = []
         end = st[0][1]
@@ -75,16 +76,31 @@ def main():
             if e > end:
                 end, prev = e, n
         gaps.sort(reverse=True)
+        for s, e, n in st:
+            d = per_kernel.setdefault(n, [0, 0])
+            d[0] += 1
+            d[1] += e - s
         out.append(dict(span_ms=round(span / 1e6, 3), busy_ms=round(busy / 1e6, 3), idle_ms=round((span - busy) / 1e6, 3),
                         busy_frac=round(busy / span, 4), kernels=len(st),
                         top_gaps=[dict(us=round(g / 1e3, 1), after=a, before=b) for g, a, b in gaps[:5]]))
-    res = dict(steps=out, naive_conv_kernels=len(naive),
+    naive_timed = sum(c for n, (c, _) in per_kernel.items() if "naive_conv" in n)
+    naive_all = sum(1 for _, _, n in rows if "naive_conv" in n)
+    res = dict(steps=out, intervals=len(out), naive_conv_kernels_in_timed_steps=naive_timed,
+               naive_conv_kernels_in_whole_process=naive_all,
                mean_busy_frac=round(sum(o["busy_frac"] for o in out) / len(out), 4),
                mean_idle_ms=round(sum(o["idle_ms"] for o in out) / len(out), 3),
                mean_span_ms=round(sum(o["span_ms"] for o in out) / len(out), 3))
+    if args.stats_csv:
+        tot = sum(t for _, t in per_kernel.values())
+        with open(args.stats_csv, "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "CallsPerStep", "MsPerStep"])
+            for n, (c, t) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
+                w.writerow([n, c, t, "%.1f" % (t / c), "%.3f" % (100.0 * t / tot), "%.2f" % (c / len(out)),
+                            "%.4f" % (t / len(out) / 1e6)])
     print(json.dumps(res, indent=1))
-    if naive and not args.allow_naive_conv:
-        raise SystemExit("naive_conv_* kernels in the trace: the MIOpen find search ran under the profiler")
+    if naive_timed:
+        raise SystemExit("naive_conv_* kernels inside the timed steps: a MIOpen search ran in the timed region")
 
 
 if __name__ == "__main__":
