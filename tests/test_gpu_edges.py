@@ -716,3 +716,50 @@ def test_nms_prefilter_box_families_vs_oracle(torch_cuda):
     want = O.nms(prop, 0.7)
     assert hip_nms(prop, 0.7) == want
     assert hip_nms(prop, 0.7, max_keep=2000) == want[:2000]
+
+
+def test_fused_mask_sweep_launch_equals_two_launches(torch_cuda):
+    """One-pass NMS of the proposal layer as ONE launch (sweep workgroups trailing the mask workgroups
+    row block by row block, nms.hip: nms_mask_sweep_fused_kernel) against the two launches it replaces:
+    identical blobs on the golden train inputs, on 8 images of synthetic RPN maps (heavy and light
+    suppression, an image with no candidates at all) and with the heavy-suppression maps of the two-pass
+    test; the golden rows themselves are pinned by test_proposal_layer_golden with the fused default."""
+    torch = torch_cuda
+    from wssdl_bus_amd import _lib
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.rpn_msr.proposal_layer_tf_bus import proposal_layer
+    assert _lib.get_tuning("nms_fused") == 1
+
+    def both(prob, pred, info, train=True):
+        with _lib.tuned(nms_fused=1):
+            a = proposal_layer(prob, pred, info, train, False)
+        with _lib.tuned(nms_fused=0):
+            b = proposal_layer(prob, pred, info, train, False)
+        assert np.array_equal(a, b)
+        return a
+
+    g = load_golden("proposal_layer")
+    both(g["res_38x63_train/prob"], g["res_38x63_train/pred"], g["res_38x63_train/im_info"])
+    rs = np.random.RandomState(5)
+    N, H, W, A = 8, 38, 63, 9
+    info = np.tile(np.array([[600, 1000, 1.0, 1]], np.float32), (N, 1))
+    logits = rs.normal(size=(N, H, W, A, 2)).astype(np.float32)
+    e = np.exp(logits - logits.max(-1, keepdims=True))
+    p = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    prob = np.concatenate((p[..., 0], p[..., 1]), axis=-1)
+    pred = rs.normal(0, 0.2, size=(N, H, W, 4 * A)).astype(np.float32)
+    pred[1] = 0.0                                   # the anchors themselves: neighbours suppress each other
+    pred[2] *= 4.0                                  # wild boxes: hardly any suppression
+    info[3, :2] = [8, 8]                            # every box filtered out (min size): no candidates
+    old = cfg.TRAIN.RPN_NMS_THRESH
+    try:
+        for t in (0.7, 0.3):
+            cfg.TRAIN.RPN_NMS_THRESH = t
+            out = both(prob, pred, info)
+            counts = [int((out[:, 0] == i).sum()) for i in range(N)]
+            assert counts[3] == 0 and counts[2] == 2000 and 0 < counts[1] <= 2000
+            for _ in range(3):                      # repeatable (the waits never change the result)
+                with _lib.tuned(nms_fused=1):
+                    assert np.array_equal(proposal_layer(prob, pred, info, True, False), out)
+    finally:
+        cfg.TRAIN.RPN_NMS_THRESH = old

@@ -21,6 +21,7 @@ static int *tuning_field(const char *key) {
     if (!strcmp(key, "roi_bwdc_variant")) return &t.roi_bwdc_variant;
     if (!strcmp(key, "roi_bwd_cg")) return &t.roi_bwd_cg;
     if (!strcmp(key, "nms_one_pass")) return &t.nms_one_pass;
+    if (!strcmp(key, "nms_fused")) return &t.nms_fused;
     return nullptr;
 }
 }  // namespace wssdl

@@ -332,28 +332,45 @@ typedef float nms_float2v __attribute__((ext_vector_type(2)));
 
 constexpr int MASK_SEG = 16;     // column blocks per workgroup
 
-// One workgroup per (64-row block, segment of 16 column blocks); its 4 waves stride over the
+// One "mask block" per (64-row block, segment of 16 column blocks); its 4 waves stride over the
 // segment's column blocks cb >= rb (upper triangle only).  A lane keeps its row box in
 // registers; the 64 column boxes of the wave's current block sit in that wave's LDS slice and
-// are read as broadcasts.
-__global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
-    const float *__restrict__ boxes, int box_stride_img, const int *__restrict__ n_dev, int n_max,
-    double thresh, unsigned long long *__restrict__ mask, int ncb,
-    unsigned long long *__restrict__ diag_t, unsigned long long *__restrict__ summ, int sw,
-    int n_limit, int cb_min, const int *__restrict__ done, int dense_ahead) {
-    const int rb = blockIdx.x, seg = blockIdx.y, img = blockIdx.z;
+// are read as broadcasts.  The waves of a mask block are independent (no workgroup barrier), so the
+// body below serves the stand-alone kernel (one block = 4 waves) and the fused mask + sweep kernel
+// (16 waves of a workgroup = 4 mask blocks): `wave` = 0..3 inside the mask block, cbox_w / cgeo_w =
+// the LDS slice of the calling wave.
+struct MaskArgs {
+    const float *boxes;  int box_stride_img;  const int *n_dev;  int n_max;
+    double thresh;  unsigned long long *mask;  int ncb;
+    unsigned long long *diag_t;  unsigned long long *summ;  int sw;
+    int n_limit;  int cb_min;  const int *done;  int dense_ahead;
+};
+
+// COHERENT: the words are read by a sweep that runs beside this kernel, possibly on another XCD (whose
+// L2 is not coherent with this one's for ordinary stores): they are stored write-through at agent scope,
+// so that the release of the row-block counter needs no L2 write-back (a buffer_wbl2 per wave made the
+// fused launch 4x slower than the two it replaces).
+template <bool COHERENT>
+__device__ __forceinline__ void nms_store_word(unsigned long long *p, unsigned long long v) {
+    if (COHERENT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+template <bool COHERENT>
+__device__ __forceinline__ void nms_mask_block(const MaskArgs &A, int rb, int seg, int img, int wave, int lane,
+                                               float (*cbox_w)[64] /* [5][64] */, nms_float4v *cgeo_w /* [64] */) {
+    const float *__restrict__ boxes = A.boxes;
+    const int box_stride_img = A.box_stride_img, n_max = A.n_max, ncb = A.ncb, sw = A.sw, n_limit = A.n_limit,
+              cb_min = A.cb_min, dense_ahead = A.dense_ahead;
+    const double thresh = A.thresh;
+    unsigned long long *__restrict__ mask = A.mask, *__restrict__ diag_t = A.diag_t, *__restrict__ summ = A.summ;
     // two-pass use (launch_nms_two_pass): the first pass covers the candidates below n_limit only,
     // the second one the column blocks >= cb_min of the images the first pass could not finish
-    if (done && done[img]) return;
-    const int n = min(min(n_dev[img], n_max), n_limit);
+    if (A.done && A.done[img]) return;
+    const int n = min(min(A.n_dev[img], n_max), n_limit);
     const int cb_first = max(rb, cb_min);
     if (rb * 64 >= n || (seg + 1) * MASK_SEG <= cb_first || seg * MASK_SEG * 64 >= n) return;
-    __shared__ float cbox[MASK_WAVES][5][64];      // x1 y1 x2 y2 area
-    __shared__ nms_float4v cgeo[MASK_WAVES][64];       // cx cy rx ry of the column boxes: one 16-byte read per pair
     const float *b = boxes + (size_t)img * box_stride_img;
-    // wave index through readfirstlane: the column-block loop and its trip counts are then
-    // scalar (loop control on the SALU)
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = rb * 64 + lane;
     const bool row_ok = i < n;
     float ix1 = 0.f, iy1 = 0.f, ix2 = 0.f, iy2 = 0.f;
@@ -399,9 +416,9 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
             x1 = v.x; y1 = v.y; x2 = v.z; y2 = v.w;
         }
         // the wave's own slice: wave-synchronous, no workgroup barrier needed
-        cbox[wave][0][lane] = x1; cbox[wave][1][lane] = y1; cbox[wave][2][lane] = x2;
-        cbox[wave][3][lane] = y2; cbox[wave][4][lane] = box_area_ref(x1, y1, x2, y2);
-        if (prefilter) cgeo[wave][lane] = geometry(x1, y1, x2, y2, col < n);
+        cbox_w[0][lane] = x1; cbox_w[1][lane] = y1; cbox_w[2][lane] = x2;
+        cbox_w[3][lane] = y2; cbox_w[4][lane] = box_area_ref(x1, y1, x2, y2);
+        if (prefilter) cgeo_w[lane] = geometry(x1, y1, x2, y2, col < n);
         __builtin_amdgcn_wave_barrier();
         const int jn = min(64, n - cb * 64);
         unsigned b_lo = 0u, b_hi = 0u, u_lo = 0u, u_hi = 0u;
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
             // candidates only: the exact loop below decides them.  Column j's verdict enters the
             // word through the carry (u = 2 u + verdict), highest column first.
             auto near = [&](int j, unsigned u) -> unsigned {
-                const nms_float4v q = cgeo[wave][j];
+                const nms_float4v q = cgeo_w[j];
                 const nms_float2v d = ic - q.xy;
                 const nms_float2v r = ir + q.zw;
                 const unsigned long long px = __builtin_amdgcn_fcmpf(__builtin_fabsf(d.x), r.x, 5 /* ole */);
@@ -431,14 +448,14 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
             // with the exact test; they are rare, so pass 1 carries no branch.
             // (two 32-column halves: 32-bit shift-or per flag instead of 64-bit shifts)
             auto pair_flags = [&](int j, unsigned &yes_bit, unsigned &und_bit) {
-                const float xx1 = fmax_ref(ix1, cbox[wave][0][j]);
-                const float yy1 = fmax_ref(iy1, cbox[wave][1][j]);
-                const float xx2 = fmin_ref(ix2, cbox[wave][2][j]);
-                const float yy2 = fmin_ref(iy2, cbox[wave][3][j]);
+                const float xx1 = fmax_ref(ix1, cbox_w[0][j]);
+                const float yy1 = fmax_ref(iy1, cbox_w[1][j]);
+                const float xx2 = fmin_ref(ix2, cbox_w[2][j]);
+                const float yy2 = fmin_ref(iy2, cbox_w[3][j]);
                 float w = xx2 - xx1;  w = fmax0_ref(w + 1.0f);
                 float h = yy2 - yy1;  h = fmax0_ref(h + 1.0f);
                 const float inter = w * h;
-                float den = iarea + cbox[wave][4][j];
+                float den = iarea + cbox_w[4][j];
                 den = den - inter;
                 const bool yes = inter > den * t_hi;
                 const bool no = inter < den * t_lo;
@@ -465,14 +482,14 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
         while (undecided != 0ull) {
             const int j = __ffsll((long long)undecided) - 1;
             undecided &= undecided - 1ull;
-            const float xx1 = fmax_ref(ix1, cbox[wave][0][j]);
-            const float yy1 = fmax_ref(iy1, cbox[wave][1][j]);
-            const float xx2 = fmin_ref(ix2, cbox[wave][2][j]);
-            const float yy2 = fmin_ref(iy2, cbox[wave][3][j]);
+            const float xx1 = fmax_ref(ix1, cbox_w[0][j]);
+            const float yy1 = fmax_ref(iy1, cbox_w[1][j]);
+            const float xx2 = fmin_ref(ix2, cbox_w[2][j]);
+            const float yy2 = fmin_ref(iy2, cbox_w[3][j]);
             float w = xx2 - xx1;  w = fmax0_ref(w + 1.0f);
             float h = yy2 - yy1;  h = fmax0_ref(h + 1.0f);
             const float inter = w * h;
-            float den = iarea + cbox[wave][4][j];
+            float den = iarea + cbox_w[4][j];
             den = den - inter;
             if ((double)(inter / den) >= thresh) bits |= 1ull << j;
         }
@@ -482,7 +499,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
             // lane's own index = the EARLIER boxes of this chunk that suppress box i (what the
             // sweep's resolver wants per lane); the mask proper keeps the bits above it.
             const unsigned long long below = (1ull << lane) - 1ull;
-            if (row_ok && diag_t) diag_t[(size_t)img * n_max + i] = bits & below;
+            if (row_ok && diag_t) nms_store_word<COHERENT>(&diag_t[(size_t)img * n_max + i], bits & below);
             bits &= ~(below | (1ull << lane));
         }
         // Over 99 % of the words are zero.  A reader that goes by the summary (the pipelined sweep)
@@ -490,13 +507,22 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
         // words up to dense_ahead blocks right of the diagonal unconditional (the sweep's stagers
         // read that band without looking at the summary); dense_ahead < 0 stores every word.
         if (row_ok && (bits != 0ull || dense_ahead < 0 || cb - rb <= dense_ahead))
-            mask[((size_t)img * n_max + i) * ncb + cb] = bits;
+            nms_store_word<COHERENT>(&mask[((size_t)img * n_max + i) * ncb + cb], bits);
         // summary: which words of the row are non-zero at all (most are zero: a box overlaps few
         // others), so that the sweep only fetches those
         if (row_ok && bits != 0ull && summ)
             atomicOr(&summ[((size_t)img * n_max + i) * sw + (cb >> 6)], 1ull << (cb & 63));
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+__global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(MaskArgs A) {
+    __shared__ float cbox[MASK_WAVES][5][64];      // x1 y1 x2 y2 area
+    __shared__ nms_float4v cgeo[MASK_WAVES][64];   // cx cy rx ry of the column boxes: one 16-byte read per pair
+    // wave index through readfirstlane: the column-block loop and its trip counts are then
+    // scalar (loop control on the SALU)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    nms_mask_block<false>(A, blockIdx.x, blockIdx.y, blockIdx.z, wave, lane, cbox[wave], cgeo[wave]);
 }
 
 int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, int n_max,
@@ -511,9 +537,9 @@ int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, in
         hipMemsetAsync(summ, 0, sizeof(unsigned long long) * (size_t)n_images * n_max * sw, st) != hipSuccess)
         return WSSDL_ERR_LAUNCH;
     const int ncb_eff = cdiv(min(n_max, n_limit), 64);      // row / column blocks this pass can touch
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(ncb_eff, cdiv(ncb_eff, MASK_SEG), n_images), dim3(64 * MASK_WAVES), 0, st,
-                       boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, sw, n_limit, cb_min, done,
-                       nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) ? NMS_DENSE_AHEAD : -1);
+    const MaskArgs A = {boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, sw, n_limit, cb_min, done,
+                        nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) ? NMS_DENSE_AHEAD : -1};
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(ncb_eff, cdiv(ncb_eff, MASK_SEG), n_images), dim3(64 * MASK_WAVES), 0, st, A);
     return check_launch();
 }
 
@@ -703,24 +729,48 @@ struct SweepShared {
         int base;                                   // boxes kept before the chunk
         int count;                                  // boxes kept after it
     } pub[2];                                       // by chunk parity
+    int timed_out;                                  // fused run: the mask kernel never finished a row block
 };
 
-__global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(
-    const unsigned long long *__restrict__ mask, const unsigned long long *__restrict__ diag_t,
-    const unsigned long long *__restrict__ summ, int sw,
-    const int *__restrict__ n_dev, int n_max, int ncb,
-    int max_keep, const int *__restrict__ order, int order_stride_img,
-    int *__restrict__ keep, int *__restrict__ num_keep,
-    const float *__restrict__ boxes, int box_stride_img, float *__restrict__ rois_padded,
-    int n_limit, const int *__restrict__ done_in, int *__restrict__ done_out) {
-    extern __shared__ unsigned long long sweep_dyn[];
-    if (done_in && done_in[blockIdx.x]) return;
+struct SweepArgs {
+    const unsigned long long *mask, *diag_t, *summ;  int sw;
+    const int *n_dev;  int n_max, ncb, max_keep;  const int *order;  int order_stride_img;
+    int *keep, *num_keep;  const float *boxes;  int box_stride_img;  float *rois_padded;
+    int n_limit;  const int *done_in;  int *done_out;
+    // fused with the mask kernel (nms_mask_sweep_fused_kernel): rowdone[img * ncb + rb] counts the
+    // waves of the mask blocks of row block rb that have finished; a row block is complete at
+    // `rowdone_expected`.  NULL: the mask is complete before the sweep starts.
+    const int *rowdone;  int rowdone_expected;
+};
+
+// Wait (one wave, before it reads rows of 64-row block `chunk`) until the mask kernel running beside
+// this sweep has finished that row block.  Bounded: after ~0.5 s without progress the wave gives up
+// and raises *timed_out (the caller then reports zero kept boxes: a loud failure instead of a hang).
+__device__ __forceinline__ void sweep_wait_rows(const int *rowdone, int expected, int index, int *timed_out) {
+    if (!rowdone) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();           // 100 MHz
+    while (__hip_atomic_load(rowdone + index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+        __builtin_amdgcn_s_sleep(16);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) { *timed_out = 1;  break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, int img, unsigned long long *sweep_dyn,
+                                                          SweepShared &sh) {
+    const unsigned long long *__restrict__ mask = A.mask, *__restrict__ diag_t = A.diag_t, *__restrict__ summ = A.summ;
+    const int sw = A.sw, n_max = A.n_max, ncb = A.ncb, max_keep = A.max_keep, order_stride_img = A.order_stride_img,
+              box_stride_img = A.box_stride_img, n_limit = A.n_limit;
+    const int *__restrict__ n_dev = A.n_dev, *__restrict__ order = A.order, *__restrict__ done_in = A.done_in;
+    int *__restrict__ keep = A.keep, *__restrict__ num_keep = A.num_keep, *__restrict__ done_out = A.done_out;
+    const float *__restrict__ boxes = A.boxes;
+    float *__restrict__ rois_padded = A.rois_padded;
+    if (done_in && done_in[img]) return;
     // dynamic LDS: per kept box the summary of its non-zero mask words [max_keep + 64][sw], then
     // the kept list [max_keep + 64]
     unsigned long long *ksum = sweep_dyn;
     int *kept_rows = reinterpret_cast<int *>(sweep_dyn + (size_t)(max_keep + 64) * sw);
-    __shared__ SweepShared sh;
-    const int img = blockIdx.x;
+    if (threadIdx.x == 0) sh.timed_out = 0;
     const int n = min(min(n_dev[img], n_max), n_limit);
     const int nchunks = (n + 63) / 64;
     const unsigned long long *m = mask + (size_t)img * n_max * ncb;
@@ -752,6 +802,7 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(
     for (int j = 0; j < SWEEP_LH; ++j) pend[j] = 0ull;
 
     auto load_rows = [&](int chunk) {
+        if (chunk < nchunks) sweep_wait_rows(A.rowdone, A.rowdone_expected, img * ncb + chunk, &sh.timed_out);
         const int row = chunk * 64 + lane;
 #pragma unroll
         for (int j = 0; j <= SWEEP_AHEAD; ++j) rows[j] = 0ull;
@@ -893,9 +944,50 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(
         if (((last + 1) & 1) == group) { expand(last); flush(); }
     }
     if (tid == 0) {
-        num_keep[img] = min(count, max_keep);
+        num_keep[img] = sh.timed_out ? 0 : min(count, max_keep);
         if (done_out) done_out[img] = (count >= max_keep || n_dev[img] <= n_limit) ? 1 : 0;
     }
+}
+
+__global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(SweepArgs A) {
+    extern __shared__ unsigned long long sweep_dyn[];
+    __shared__ SweepShared sh;
+    nms_sweep_pipelined_block(A, blockIdx.x, sweep_dyn, sh);
+}
+
+// Mask and sweep in ONE launch.  The sweep of an image is a single workgroup walking 64-box chunks
+// (~1 us each: 0.2 ms for 188 chunks) on 8 of 256 CUs, and it only ever reads rows of blocks <= c + 3
+// at chunk c; the mask kernel fills the chip for 0.16 ms before it.  Here the first n_images
+// workgroups are the sweeps and all others compute the mask, ROW BLOCK BY ROW BLOCK (all images
+// abreast, a row block's 12 column segments next to each other), each wave counting its row block
+// up in `rowdone` when its words are stored (release); the sweep's stagers wait for the row block they
+// are about to load (acquire).  The early row blocks are the long ones (upper triangle), so the sweep
+// trails the mask by a few chunks at first and runs free for the rest: mask + sweep take about as
+// long as the longer of the two.  Workgroups are dispatched in index order, so the sweeps hold
+// n_images workgroup slots while the mask blocks flow through the rest of the chip: every wait ends.
+__global__ __launch_bounds__(SWEEP_BLOCK) void nms_mask_sweep_fused_kernel(MaskArgs M, SweepArgs S, int n_images,
+                                                                            int nrb, int nseg, int *rowdone) {
+    extern __shared__ unsigned long long sweep_dyn[];
+    __shared__ SweepShared sh;
+    if ((int)blockIdx.x < n_images) {
+        nms_sweep_pipelined_block(S, blockIdx.x, sweep_dyn, sh);
+        return;
+    }
+    // 16 waves = 4 mask blocks; mask block v = (rb * n_images + img) * nseg + seg
+    const int lane = threadIdx.x & 63, pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long v = ((long long)blockIdx.x - n_images) * (SWEEP_BLOCK / 64 / MASK_WAVES) + (pw / MASK_WAVES);
+    if (v >= (long long)nrb * n_images * nseg) return;
+    const int seg = (int)(v % nseg);
+    const int img = (int)((v / nseg) % n_images);
+    const int rb = (int)(v / ((long long)nseg * n_images));
+    float (*cbox)[5][64] = reinterpret_cast<float (*)[5][64]>(sweep_dyn);
+    nms_float4v (*cgeo)[64] = reinterpret_cast<nms_float4v (*)[64]>(reinterpret_cast<char *>(sweep_dyn) +
+                                                                     sizeof(float) * (SWEEP_BLOCK / 64) * 5 * 64);
+    nms_mask_block<true>(M, rb, seg, img, pw % MASK_WAVES, lane, cbox[pw], cgeo[pw]);
+    // this wave's words (and its bits of the summary and of diag_t) have been written through: once they
+    // are acknowledged, count the row block up
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(rowdone + (size_t)img * M.ncb + rb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *diag_t,
@@ -909,9 +1001,9 @@ int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *d
     const int sw = nms_summary_words(n_max);
     const size_t lds_p = ((size_t)max_keep + 64) * (sizeof(int) + sizeof(unsigned long long) * sw);
     if (nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ)) {
-        hipLaunchKernelGGL(nms_sweep_pipelined_kernel, dim3(n_images), dim3(SWEEP_BLOCK), lds_p, st,
-                           mask, diag_t, summ, sw, n_dev, n_max, ncb, max_keep, order, order_stride_img,
-                           keep, num_keep, boxes, box_stride_img, rois_padded, n_limit, done_in, done_out);
+        const SweepArgs S = {mask, diag_t, summ, sw, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
+                             boxes, box_stride_img, rois_padded, n_limit, done_in, done_out, nullptr, 0};
+        hipLaunchKernelGGL(nms_sweep_pipelined_kernel, dim3(n_images), dim3(SWEEP_BLOCK), lds_p, st, S);
         return check_launch();
     }
     if (lds > SWEEP_LDS_LIMIT) {
@@ -944,6 +1036,35 @@ int nms_probe_size(int n_max, int max_keep) {
     return (p * 2 <= (long long)n_max) ? (int)p : n_max;
 }
 
+// rowdone counters of the fused launch live behind the summary: [n_images * ceil(n_max / 64)] ints
+size_t nms_summary_alloc_words(int n_images, int n_max) {
+    return (size_t)n_images * n_max * nms_summary_words(n_max) + ((size_t)n_images * cdiv(n_max, 64) + 1) / 2;
+}
+
+static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n_dev, int n_max, int n_images,
+                            double thresh, unsigned long long *mask, unsigned long long *diag_t,
+                            unsigned long long *summ, int max_keep, const int *order, int order_stride_img,
+                            int *keep, int *num_keep, float *rois_padded, hipStream_t st) {
+    const int ncb = cdiv(n_max, 64), sw = nms_summary_words(n_max);
+    const int nseg = cdiv(ncb, MASK_SEG);
+    int *rowdone = reinterpret_cast<int *>(summ + (size_t)n_images * n_max * sw);
+    // summary and counters = 0 (one memset: they are contiguous)
+    if (hipMemsetAsync(summ, 0, sizeof(unsigned long long) * nms_summary_alloc_words(n_images, n_max), st) != hipSuccess)
+        return WSSDL_ERR_LAUNCH;
+    const MaskArgs M = {boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, sw, 0x7fffffff, 0, nullptr,
+                        NMS_DENSE_AHEAD};
+    const SweepArgs S = {mask, diag_t, summ, sw, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
+                         boxes, box_stride_img, rois_padded, 0x7fffffff, nullptr, nullptr, rowdone, nseg * MASK_WAVES};
+    const size_t lds_sweep = ((size_t)max_keep + 64) * (sizeof(int) + sizeof(unsigned long long) * sw);
+    const size_t lds_mask = (size_t)(SWEEP_BLOCK / 64) * (5 * 64 * sizeof(float) + 64 * sizeof(nms_float4v));
+    const long long vblocks = (long long)ncb * n_images * nseg;
+    const long long blocks = n_images + (vblocks + SWEEP_BLOCK / 64 / MASK_WAVES - 1) / (SWEEP_BLOCK / 64 / MASK_WAVES);
+    if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(nms_mask_sweep_fused_kernel, dim3((unsigned)blocks), dim3(SWEEP_BLOCK),
+                       lds_sweep > lds_mask ? lds_sweep : lds_mask, st, M, S, n_images, ncb, nseg, rowdone);
+    return check_launch();
+}
+
 int launch_nms_two_pass(const float *boxes, int box_stride_img, const int *n_dev, int n_max, int n_images,
                         double thresh, unsigned long long *mask, unsigned long long *diag_t,
                         unsigned long long *summ, int max_keep, const int *order, int order_stride_img,
@@ -952,6 +1073,10 @@ int launch_nms_two_pass(const float *boxes, int box_stride_img, const int *n_dev
     const int probe = done ? nms_probe_size(n_max, max_keep) : n_max;
     const int NO_LIMIT = 0x7fffffff;
     int rc;
+    if (probe >= n_max && tuning().nms_fused != 0 && nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) &&
+        n_max >= 2048)
+        return launch_nms_fused(boxes, box_stride_img, n_dev, n_max, n_images, thresh, mask, diag_t, summ, max_keep,
+                                order, order_stride_img, keep, num_keep, rois_padded, st);
     if (probe >= n_max) {
         if ((rc = launch_nms_mask(boxes, box_stride_img, n_dev, n_max, n_images, thresh, mask, diag_t, summ, st,
                                   NO_LIMIT, 0, nullptr, max_keep)))

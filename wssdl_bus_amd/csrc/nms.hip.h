@@ -34,6 +34,9 @@ int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int to
 // summ (optional): per image [n_max, nms_summary_words(n_max)] u64, bit w of a row = its mask
 // word w is non-zero (zeroed here); lets the sweep skip the loads of all-zero words.
 int nms_summary_words(int n_max);
+// u64 words to allocate for `summ` of launch_nms_two_pass: the summary plus the row-block counters of
+// the fused mask + sweep launch behind it
+size_t nms_summary_alloc_words(int n_images, int n_max);
 int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, int n_max,
                     int n_images, double thresh, unsigned long long *mask,
                     unsigned long long *diag_t, unsigned long long *summ, hipStream_t st,

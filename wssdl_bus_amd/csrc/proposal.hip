@@ -138,7 +138,7 @@ static size_t carve_proposal(void *ws, int N, int M, int topn, ProposalWs *out) 
     w.kept = c.take<int>((size_t)N * ((size_t)topn + 64));
     w.sorted_boxes = c.take<float>((size_t)N * topn * 4);
     w.mask = c.take<unsigned long long>((size_t)N * topn * ncb);
-    w.summ = c.take<unsigned long long>((size_t)N * topn * nms_summary_words(topn));
+    w.summ = c.take<unsigned long long>(nms_summary_alloc_words(N, topn));
     if (out) *out = w;
     return c.off;
 }
