@@ -313,6 +313,8 @@ def main():
     ap.add_argument("--padded-rois", action="store_true",
                     help="fixed-shape RoI blob (dead rows carry batch index -1): no device->host copy between "
                          "the backbone and the loss; the per-RoI head then runs on the padded row count")
+    ap.add_argument("--roi-bwd-plan", type=int, default=-1,
+                    help="force a plan of the list-driven RoI-pool backward (wssdl_set_tuning roi_bwd_plan; -1 = automatic)")
     args = ap.parse_args()
 
     # before MIOpen initialises.  No usable find-db -> no find mode (a search costs minutes per rank)
@@ -331,6 +333,8 @@ def main():
         sys.exit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
     torch.backends.cudnn.benchmark = not args.no_miopen_benchmark
     _lib.lib()
+    if args.roi_bwd_plan >= 0:
+        _lib.set_tuning("roi_bwd_plan", args.roi_bwd_plan)
     ctx = DistContext()
     if ctx.world_size != args.gpus:
         if ctx.world_size == 1 and args.gpus > 1:

@@ -196,3 +196,32 @@ def test_fused_mil_loss_values_and_gradients(torch_cuda, mode):
             assert torch.equal((g_f != 0).any(dim=1), (g_t != 0).any(dim=1))
     finally:
         cfg.TRAIN.WS_LOSS_USE_ADAPTIVE_SCALE_FACTOR, cfg.FUSED_LOSS = old
+
+
+def test_wide_heads_take_the_torch_chain_instead_of_failing(torch_cuda):
+    """The fused loss ops serve 2..32 classes (multi-task) and 3..8 (MIL); a wider head must fall back to
+    the chain of torch ops, not raise INVALID_ARGUMENT."""
+    torch = torch_cuda
+    from wssdl_bus_amd.fast_rcnn import train_bus
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.mil import core as mil_core
+    rs = np.random.RandomState(40)
+    N, H, W, A, K = 1, 9, 11, 9, 40
+    rpn_cls, rpn_box, cls, box, rpn_data, roi_data = _inputs(torch, rs, N, H, W, A, 24, 24, K=K)
+    layers = {"rpn_cls_score": rpn_cls, "rpn_bbox_pred": rpn_box, "cls_score": cls, "bbox_pred": box,
+              "rpn-data": rpn_data, "roi-data": roi_data,
+              "rpn_cls_score_reshape": rpn_cls.reshape(N, H, W, 2, A).permute(0, 4, 1, 2, 3).reshape(N, A * H, W, 2)}
+    assert cfg.get("FUSED_LOSS", True)
+    l = train_bus.supervised_loss(layers, [])
+    want = _oracle_terms(rpn_cls, rpn_box, cls, box, rpn_data, roi_data, None)
+    got = np.array([float(l[k]) for k in ("rpn_cross_entropy", "rpn_loss_box", "cross_entropy", "loss_box")])
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
+    l["loss"].backward()
+    assert cls.grad is not None and bool(torch.isfinite(cls.grad).all())
+    # MIL with 12 classes: selection op + torch CE
+    logits = torch.tensor(rs.normal(size=(30, 12)), dtype=torch.float32, device="cuda", requires_grad=True)
+    inds = torch.tensor(rs.randint(0, 2, size=30).astype(np.float32), device="cuda")
+    lab = torch.tensor([1, 2], dtype=torch.int32, device="cuda")
+    m = train_bus.mil_loss(logits, inds, lab, 2, 0, [mil_core.get_mal_max_logit, mil_core.get_mal_max_logit])
+    m.backward()
+    assert bool(torch.isfinite(m)) and bool(torch.isfinite(logits.grad).all())

@@ -70,7 +70,8 @@ def mil_loss(cls_score_ws, batch_inds, mil_label, n_bags, global_step, funcs, co
         scale = 1.0 - 0.99 * (0.9 ** (int(global_step) // 2000))      # exponential_decay, staircase
     else:
         scale = cfg.TRAIN.WS_LOSS_SCALE_FACTOR
-    if cls_score_ws.is_cuda and cfg.get('FUSED_LOSS', True):
+    # (the fused MIL op takes 3..8 classes, the reference has 3; anything else: selection op + torch CE)
+    if cls_score_ws.is_cuda and cfg.get('FUSED_LOSS', True) and 3 <= cls_score_ws.shape[1] <= 8:
         # selection + weighted CE + mean as one device op with its own backward (f1)
         prior = [0.0, float(cfg.TRAIN.WS_MAL_PCT), 1.0 - float(cfg.TRAIN.WS_MAL_PCT)]
         return mil_core.mil_loss_device(cls_score_ws, batch_inds, 0.0, mil_label, n_bags, funcs, prior, scale)
@@ -111,7 +112,9 @@ def l2_weight_decay(params):
 
 
 def supervised_loss(layers, params, n_sup=None):
-    if cfg.get('FUSED_LOSS', True) and layers['cls_score'].is_cuda and 'rpn_cls_score' in layers:
+    # (the device op takes 2 <= K <= 32 classes; wider heads take the torch chain)
+    if cfg.get('FUSED_LOSS', True) and layers['cls_score'].is_cuda and 'rpn_cls_score' in layers \
+            and 2 <= layers['cls_score'].shape[1] <= 32:
         # the four terms and their gradients as one device op (csrc/loss.hip)
         from .loss_op import multi_task_loss, TERMS
         terms = multi_task_loss(layers['rpn_cls_score'], layers['rpn_bbox_pred'], layers['cls_score'],
