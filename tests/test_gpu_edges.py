@@ -749,17 +749,20 @@ def test_fused_mask_sweep_launch_equals_two_launches(torch_cuda):
     prob = np.concatenate((p[..., 0], p[..., 1]), axis=-1)
     pred = rs.normal(0, 0.2, size=(N, H, W, 4 * A)).astype(np.float32)
     pred[1] = 0.0                                   # the anchors themselves: neighbours suppress each other
-    pred[2] *= 4.0                                  # wild boxes: hardly any suppression
+    pred[2] *= 4.0                                  # wild boxes, mostly clipped to the image border
     info[3, :2] = [8, 8]                            # every box filtered out (min size): no candidates
     old = cfg.TRAIN.RPN_NMS_THRESH
+    seen = set()
     try:
         for t in (0.7, 0.3):
             cfg.TRAIN.RPN_NMS_THRESH = t
             out = both(prob, pred, info)
             counts = [int((out[:, 0] == i).sum()) for i in range(N)]
-            assert counts[3] == 0 and counts[2] == 2000 and 0 < counts[1] <= 2000
+            assert counts[3] == 0 and all(0 < c <= 2000 for i, c in enumerate(counts) if i != 3)
+            seen.update(counts)
             for _ in range(3):                      # repeatable (the waits never change the result)
                 with _lib.tuned(nms_fused=1):
                     assert np.array_equal(proposal_layer(prob, pred, info, True, False), out)
     finally:
         cfg.TRAIN.RPN_NMS_THRESH = old
+    assert 2000 in seen and any(0 < c < 2000 for c in seen)      # sweeps that stop early and sweeps that walk every chunk
