@@ -120,6 +120,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--roi-bwd-plan", type=int, default=-1, help="force a backward plan (wssdl_set_tuning)")
     ap.add_argument("--check", action="store_true",
                     help="before timing: the pair's outputs on this RoI set against the C oracle, bit for bit "
                          "(one supervised and one weak image; tests/test_gpu_roi_compact.py)")
@@ -132,6 +133,9 @@ def main():
         checked, plans = roofline_set_parity(torch)
         print(json.dumps(dict(check="top, argmax, bottom_diff == C oracle", rois_per_image=checked, plans=plans)))
     rois, tag = load_rois()
+    if args.roi_bwd_plan >= 0:
+        from wssdl_bus_amd import _lib
+        _lib.set_tuning("roi_bwd_plan", args.roi_bwd_plan)
     N = int(rois[:, 0].max()) + 1
     ops, meta = run(rois, N, 38, 63, 1024, args.iters, args.warmup)
     print(json.dumps(dict(roi_set=tag, meta=meta, ops=ops)))

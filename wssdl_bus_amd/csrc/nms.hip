@@ -790,14 +790,18 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
     const int hw = wave - SWEEP_FIRST_HELPER;
     const int group = helper ? (hw & 1) : (wave & 1);
     const int hidx = (hw >> 1) * 64 + lane;                   // index inside the helper group
-    unsigned long long rows[SWEEP_AHEAD + 1];                 // stager: T + words of one chunk's rows
-    unsigned long long pend[SWEEP_LH];                        // helper: one word of kept boxes
+    // A wave has ONE role, so the loop-carried 64-bit registers of the three roles share one array
+    // (separate arrays are all live across the loop for every wave: 95 VGPRs instead of 77):
+    //   stager  rows[0..4]    T + words of one chunk's rows
+    //   helper  pend[0..6]    one word of kept boxes
+    //   scribe  out_sum[0..3] summary of one kept box, fetched but not yet stored
+    static_assert(SWEEP_AHEAD + 1 <= SWEEP_LH && 4 <= SWEEP_LH, "roles share pend[]");
+    unsigned long long pend[SWEEP_LH];
+    unsigned long long (&rows)[SWEEP_LH] = pend;
+    unsigned long long (&out_sum)[SWEEP_LH] = pend;
     // scribe: outputs of one kept box, fetched but not yet stored
     int out_pos = -1, out_idx = 0;
     float out_box[4] = {0.f, 0.f, 0.f, 0.f};
-    unsigned long long out_sum[4] = {0ull, 0ull, 0ull, 0ull};
-#pragma unroll
-    for (int j = 0; j <= SWEEP_AHEAD; ++j) rows[j] = 0ull;
 #pragma unroll
     for (int j = 0; j < SWEEP_LH; ++j) pend[j] = 0ull;
 
@@ -965,7 +969,9 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(SweepA
 // trails the mask by a few chunks at first and runs free for the rest: mask + sweep take about as
 // long as the longer of the two.  Workgroups are dispatched in index order, so the sweeps hold
 // n_images workgroup slots while the mask blocks flow through the rest of the chip: every wait ends.
-__global__ __launch_bounds__(SWEEP_BLOCK) void nms_mask_sweep_fused_kernel(MaskArgs M, SweepArgs S, int n_images,
+// (capped at 64 VGPRs: two 16-wave workgroups per CU, so that the mask role keeps 8 waves per SIMD -- 0.20 ->
+// 0.17 ms for the mask role; the cap costs the sweep role five spilled dwords, no measurable time)
+__global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void nms_mask_sweep_fused_kernel(MaskArgs M, SweepArgs S, int n_images,
                                                                             int nrb, int nseg, int *rowdone) {
     extern __shared__ unsigned long long sweep_dyn[];
     __shared__ SweepShared sh;
