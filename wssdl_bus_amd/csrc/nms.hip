@@ -1079,8 +1079,9 @@ int launch_nms_two_pass(const float *boxes, int box_stride_img, const int *n_dev
     const int probe = done ? nms_probe_size(n_max, max_keep) : n_max;
     const int NO_LIMIT = 0x7fffffff;
     int rc;
+    // (n_images <= 64: the sweeps must leave workgroup slots for the mask blocks they wait for)
     if (probe >= n_max && tuning().nms_fused != 0 && nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) &&
-        n_max >= 2048)
+        n_max >= 2048 && n_images <= 64)
         return launch_nms_fused(boxes, box_stride_img, n_dev, n_max, n_images, thresh, mask, diag_t, summ, max_keep,
                                 order, order_stride_img, keep, num_keep, rois_padded, st);
     if (probe >= n_max) {
