@@ -1,3 +1,6 @@
+#!/bin/bash
+# Time (tools/bwd_fixed_sweep.py) and HBM-side reads (FETCH_SIZE, one rocprofv3 pass per plan) of a few plans of the
+# RoI-pool backward walk on the fixed roofline set.  usage: bash tools/pmc_bwd_plans.sh   -> gpurun_out/r3j/
 OUT=gpurun_out/r3j; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 120 python3 tools/bwd_fixed_sweep.py --plans 11,13,6,7,8,25,9,17 > $OUT/sweep.log 2>&1; cat $OUT/sweep.log
