@@ -19,21 +19,23 @@ from ..rpn_msr.proposal_target_layer_tf_bus import (proposal_target_layer as pro
 
 
 def layer(op):
-    """network.py:21-40: feed the current inputs to `op`, record the output under `name`,
-    make it the next input, return self for chaining."""
-    def layer_decorated(self, *args, **kwargs):
-        name = kwargs.setdefault('name', self.get_unique_name(op.__name__))
-        if len(self.inputs) == 0:
-            raise RuntimeError('No input variables found for layer %s.' % name)
-        elif len(self.inputs) == 1:
-            layer_input = self.inputs[0]
-        else:
-            layer_input = list(self.inputs)
-        layer_output = op(self, layer_input, *args, **kwargs)
-        self.layers[name] = layer_output
-        self.feed(layer_output)
-        return self
-    return layer_decorated
+    """The chaining protocol of network.py:21-40 as a decorator: a layer method consumes whatever was
+    fed last (one tensor, or a list when several were fed), its result is stored in ``self.layers``
+    under ``name`` (auto-numbered from the method's name when the caller gives none) and becomes
+    the fed input of the next call; the call returns the network so that calls chain."""
+    import functools
+
+    @functools.wraps(op)
+    def chained(net, *args, **kwargs):
+        if 'name' not in kwargs:
+            kwargs['name'] = net.get_unique_name(op.__name__)
+        fed = net.inputs
+        if not fed:
+            raise RuntimeError('No input variables found for layer %s.' % kwargs['name'])
+        result = op(net, fed[0] if len(fed) == 1 else list(fed), *args, **kwargs)
+        net._register(kwargs['name'], result)
+        return net
+    return chained
 
 
 def _blob(out):
@@ -52,30 +54,35 @@ def _first(x):
 
 
 class Network(object):
+    """``layers``: name -> tensor (or tuple of tensors); ``inputs``: what the next layer call consumes."""
+
     def __init__(self, inputs=None):
         self.inputs = []
         self.layers = dict(inputs or {})
 
+    def _lookup(self, key):
+        if key not in self.layers:
+            raise KeyError('Unknown layer name fed: %s' % key)
+        return self.layers[key]
+
+    def _register(self, name, result):
+        self.layers[name] = result
+        self.inputs = [result]
+
     def feed(self, *args):
+        """network.py:54-66: names are resolved through ``layers``, anything else is fed as it is."""
         assert len(args) != 0
-        self.inputs = []
-        for l in args:
-            if isinstance(l, str):
-                try:
-                    l = self.layers[l]
-                except KeyError:
-                    raise KeyError('Unknown layer name fed: %s' % l)
-            self.inputs.append(l)
+        self.inputs = [self._lookup(a) if isinstance(a, str) else a for a in args]
         return self
 
     def get_output(self, l):
-        try:
-            return self.layers[l]
-        except KeyError:
-            raise KeyError('Unknown layer name fed: %s' % l)
+        """network.py:68-74."""
+        return self._lookup(l)
 
     def get_unique_name(self, prefix):
-        return '%s_%d' % (prefix, sum(t.startswith(prefix) for t in self.layers) + 1)
+        """network.py:76-78: ``<prefix>_<k>``, k = 1 + the number of layers whose name starts with prefix."""
+        taken = [n for n in self.layers if n.startswith(prefix)]
+        return '%s_%d' % (prefix, len(taken) + 1)
 
     # ------------------------------------------------------------ hot path ---
     @layer
