@@ -20,7 +20,10 @@ ap.add_argument("--images", type=int, default=8)
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--pred-scale", type=float, default=1.0,
                 help="scale of the box deltas: 0 = the anchors themselves (heavy suppression: the sweep walks every chunk)")
+ap.add_argument("--nms-thresh", type=float, default=0.7, help="0.3 with --pred-scale 0.3: fewer than 2000 boxes survive, the sweep walks every chunk")
 args = ap.parse_args()
+from wssdl_bus_amd.fast_rcnn.config import cfg  # noqa: E402
+cfg.TRAIN.RPN_NMS_THRESH = args.nms_thresh
 N = args.images
 info = torch.tensor([[600, 1000, 1.0, 1.0]] * N, device="cuda")
 prob, pred = synth_rpn(N, 38, 63, 9, 3)
@@ -34,4 +37,4 @@ for rep in range(2):
                 ref = [t.clone() for t in out]
             assert all(torch.equal(a, b) for a, b in zip(out, ref))
             ms = timeit(lambda: proposal_layer_padded(prob, pred, info, True), args.iters, warmup=5)
-        print(json.dumps(dict(nms_fused=fused, proposal_layer_ms=round(ms, 4), images=N, pred_scale=args.pred_scale, kept=[int(v) for v in out[1].tolist()])))
+        print(json.dumps(dict(nms_fused=fused, proposal_layer_ms=round(ms, 4), images=N, pred_scale=args.pred_scale, nms_thresh=args.nms_thresh, kept=[int(v) for v in out[1].tolist()])))
