@@ -1,0 +1,66 @@
+"""CPU: the measurement helpers that turn profiler output into the committed summaries."""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _trace(path, rows):
+    with open(path, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Kind", "Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+        for name, s, e in rows:
+            w.writerow(["KERNEL_DISPATCH", name, s * 1000, e * 1000])       # units of the test: microseconds
+
+
+def test_trace_gaps_timed_steps_only(tmp_path):
+    """tools/trace_gaps.py: steps are delimited by the marker kernel, warm-up steps (with MIOpen's naive_conv
+    reference kernels) are left out of the per-kernel summary, busy time merges overlapping kernels, and a
+    naive_conv kernel INSIDE a timed step fails the script."""
+    d = tmp_path / "prof" / "run"
+    d.mkdir(parents=True)
+    rows, t = [], 0
+    for step in range(6):                                   # 2 warm-up + 4 timed
+        rows.append(("wssdl::proposal_decode_kernel(float const*)", t, t + 10))
+        if step < 2:
+            rows.append(("naive_conv_ab_nonpacked_fwd_nhwc_float_double_float", t + 10, t + 5000))
+            t += 5000
+        rows.append(("backbone_kernel", t + 20, t + 520))    # 10 us gap after the marker
+        rows.append(("overlapping_kernel_on_another_queue", t + 100, t + 300))
+        rows.append(("wssdl::roi_pool_fwd_rows_kernel<4>", t + 600, t + 1000))   # 80 us gap
+        t += 1000
+    _trace(str(d / "1_kernel_trace.csv"), rows)
+    out_csv = str(tmp_path / "stats.csv")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "trace_gaps.py"), str(tmp_path / "prof"), "--steps", "4",
+           "--warmup", "2", "--stats-csv", out_csv]
+    res = json.loads(subprocess.check_output(cmd).decode())
+    assert res["intervals"] == 3 and res["naive_conv_kernels_in_timed_steps"] == 0
+    assert res["naive_conv_kernels_in_whole_process"] == 2
+    st = res["steps"][0]
+    assert st["kernels"] == 4 and abs(st["busy_ms"] - (10 + 500 + 400) / 1e3) < 1e-9
+    assert st["top_gaps"][0]["us"] == 80.0 and "backbone_kernel" in st["top_gaps"][0]["after"]
+    assert st["top_gaps"][1]["us"] == 10.0 and abs(st["idle_ms"] - 0.09) < 1e-9
+    names = [r["Name"] for r in csv.DictReader(open(out_csv))]
+    assert names[0] == "backbone_kernel" and not any("naive" in n for n in names)
+    # a naive_conv kernel inside a timed step: non-zero exit
+    rows.append(("naive_conv_ab_nonpacked_fwd_nhwc_float_double_float", 12500, 12600))
+    _trace(str(d / "1_kernel_trace.csv"), rows)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"naive_conv" in p.stderr
+
+
+def test_bench_byte_models_agree_with_the_roofline_leg():
+    """bench.py and tools/roofline_leg.py state the same byte counts: 8 B per pooled element in SURVEY 8(d)'s
+    layout, 5 B moved by the 1-byte arg-max pair, plus the feature map once."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    import roofline_leg
+    m = dict(N=8, H=38, W=63, C=1024, R=8512)
+    for op in ("roi_pool_forward", "roi_pool_backward"):
+        assert bench.alg_bytes(op, m) == roofline_leg.alg_bytes(op, **m)
+        assert roofline_leg.alg_bytes(op, **m) - roofline_leg.moved_bytes(op, **m) == m["R"] * 49 * m["C"] * 3
+    assert roofline_leg.moved_bytes("roi_pool_backward", **m) == 2213937152          # the figure in DESIGN.md / profiles
