@@ -410,6 +410,21 @@ WSSDL_API int wssdl_image_to_blob(const void *im, int im_is_f64, int h, int w, d
                      float *blob, int index, int n_images, int Hmax, int Wmax, wssdl_stream_t stream);
 WSSDL_API int wssdl_flip_boxes(float *boxes, int n, int stride, float width, wssdl_stream_t stream);
 
+/* ---------------------------------------------------------------------- f3 ---
+ * The post-detection step of the test path, fast_rcnn/test_bus.py:360-401, batched over the classes:
+ * for every class j = 1 .. num_classes-1 the rows with scores[r, j] > score_thresh, greedy NMS at
+ * nms_thresh with the cpu_nms rule (utils/cython_nms) on (boxes[r, 4j:4j+4], scores[r, j]) in descending
+ * score order, then the cap: if more than max_per_image (> 0) detections are left over all classes, only
+ * those with a score >= the max_per_image-th largest stay (ties stay, like the reference's `>=`).
+ *   scores [R, num_classes] f32, boxes [R, 4 * num_classes] f32 (class-wise decoded boxes);
+ *   dets   [num_classes-1, R, 5] f32: row p of class j-1 = (x1, y1, x2, y2, score) of its p-th kept
+ *          detection in descending score order; counts [num_classes-1] i32 = rows that survive the cap.
+ * One set of launches for all classes, no host read-back.  num_classes <= 65. */
+WSSDL_API size_t wssdl_post_detections_workspace_bytes(int R, int num_classes);
+WSSDL_API int wssdl_post_detections(const float *scores, const float *boxes, int R, int num_classes,
+                     float score_thresh, double nms_thresh, int max_per_image, float *dets,
+                     int32_t *counts, void *workspace, size_t workspace_bytes, wssdl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -766,3 +766,70 @@ def test_fused_mask_sweep_launch_equals_two_launches(torch_cuda):
     finally:
         cfg.TRAIN.RPN_NMS_THRESH = old
     assert 2000 in seen and any(0 < c < 2000 for c in seen)      # sweeps that stop early and sweeps that walk every chunk
+
+
+def test_post_detections_device_op_edges(torch_cuda):
+    """wssdl_post_detections (f3 as one C-ABI call) against the step-by-step form (which
+    test_post_detection_nms_matches_oracle pins to the oracle) and against the oracle directly: more
+    classes, a class with no row above the score threshold, no cap, a cap whose threshold score is tied
+    (`>=` keeps the ties), a single row, no rows."""
+    torch = torch_cuda
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.fast_rcnn.test_bus import post_detections_device, postprocess_detections
+    rs = np.random.RandomState(12)
+
+    def oracle(scores, boxes, K, thresh, cap):
+        want = {}
+        for j in range(1, K):
+            inds = np.where(scores[:, j] > thresh)[0]
+            d = np.hstack((boxes[inds, 4 * j:4 * j + 4], scores[inds, j:j + 1])).astype(np.float32)
+            want[j] = d[O.nms(d, cfg.TEST.NMS)] if len(d) else d
+        alls = np.hstack([want[j][:, 4] for j in range(1, K)]) if K > 1 else np.zeros(0)
+        if cap > 0 and len(alls) > cap:
+            th = np.sort(alls)[-cap]
+            for j in range(1, K):
+                want[j] = want[j][want[j][:, 4] >= th]
+        return want
+
+    def case(R, K, thresh, cap, tie=False, dead_class=None):
+        ctr = rs.uniform(50, 900, size=(R, 1, 2)) * [1.0, 0.6] + rs.normal(0, 6, size=(R, K, 2))
+        wh = rs.uniform(30, 220, size=(R, K, 2))
+        boxes = np.concatenate((ctr - wh / 2, ctr + wh / 2), axis=2).reshape(R, 4 * K).astype(np.float32)
+        scores = rs.uniform(0, 1, size=(R, K)).astype(np.float32)
+        if tie and R > 8:
+            scores[:8, 1] = np.float32(0.625)                     # eight equal scores around the cap's threshold
+            scores[8:, 1] = np.minimum(scores[8:, 1], np.float32(0.6))
+            scores[:, 2:] = np.minimum(scores[:, 2:], np.float32(0.5)) if K > 2 else scores[:, 2:]
+            boxes[:8, 4:8] = boxes[:8, 4:8] + np.arange(8, dtype=np.float32)[:, None] * 400     # far apart: none suppressed
+        if dead_class is not None:
+            scores[:, dead_class] = np.float32(0.01)
+        st, bt = torch.from_numpy(scores).cuda(), torch.from_numpy(boxes).cuda()
+        want = oracle(scores, boxes, K, thresh, cap)
+        got = postprocess_detections(st, bt, K, thresh=thresh, max_per_image=cap)
+        old = cfg.TEST.FUSED_POST_DETECTIONS
+        try:
+            cfg.TEST.FUSED_POST_DETECTIONS = False
+            slow = postprocess_detections(st, bt, K, thresh=thresh, max_per_image=cap)
+        finally:
+            cfg.TEST.FUSED_POST_DETECTIONS = old
+        def canon(a):                     # rows of EQUAL score come in an order the reference leaves to argsort
+            a = np.asarray(a)
+            return a[np.lexsort((a[:, 0], a[:, 1], -a[:, 4]))] if tie and len(a) else a
+        for j in range(1, K):
+            assert np.array_equal(canon(got[j].cpu().numpy()), canon(want[j])), (R, K, cap, j)
+            assert np.array_equal(canon(slow[j].cpu().numpy()), canon(want[j])), (R, K, cap, j, "step-by-step")
+            g = got[j].cpu().numpy()
+            assert np.all(g[:-1, 4] >= g[1:, 4])                  # descending scores either way
+        return want
+
+    case(300, 3, 0.05, 300)
+    case(300, 3, 0.05, 0)                                  # no cap
+    w = case(300, 6, 0.3, 25, dead_class=4)
+    assert len(w[4]) == 0 and sum(len(v) for v in w.values()) >= 25
+    w = case(120, 3, 0.05, 5, tie=True)                    # cap 5 inside eight tied scores: all eight stay
+    assert len(w[1]) == 8 and len(w[2]) == 0
+    case(1, 3, 0.05, 10)
+    case(700, 2, 0.5, 50)
+    # no rows at all: zero counts, nothing launched
+    dets, counts = post_detections_device(torch.zeros((0, 3), device="cuda"), torch.zeros((0, 12), device="cuda"), 3)
+    assert counts.cpu().tolist() == [0, 0]

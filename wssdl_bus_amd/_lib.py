@@ -70,6 +70,8 @@ SYMBOLS = {
     "wssdl_image_prep": (_i, [_vp, _i, _i, _i, _i, _i, _f, _i, _f, _d, _vp, _vp, _sz, _vp]),
     "wssdl_image_to_blob": (_i, [_vp, _i, _i, _i, _d, _i, _vp, _i, _i, _i, _i, _vp]),
     "wssdl_flip_boxes": (_i, [_vp, _i, _i, _f, _vp]),
+    "wssdl_post_detections_workspace_bytes": (_sz, [_i, _i]),
+    "wssdl_post_detections": (_i, [_vp, _vp, _i, _i, _f, _d, _i, _vp, _vp, _vp, _sz, _vp]),
     "wssdl_mil_select": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "wssdl_mil_loss_forward": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp]),
     "wssdl_mil_loss_backward": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp]),

@@ -68,6 +68,8 @@ __C.TEST = AttrDict()
 __C.TEST.NMS = 0.3                                  # :238
 __C.TEST.CLS_AGNOSTIC_NMS = False                   # :241
 __C.TEST.BBOX_REG = True                            # :248
+# (addition) the post-detection step (test_bus.py:360-401) as one device op when the tensors are on the GPU
+__C.TEST.FUSED_POST_DETECTIONS = True
 __C.TEST.RPN_NMS_THRESH = 0.7                       # :257
 __C.TEST.RPN_PRE_NMS_TOP_N = 6000                   # :259
 __C.TEST.RPN_POST_NMS_TOP_N = 300                   # :262

@@ -46,9 +46,37 @@ def im_detect(net, data, im_info):
 
 
 @torch.no_grad()
+def post_detections_device(scores, boxes, num_classes, thresh=0.05, max_per_image=300):
+    """The whole post-detection step as one C-ABI call (wssdl_post_detections: one set of launches for all
+    classes, no read-back): returns (dets [K-1, R, 5] f32, counts [K-1] i32) on the GPU; rows
+    dets[j-1, :counts[j-1]] are class j's detections in descending score order."""
+    from .. import _lib
+    s = scores.to(torch.float32).contiguous()
+    b = boxes.to(torch.float32).contiguous()
+    R, K = s.shape
+    L = _lib.lib()
+    dets = torch.empty((K - 1, max(R, 1), 5), dtype=torch.float32, device=s.device)
+    counts = torch.empty((K - 1,), dtype=torch.int32, device=s.device)
+    with torch.cuda.device(s.device):
+        n = L.wssdl_post_detections_workspace_bytes(R, K)
+        ws = torch.empty((n,), dtype=torch.uint8, device=s.device)
+        _lib.check(L.wssdl_post_detections(_lib.ptr(s), _lib.ptr(b), R, K, float(thresh), float(cfg.TEST.NMS),
+                                           int(max_per_image), _lib.ptr(dets), _lib.ptr(counts), _lib.ptr(ws), n,
+                                           _lib.stream()), "wssdl_post_detections")
+    return dets, counts
+
+
+@torch.no_grad()
 def postprocess_detections(scores, boxes, num_classes, thresh=0.05, max_per_image=300):
     """test_bus.py:360-401: per class j >= 1 keep scores > thresh, NMS at cfg.TEST.NMS, then cap
-    the image at max_per_image detections over all classes.  Returns {j: dets [n,5]} (GPU)."""
+    the image at max_per_image detections over all classes.  Returns {j: dets [n,5]} (GPU).
+    On the GPU this is one device op (post_detections_device) followed by ONE read-back of the per-class
+    counts; the class-agnostic variant and CPU tensors take the step-by-step form below."""
+    if scores.is_cuda and not cfg.TEST.CLS_AGNOSTIC_NMS and scores.shape[1] == num_classes and num_classes <= 65 \
+            and cfg.TEST.get("FUSED_POST_DETECTIONS", True):
+        dets, counts = post_detections_device(scores, boxes, num_classes, thresh, max_per_image)
+        n = counts.cpu().tolist()
+        return {j: dets[j - 1, :n[j - 1]] for j in range(1, num_classes)}
     out = {}
     for j in range(1, num_classes):
         inds = torch.nonzero(scores[:, j] > thresh).reshape(-1)
