@@ -25,6 +25,14 @@ int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int to
                      int *sorted_index, int *n_sorted, void *scratch, size_t scratch_bytes,
                      hipStream_t st);
 
+// The same result by one device-wide radix sort of all keys of all images (order_sort.hip): faster than the
+// ranking above whenever it applies (M <= 65 535).  `valid` [n_images] i32 pre-zeroed counters; scratch =
+// order_sort_scratch_bytes (may alias memory that is only written after the ordering).
+bool order_sort_supported(int M, int n_images);
+size_t order_sort_scratch_bytes(int n_images, int M);
+int launch_order_sort(const unsigned long long *keys, int M, int n_images, int topn, int *sorted_index, int *n_sorted,
+                      int *valid, void *scratch, size_t scratch_bytes, hipStream_t st);
+
 // boxes: per image [n_max, 4] f32 in score order (image stride box_stride_img floats);
 // mask: per image [n_max, ceil(n_max/64)] u64, upper triangle written -- every word when the sweep
 // for (n_max, max_keep) is the general one; only the non-zero words and the band next to the diagonal

@@ -196,8 +196,13 @@ static int proposal_layer_impl(int from_logits, const float *rpn_cls_prob, const
                        min_size, from_logits, boxes, w.keys, sidx, (long long)N * topn, nsorted, w.cand_fill,
                        rois_padded, (long long)N * pitch * 5);
     if ((rc = check_launch())) return rc;
-    if ((rc = launch_rank_topk(w.keys, M, N, topn, w.cand, w.thresh, w.cand_fill, sidx, nsorted, w.mask,
-                               sizeof(unsigned long long) * (size_t)N * topn * cdiv(topn, 64), st)))
+    // order of the candidates: one device-wide radix sort of all keys (order_sort.hip) when it applies, else the
+    // hand-written select + sample sort (nms.hip).  Scratch = the suppression matrix, which is written later.
+    const size_t mask_bytes = sizeof(unsigned long long) * (size_t)N * topn * cdiv(topn, 64);
+    if (tuning().topk_sort != 0 && order_sort_supported(M, N) && order_sort_scratch_bytes(N, M) <= mask_bytes) {
+        if ((rc = launch_order_sort(w.keys, M, N, topn, sidx, nsorted, w.cand_fill, w.mask, mask_bytes, st))) return rc;
+    } else if ((rc = launch_rank_topk(w.keys, M, N, topn, w.cand, w.thresh, w.cand_fill, sidx, nsorted, w.mask, mask_bytes,
+                                      st)))
         return rc;
     hipLaunchKernelGGL(proposal_gather_kernel, dim3(cdiv(topn, 256), N), dim3(256), 0, st, boxes,
                        sidx, nsorted, M, topn, w.sorted_boxes);
