@@ -1177,8 +1177,11 @@ extern "C" int wssdl_nms(const float *dets, int n, double thresh, int max_keep, 
                        w.n_sorted, w.cand_fill);
     int rc = check_launch();
     if (rc) return rc;
-    rc = launch_rank_topk(w.keys, n, 1, n, w.cand, w.thresh, w.cand_fill, w.order, w.n_sorted, w.mask,
-                          sizeof(unsigned long long) * (size_t)n * cdiv(n, 64), st);
+    const size_t mask_bytes = sizeof(unsigned long long) * (size_t)n * cdiv(n, 64);
+    if (tuning().topk_sort != 0 && order_sort_supported(n, 1) && order_sort_scratch_bytes(1, n) <= mask_bytes)
+        rc = launch_order_sort(w.keys, n, 1, n, w.order, w.n_sorted, w.cand_fill, w.mask, mask_bytes, st);
+    else
+        rc = launch_rank_topk(w.keys, n, 1, n, w.cand, w.thresh, w.cand_fill, w.order, w.n_sorted, w.mask, mask_bytes, st);
     if (rc) return rc;
     hipLaunchKernelGGL(nms_gather_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dets, w.order,
                        w.n_sorted, n, w.boxes);
