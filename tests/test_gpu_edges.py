@@ -836,18 +836,27 @@ def test_post_detections_device_op_edges(torch_cuda):
 
 
 def test_order_sort_equals_hand_written_ranking(torch_cuda):
-    """The candidates' order by the device-wide radix sort (order_sort.hip, the default) against the hand-written
-    select + sample sort (nms.hip): identical blobs and identical sorted candidate lists -- train and test mode,
-    1-8 images, duplicated scores (ties go to the higher index either way), images with few or no candidates."""
+    """The candidates' order by sorted runs + cross ranks (order_sort.hip, the default), by the device-wide library
+    sort and by the hand-written select + sample sort (nms.hip): identical blobs and identical sorted candidate
+    lists -- train and test mode, 1-8 images, duplicated scores (ties go to the higher index either way), images
+    with few or no candidates, scores that follow the anchor index (a run's keys then all fall into one gap of
+    its neighbour's: the galloping search), a map with fewer anchors than one run."""
     torch = torch_cuda
     from wssdl_bus_amd import _lib
     from wssdl_bus_amd.rpn_msr.proposal_layer_tf_bus import proposal_layer_padded
     assert _lib.get_tuning("topk_sort") == 1
     rs = np.random.RandomState(31)
-    for N, (H, W), train in ((8, (38, 63), True), (1, (63, 100), False), (3, (37, 62), True), (2, (12, 17), False)):
+    # (8, 1 and 12 images of this size take the rank kernel with 4, 2 and 8 own keys per thread)
+    for N, (H, W), train in ((8, (38, 63), True), (1, (63, 100), False), (3, (37, 62), True), (2, (12, 17), False),
+                             (2, (5, 7), True), (12, (38, 63), True)):
         A = 9
         prob = rs.uniform(0.01, 0.99, size=(N, H, W, 2 * A)).astype(np.float32)
         prob[0, :, :, A:] = np.round(prob[0, :, :, A:], 2)                   # image 0: ~100 distinct scores, many ties
+        if N >= 8:                                                            # scores rising / falling with the index
+            ramp = np.linspace(0.02, 0.98, H * W * A, dtype=np.float32).reshape(H, W, A)
+            prob[1, :, :, A:] = ramp
+            prob[2, :, :, A:] = ramp[::-1, ::-1, ::-1]
+            prob[3, :, :, A:] = np.where(ramp > 0.5, 0.75, 0.25)              # two plateaus
         pred = rs.normal(0, 0.25, size=(N, H, W, 4 * A)).astype(np.float32)
         info = np.tile(np.array([[16 * H - 8, 16 * W - 8, 1.0, 1]], np.float32), (N, 1))
         if N >= 3:
@@ -855,11 +864,12 @@ def test_order_sort_equals_hand_written_ranking(torch_cuda):
             info[2, :2] = [8, 8]                                              # none does
         args = [torch.from_numpy(a).cuda() for a in (prob, pred, info)]
         outs = []
-        for mode in (1, 0):
+        for mode in (1, 0, 2):
             with _lib.tuned(topk_sort=mode):
                 outs.append([t.clone() for t in proposal_layer_padded(*args, train, debug=True)])
-        for a, b in zip(*outs):
-            assert torch.equal(a, b), (N, H, W, train)
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                assert torch.equal(a, b), (N, H, W, train)
         counts = outs[0][1].cpu().tolist()
         if N >= 3:
             assert counts[2] == 0 and 0 < counts[0]
