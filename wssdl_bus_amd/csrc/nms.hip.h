@@ -32,6 +32,12 @@ bool order_sort_supported(int M, int n_images);
 size_t order_sort_scratch_bytes(int n_images, int M);
 int launch_order_sort(const unsigned long long *keys, int M, int n_images, int topn, int *sorted_index, int *n_sorted,
                       int *valid, void *scratch, size_t scratch_bytes, hipStream_t st);
+// Its two launches apart, for a caller whose own kernel produces the sorted runs (order_sort.hip.h):
+// sorted_runs [n_images, order_runs_of(M), 2048] u64; optional gather boxes [n_images, M, 4] -> sorted_boxes
+// [n_images, topn, 4] of the ranked candidates.
+int order_runs_of(int M);
+int launch_order_rank(const unsigned long long *sorted_runs, int M, int n_images, int topn, int *sorted_index, int *n_sorted,
+                      const float *boxes, float *sorted_boxes, hipStream_t st);
 
 // boxes: per image [n_max, 4] f32 in score order (image stride box_stride_img floats);
 // mask: per image [n_max, ceil(n_max/64)] u64, upper triangle written -- every word when the sweep

@@ -13,7 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "nms.hip.h"
+#include "order_sort.hip.h"
 
 // The C ABI promises that this library never reads the environment (include/wssdl_bus_hip.h); rocPRIM consults
 // one variable of its own (ROCPRIM_USE_ATOMIC_BLOCK_ID, device/detail/ordered_block_id.hpp).  Inside this
@@ -22,11 +22,12 @@ namespace std {
 inline char *wssdl_no_environment(const char *) { return nullptr; }
 }  // namespace std
 #define getenv wssdl_no_environment
-#include <rocprim/block/block_sort.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #undef getenv
 
 namespace wssdl {
+
+typedef float float4v __attribute__((ext_vector_type(4)));
 
 static bool device_sort_supported(int M, int n_images) { return M >= 1 && M <= 65535 && n_images >= 1 && n_images <= 32768; }
 
@@ -114,29 +115,22 @@ static int launch_device_sort(const unsigned long long *keys, int M, int n_image
 // scan from the previous key's position would not be bounded; this is, by log2 of the gap).  Keys are the
 // plain score_key values (no composite, no 16-bit index limit); zero keys sort to the end of their run and are
 // neither ranked nor written.
-constexpr int RUN_THREADS = 256, RUN_ITEMS = 8, RUN = RUN_THREADS * RUN_ITEMS;
+constexpr int RUN_THREADS = 256, RUN_ITEMS = 8;      // the rank kernel's view of a run: 8 keys per thread of a 256-lane group
 constexpr int RANK_GROUPS = 4;
 constexpr int MAX_RUNS = 64;
 
-struct KeyGreater {
-    __device__ __forceinline__ bool operator()(const unsigned long long &a, const unsigned long long &b) const { return a > b; }
-};
+int order_runs_of(int M) { return cdiv(M, RUN); }
+static int runs_of(int M) { return order_runs_of(M); }
 
-static int runs_of(int M) { return cdiv(M, RUN); }
-
-__global__ __launch_bounds__(RUN_THREADS) void order_runs_kernel(const unsigned long long *__restrict__ keys, int M, int runs,
+__global__ __launch_bounds__(SORT_THREADS) void order_runs_kernel(const unsigned long long *__restrict__ keys, int M, int runs,
                                                                  unsigned long long *__restrict__ sorted_runs) {
-    using Sort = rocprim::block_sort<unsigned long long, RUN_THREADS, RUN_ITEMS>;
-    __shared__ typename Sort::storage_type storage;
+    __shared__ typename RunSort::storage_type storage;
     const int img = blockIdx.x / runs, r = blockIdx.x - img * runs;
-    const int base = r * RUN + threadIdx.x * RUN_ITEMS;
-    unsigned long long k[RUN_ITEMS];
+    const int base = r * RUN + threadIdx.x * SORT_ITEMS;
+    unsigned long long k[SORT_ITEMS];
 #pragma unroll
-    for (int i = 0; i < RUN_ITEMS; ++i) k[i] = (base + i < M) ? keys[(size_t)img * M + base + i] : 0ull;
-    Sort().sort(k, storage, KeyGreater());
-    unsigned long long *o = sorted_runs + (size_t)blockIdx.x * RUN + threadIdx.x * RUN_ITEMS;
-#pragma unroll
-    for (int i = 0; i < RUN_ITEMS; ++i) o[i] = k[i];
+    for (int i = 0; i < SORT_ITEMS; ++i) k[i] = (base + i < M) ? keys[(size_t)img * M + base + i] : 0ull;
+    sort_and_store_run(k, storage, sorted_runs + (size_t)blockIdx.x * RUN);
 }
 
 // OWN = own keys per thread: a workgroup ranks RUN_THREADS * OWN keys of its run (a 1/(8/OWN) part of it), so that
@@ -144,7 +138,8 @@ __global__ __launch_bounds__(RUN_THREADS) void order_runs_kernel(const unsigned 
 template <int OWN>
 __global__ __launch_bounds__(RUN_THREADS *RANK_GROUPS) void order_rank_kernel(const unsigned long long *__restrict__ sorted_runs,
                                                                               int runs, int topn, int *__restrict__ sorted_index,
-                                                                              int *__restrict__ n_sorted) {
+                                                                              int *__restrict__ n_sorted, const float *__restrict__ boxes,
+                                                                              int M, float *__restrict__ sorted_boxes) {
     __shared__ unsigned long long stage[RANK_GROUPS][RUN];
     constexpr int PARTS = RUN_ITEMS / OWN, PART = RUN / PARTS;
     __shared__ int rank[PART];
@@ -237,7 +232,13 @@ __global__ __launch_bounds__(RUN_THREADS *RANK_GROUPS) void order_rank_kernel(co
 #pragma unroll
         for (int i = 0; i < OWN; ++i) {
             const int pos = part * PART + t * OWN + i + rank[t * OWN + i];
-            if (own[i] != 0ull && pos < topn) sorted_index[(size_t)img * topn + pos] = (int)(own[i] & 0xffffffffull);
+            if (own[i] != 0ull && pos < topn) {
+                const int idx = (int)(own[i] & 0xffffffffull);
+                sorted_index[(size_t)img * topn + pos] = idx;
+                if (sorted_boxes)         // the caller's gather, fused: boxes [n_images, M, 4] -> [n_images, topn, 4]
+                    *reinterpret_cast<float4v *>(sorted_boxes + ((size_t)img * topn + pos) * 4) =
+                        *reinterpret_cast<const float4v *>(boxes + ((size_t)img * M + idx) * 4);
+            }
         }
     }
     if (r == 0 && part == 0 && threadIdx.x == 0) n_sorted[img] = min(s_candidates, topn);
@@ -261,18 +262,31 @@ int launch_order_sort(const unsigned long long *keys, int M, int n_images, int t
         return launch_device_sort(keys, M, n_images, topn, sorted_index, n_sorted, scratch, st);
     const int runs = runs_of(M);
     unsigned long long *sorted_runs = static_cast<unsigned long long *>(scratch);
-    hipLaunchKernelGGL(order_runs_kernel, dim3(n_images * runs), dim3(RUN_THREADS), 0, st, keys, M, runs, sorted_runs);
+    hipLaunchKernelGGL(order_runs_kernel, dim3(n_images * runs), dim3(SORT_THREADS), 0, st, keys, M, runs, sorted_runs);
     int rc = check_launch();
     if (rc) return rc;
+    return launch_order_rank(sorted_runs, M, n_images, topn, sorted_index, n_sorted, nullptr, nullptr, st);
+}
+
+// The second launch alone, for callers whose own first kernel writes the sorted runs (sort_and_store_run):
+// sorted_runs [n_images, order_runs_of(M), RUN].  boxes / sorted_boxes (optional): the gather of the ranked
+// candidates' boxes, [n_images, M, 4] -> [n_images, topn, 4].
+int launch_order_rank(const unsigned long long *sorted_runs, int M, int n_images, int topn, int *sorted_index, int *n_sorted,
+                      const float *boxes, float *sorted_boxes, hipStream_t st) {
+    if (!order_sort_supported(M, n_images)) return WSSDL_ERR_INVALID_ARGUMENT;
+    const int runs = runs_of(M);
     // as many parts per run as keep the launch within one workgroup per CU
     const dim3 block(RUN_THREADS * RANK_GROUPS);
     const int run_count = n_images * runs;
     if (run_count * 4 <= 256)
-        hipLaunchKernelGGL(order_rank_kernel<2>, dim3(run_count * 4), block, 0, st, sorted_runs, runs, topn, sorted_index, n_sorted);
+        hipLaunchKernelGGL(order_rank_kernel<2>, dim3(run_count * 4), block, 0, st, sorted_runs, runs, topn, sorted_index, n_sorted,
+                           boxes, M, sorted_boxes);
     else if (run_count * 2 <= 256)
-        hipLaunchKernelGGL(order_rank_kernel<4>, dim3(run_count * 2), block, 0, st, sorted_runs, runs, topn, sorted_index, n_sorted);
+        hipLaunchKernelGGL(order_rank_kernel<4>, dim3(run_count * 2), block, 0, st, sorted_runs, runs, topn, sorted_index, n_sorted,
+                           boxes, M, sorted_boxes);
     else
-        hipLaunchKernelGGL(order_rank_kernel<8>, dim3(run_count), block, 0, st, sorted_runs, runs, topn, sorted_index, n_sorted);
+        hipLaunchKernelGGL(order_rank_kernel<8>, dim3(run_count), block, 0, st, sorted_runs, runs, topn, sorted_index, n_sorted,
+                           boxes, M, sorted_boxes);
     return check_launch();
 }
 

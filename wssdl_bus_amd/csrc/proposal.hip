@@ -13,7 +13,7 @@
 // All arithmetic is f32 in NumPy's operation order (separate multiply and add);
 // exp is evaluated in f64 and rounded once to f32 (NumPy's own f32 exp is only
 // accurate to ~2.5 ulp, so decoded boxes are tolerance-level by nature).
-#include "nms.hip.h"
+#include "order_sort.hip.h"
 
 #include <stdlib.h>
 
@@ -21,75 +21,104 @@ namespace wssdl {
 
 typedef float float4v __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void proposal_decode_kernel(
-    const float *__restrict__ prob, const float *__restrict__ pred,
-    const float *__restrict__ im_info, int info_stride, int N, int H, int W, BaseAnchors base,
-    int A, int stride, float min_size, int from_logits, float *__restrict__ boxes,
-    unsigned long long *__restrict__ keys, int *__restrict__ sorted_index, long long n_sorted_index,
-    int *__restrict__ n_sorted, int *__restrict__ cand_fill, float *__restrict__ rois_padded,
-    long long n_rois_floats) {
-    const int M = H * W * A;
-    const long long total = (long long)N * M;
-    {
-        // the layer's buffers that later kernels count on being initialised (four memset launches folded
-        // into this first kernel): sorted_index = -1, the per-image counters = 0, rois_padded = 0
-        const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-        const long long nthreads = (long long)gridDim.x * blockDim.x;
-        for (long long i = tid; i < n_sorted_index; i += nthreads) sorted_index[i] = -1;
-        for (long long i = tid; i < n_rois_floats; i += nthreads) rois_padded[i] = 0.0f;
-        if (tid < N) { n_sorted[tid] = 0;  cand_fill[tid] = 0; }
+struct DecodeArgs {
+    const float *prob, *pred, *im_info;
+    int info_stride, N, H, W, A, stride, from_logits;
+    float min_size;
+    BaseAnchors base;
+    float *boxes;                      // [N, M, 4]
+    unsigned long long *keys;          // [N, M] (decode kernel) or the sorted runs (decode + runs kernel)
+    int *sorted_index;  long long n_sorted_index;
+    int *n_sorted, *cand_fill;
+    float *rois_padded;  long long n_rois_floats;
+};
+
+// the layer's buffers that later kernels count on being initialised (four memset launches folded into the
+// first kernel): sorted_index = -1, the per-image counters = 0, rois_padded = 0
+__device__ __forceinline__ void proposal_init_buffers(const DecodeArgs &a) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    for (long long i = tid; i < a.n_sorted_index; i += nthreads) a.sorted_index[i] = -1;
+    for (long long i = tid; i < a.n_rois_floats; i += nthreads) a.rois_padded[i] = 0.0f;
+    if (tid < a.N) { a.n_sorted[tid] = 0;  a.cand_fill[tid] = 0; }
+}
+
+// anchor i of image n: its decoded, clipped box (stored) and its sort key (0 when the size filter drops it)
+__device__ __forceinline__ unsigned long long decode_anchor(const DecodeArgs &g, int n, int i) {
+    const int A = g.A, W = g.W, stride = g.stride;
+    const int cell = i / A, a = i - cell * A;
+    const int h = cell / W, w = cell - h * W;
+    const float im_h = g.im_info[n * g.info_stride + 0];
+    const float im_w = g.im_info[n * g.info_stride + 1];
+    const float im_scale = g.im_info[n * g.info_stride + 2];
+    const size_t cbase = (size_t)n * g.H * W + cell;
+    // fg probability: channels A..2A-1 (proposal_layer_tf_bus.py:86)
+    float score = g.prob[cbase * (2 * A) + A + a];
+    if (g.from_logits) {
+        // fused reshape -> softmax -> reshape (network.py:283-291,398-404): the pair of anchor
+        // a is (score[a], score[A+a]); softmax as exp(x - max) / sum like TF's kernel
+        const float bg = g.prob[cbase * (2 * A) + a];
+        const float mx = fmaxf(bg, score);
+        const float e0 = (float)exp((double)(bg - mx)), e1 = (float)exp((double)(score - mx));
+        score = e1 / (e0 + e1);
     }
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
-         g += (long long)gridDim.x * blockDim.x) {
-        const int n = (int)(g / M);
-        const int i = (int)(g - (long long)n * M);
-        const int cell = i / A, a = i - cell * A;
-        const int h = cell / W, w = cell - h * W;
-        const float im_h = im_info[n * info_stride + 0];
-        const float im_w = im_info[n * info_stride + 1];
-        const float im_scale = im_info[n * info_stride + 2];
-        const size_t cbase = (size_t)n * H * W + cell;
-        // fg probability: channels A..2A-1 (proposal_layer_tf_bus.py:86)
-        float score = prob[cbase * (2 * A) + A + a];
-        if (from_logits) {
-            // fused reshape -> softmax -> reshape (network.py:283-291,398-404): the pair of anchor
-            // a is (score[a], score[A+a]); softmax as exp(x - max) / sum like TF's kernel
-            const float bg = prob[cbase * (2 * A) + a];
-            const float mx = fmaxf(bg, score);
-            const float e0 = (float)exp((double)(bg - mx)), e1 = (float)exp((double)(score - mx));
-            score = e1 / (e0 + e1);
-        }
-        const float4v d = *reinterpret_cast<const float4v *>(pred + (cbase * A + a) * 4);
-        // anchors are integer-valued doubles cast to f32 (bbox_transform.py:34)
-        const float ax1 = (float)(base.v[a][0] + (double)(stride * w));
-        const float ay1 = (float)(base.v[a][1] + (double)(stride * h));
-        const float ax2 = (float)(base.v[a][2] + (double)(stride * w));
-        const float ay2 = (float)(base.v[a][3] + (double)(stride * h));
-        float aw = ax2 - ax1;  aw = aw + 1.0f;
-        float ah = ay2 - ay1;  ah = ah + 1.0f;
-        float hx = 0.5f * aw, hy = 0.5f * ah;
-        const float cx = ax1 + hx, cy = ay1 + hy;
-        float pcx = d.x * aw;  pcx = pcx + cx;
-        float pcy = d.y * ah;  pcy = pcy + cy;
-        const float pw = (float)exp((double)d.z) * aw;
-        const float ph = (float)exp((double)d.w) * ah;
-        const float hpw = 0.5f * pw, hph = 0.5f * ph;
-        float x1 = pcx - hpw, y1 = pcy - hph, x2 = pcx + hpw, y2 = pcy + hph;
-        // clip_boxes (bbox_transform.py:63-77): max(min(v, im-1), 0)
-        const float xm = im_w - 1.0f, ym = im_h - 1.0f;
-        x1 = fmaxf(fminf(x1, xm), 0.0f);
-        y1 = fmaxf(fminf(y1, ym), 0.0f);
-        x2 = fmaxf(fminf(x2, xm), 0.0f);
-        y2 = fmaxf(fminf(y2, ym), 0.0f);
-        // _filter_boxes (proposal_layer_tf_bus.py:123,151-156)
-        const float ms = min_size * im_scale;
-        float bw = x2 - x1;  bw = bw + 1.0f;
-        float bh = y2 - y1;  bh = bh + 1.0f;
-        const bool valid = (bw >= ms) && (bh >= ms);
-        float4v o;  o.x = x1;  o.y = y1;  o.z = x2;  o.w = y2;
-        *reinterpret_cast<float4v *>(boxes + (size_t)g * 4) = o;
-        keys[g] = valid ? score_key(score, (unsigned)i) : 0ull;
+    const float4v d = *reinterpret_cast<const float4v *>(g.pred + (cbase * A + a) * 4);
+    // anchors are integer-valued doubles cast to f32 (bbox_transform.py:34)
+    const float ax1 = (float)(g.base.v[a][0] + (double)(stride * w));
+    const float ay1 = (float)(g.base.v[a][1] + (double)(stride * h));
+    const float ax2 = (float)(g.base.v[a][2] + (double)(stride * w));
+    const float ay2 = (float)(g.base.v[a][3] + (double)(stride * h));
+    float aw = ax2 - ax1;  aw = aw + 1.0f;
+    float ah = ay2 - ay1;  ah = ah + 1.0f;
+    float hx = 0.5f * aw, hy = 0.5f * ah;
+    const float cx = ax1 + hx, cy = ay1 + hy;
+    float pcx = d.x * aw;  pcx = pcx + cx;
+    float pcy = d.y * ah;  pcy = pcy + cy;
+    const float pw = (float)exp((double)d.z) * aw;
+    const float ph = (float)exp((double)d.w) * ah;
+    const float hpw = 0.5f * pw, hph = 0.5f * ph;
+    float x1 = pcx - hpw, y1 = pcy - hph, x2 = pcx + hpw, y2 = pcy + hph;
+    // clip_boxes (bbox_transform.py:63-77): max(min(v, im-1), 0)
+    const float xm = im_w - 1.0f, ym = im_h - 1.0f;
+    x1 = fmaxf(fminf(x1, xm), 0.0f);
+    y1 = fmaxf(fminf(y1, ym), 0.0f);
+    x2 = fmaxf(fminf(x2, xm), 0.0f);
+    y2 = fmaxf(fminf(y2, ym), 0.0f);
+    // _filter_boxes (proposal_layer_tf_bus.py:123,151-156)
+    const float ms = g.min_size * im_scale;
+    float bw = x2 - x1;  bw = bw + 1.0f;
+    float bh = y2 - y1;  bh = bh + 1.0f;
+    const bool valid = (bw >= ms) && (bh >= ms);
+    float4v o;  o.x = x1;  o.y = y1;  o.z = x2;  o.w = y2;
+    const int M = g.H * W * A;
+    *reinterpret_cast<float4v *>(g.boxes + ((size_t)n * M + i) * 4) = o;
+    return valid ? score_key(score, (unsigned)i) : 0ull;
+}
+
+__global__ __launch_bounds__(256) void proposal_decode_kernel(DecodeArgs g) {
+    const int M = g.H * g.W * g.A;
+    const long long total = (long long)g.N * M;
+    proposal_init_buffers(g);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(e / M);
+        const int i = (int)(e - (long long)n * M);
+        g.keys[e] = decode_anchor(g, n, i);
     }
+}
+
+// decode + the first launch of the ordering (order_sort.hip) in one: workgroup (image, run) decodes the 2048
+// anchors of its run, 8 consecutive ones per thread, and sorts their keys; g.keys receives the sorted runs.
+__global__ __launch_bounds__(SORT_THREADS) void proposal_decode_runs_kernel(DecodeArgs g, int runs) {
+    __shared__ typename RunSort::storage_type storage;
+    const int M = g.H * g.W * g.A;
+    proposal_init_buffers(g);
+    const int n = blockIdx.x / runs, r = blockIdx.x - n * runs;
+    const int first = r * RUN + threadIdx.x * SORT_ITEMS;
+    unsigned long long k[SORT_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) k[i] = (first + i < M) ? decode_anchor(g, n, first + i) : 0ull;
+    sort_and_store_run(k, storage, g.keys + (size_t)blockIdx.x * RUN);
 }
 
 __global__ __launch_bounds__(256) void proposal_gather_kernel(
@@ -188,25 +217,41 @@ static int proposal_layer_impl(int from_logits, const float *rpn_cls_prob, const
     int *sidx = w.sorted_index;
     int *nsorted = w.n_sorted;
 
-    long long total = (long long)N * M;
-    int blocks = cdiv(total, 256);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(proposal_decode_kernel, dim3(blocks), dim3(256), 0, st, rpn_cls_prob,
-                       rpn_bbox_pred, im_info, im_info_stride, N, H, W, base, A, feat_stride,
-                       min_size, from_logits, boxes, w.keys, sidx, (long long)N * topn, nsorted, w.cand_fill,
-                       rois_padded, (long long)N * pitch * 5);
-    if ((rc = check_launch())) return rc;
-    // order of the candidates: one device-wide radix sort of all keys (order_sort.hip) when it applies, else the
-    // hand-written select + sample sort (nms.hip).  Scratch = the suppression matrix, which is written later.
+    DecodeArgs g;
+    g.prob = rpn_cls_prob;  g.pred = rpn_bbox_pred;  g.im_info = im_info;
+    g.info_stride = im_info_stride;  g.N = N;  g.H = H;  g.W = W;  g.A = A;  g.stride = feat_stride;
+    g.from_logits = from_logits;  g.min_size = min_size;  g.base = base;
+    g.boxes = boxes;  g.keys = w.keys;
+    g.sorted_index = sidx;  g.n_sorted_index = (long long)N * topn;
+    g.n_sorted = nsorted;  g.cand_fill = w.cand_fill;
+    g.rois_padded = rois_padded;  g.n_rois_floats = (long long)N * pitch * 5;
+    // Order of the candidates.  Default (order_sort.hip): sorted runs + cross ranks, with the decode fused into the
+    // run sort and the gather of the ranked boxes into the rank kernel: two launches in front of the NMS.  Scratch
+    // (the sorted runs) = the suppression matrix, which is written later.  topk_sort = 2: decode, one device-wide
+    // library sort, gather; topk_sort = 0: decode, the select + sample sort of nms.hip, gather.
     const size_t mask_bytes = sizeof(unsigned long long) * (size_t)N * topn * cdiv(topn, 64);
-    if (tuning().topk_sort != 0 && order_sort_supported(M, N) && order_sort_scratch_bytes(N, M) <= mask_bytes) {
-        if ((rc = launch_order_sort(w.keys, M, N, topn, sidx, nsorted, w.cand_fill, w.mask, mask_bytes, st))) return rc;
-    } else if ((rc = launch_rank_topk(w.keys, M, N, topn, w.cand, w.thresh, w.cand_fill, sidx, nsorted, w.mask, mask_bytes,
-                                      st)))
-        return rc;
-    hipLaunchKernelGGL(proposal_gather_kernel, dim3(cdiv(topn, 256), N), dim3(256), 0, st, boxes,
-                       sidx, nsorted, M, topn, w.sorted_boxes);
-    if ((rc = check_launch())) return rc;
+    const bool sortable = order_sort_supported(M, N) && order_sort_scratch_bytes(N, M) <= mask_bytes;
+    if (tuning().topk_sort == 1 && sortable) {
+        const int runs = order_runs_of(M);
+        g.keys = w.mask;
+        hipLaunchKernelGGL(proposal_decode_runs_kernel, dim3(N * runs), dim3(SORT_THREADS), 0, st, g, runs);
+        if ((rc = check_launch())) return rc;
+        if ((rc = launch_order_rank(w.mask, M, N, topn, sidx, nsorted, boxes, w.sorted_boxes, st))) return rc;
+    } else {
+        long long total = (long long)N * M;
+        int blocks = cdiv(total, 256);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(proposal_decode_kernel, dim3(blocks), dim3(256), 0, st, g);
+        if ((rc = check_launch())) return rc;
+        if (tuning().topk_sort != 0 && sortable) {
+            if ((rc = launch_order_sort(w.keys, M, N, topn, sidx, nsorted, w.cand_fill, w.mask, mask_bytes, st))) return rc;
+        } else if ((rc = launch_rank_topk(w.keys, M, N, topn, w.cand, w.thresh, w.cand_fill, sidx, nsorted, w.mask,
+                                          mask_bytes, st)))
+            return rc;
+        hipLaunchKernelGGL(proposal_gather_kernel, dim3(cdiv(topn, 256), N), dim3(256), 0, st, boxes,
+                           sidx, nsorted, M, topn, w.sorted_boxes);
+        if ((rc = check_launch())) return rc;
+    }
     // w.cand is free once the ranking is done: it receives the transposed diagonal blocks
     // mask + sweep (two passes when a probe over the first candidates can settle an image, nms.hip);
     // the sweep writes (batch_idx, box) rows straight into rois_padded and stops after `pitch` kept boxes
