@@ -214,7 +214,10 @@ __global__ __launch_bounds__(MTL_BLOCK) void mtl_backward_kernel(MtlArgs x, cons
     } else {
         const float sc_ce = (state->row_count > 0.0) ? (float)((double)gl[2] / state->row_count) : 0.0f;
         const float sc_box = (float)((double)gl[3] / (state->row_count < 1.0 ? 1.0 : state->row_count));
-        for (int r = t; r < x.rows_total; r += MTL_BLOCK) {
+        // a thread per row, a workgroup per MTL_BLOCK rows (one workgroup for all 8512 rows of a combined step
+        // was a 32 us chain)
+        const int r = (b - x.nb_cls - x.nb_box) * MTL_BLOCK + t;
+        if (r < x.rows_total) {
             float *gc = g_cls + (size_t)r * x.K;
             float *gb = g_box + (size_t)r * 4 * x.K;
             const int l = (r < x.n_rows) ? x.labels[r] : -1;
@@ -318,7 +321,8 @@ extern "C" int wssdl_multi_task_loss_backward(
     if (rc) return rc;
     if (!grad_losses || !workspace || !grad_rpn_cls_score || !grad_rpn_bbox_pred) return WSSDL_ERR_INVALID_ARGUMENT;
     if (rows_total > 0 && (!grad_cls_score || !grad_bbox_pred)) return WSSDL_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(mtl_backward_kernel, dim3(x.nb_cls + x.nb_box + 1), dim3(MTL_BLOCK), 0, as_stream(stream), x,
+    const int row_blocks = rows_total > 0 ? cdiv(rows_total, MTL_BLOCK) : 0;
+    hipLaunchKernelGGL(mtl_backward_kernel, dim3(x.nb_cls + x.nb_box + row_blocks), dim3(MTL_BLOCK), 0, as_stream(stream), x,
                        static_cast<const MtlState *>(workspace), grad_losses, grad_rpn_cls_score, grad_rpn_bbox_pred,
                        grad_cls_score, grad_bbox_pred);
     return check_launch();

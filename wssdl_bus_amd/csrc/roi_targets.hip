@@ -178,16 +178,17 @@ constexpr int RS_LIST = 512;
 
 // key of the quota-th smallest among the candidates of class `which` (all of them when there
 // are no more than quota: returns ~0)
-__device__ unsigned long long rs_select(const RoiClassifier &cls, int Rc, int which, int n_have,
+__device__ unsigned long long rs_select(const RoiClassifier &cls, int lo, int hi, int which, int n_have,
                                         int quota, unsigned long long seed,
                                         SelectScratch<RS_LIST> &sc) {
     if (n_have <= quota || quota <= 0) return ~0ull;
     return block_radix_select<RS_BLOCK, RS_LIST, false>(
-        [=](int i, unsigned long long &v) {
+        [=](int j, unsigned long long &v) {
+            const int i = lo + j;
             if (cls(i) != which) return false;
             v = rs_key(seed, cls.img, i);
             return true;
-        }, Rc, [quota](int) { return quota; }, sc);
+        }, hi - lo, [quota](int) { return quota; }, sc);
 }
 
 __device__ int rs_block_exclusive_scan(int v, int *s_wave, int &total) {
@@ -223,15 +224,35 @@ __global__ __launch_bounds__(RS_BLOCK) void roi_sample_kernel(
     RoiClassifier cls;
     cls.cand = cand;  cls.ov = max_overlap;  cls.img = images[s];
     cls.fg_thresh = fg_thresh;  cls.bg_hi = bg_hi;  cls.bg_lo = bg_lo;
-    // each thread owns a contiguous slice so that the output keeps the candidate order
-    const int per = (Rc + RS_BLOCK - 1) / RS_BLOCK;
-    const int i0 = min(t * per, Rc), i1 = min(i0 + per, Rc);
+    // The rows of image `img` usually are one stretch of the candidate list (the proposal blob is ordered by
+    // image, the gt rows follow): [lo, hi) = the span that holds all of them, found by one coalesced pass over
+    // the image column; everything after it only walks the span (8512 candidates of 8 images: every pass
+    // was 9 dependent load pairs per thread, 50 us for the kernel).  Any order of the rows stays correct.
+    __shared__ int s_lo, s_hi;
+    if (t == 0) { s_lo = Rc;  s_hi = 0; }
+    __syncthreads();
+    {
+        int my_lo = Rc, my_hi = 0;
+        for (int i = t; i < Rc; i += RS_BLOCK)
+            if ((int)cand[(size_t)i * 5] == cls.img) { my_lo = min(my_lo, i);  my_hi = i + 1; }
+        if (my_hi > 0) { atomicMin(&s_lo, my_lo);  atomicMax(&s_hi, my_hi); }
+    }
+    __syncthreads();
+    const int lo = min(s_lo, s_hi), hi = s_hi;
+    // each thread owns a contiguous slice of the span so that the output keeps the candidate order; the class
+    // of its rows is kept in two bit masks (slices of up to 32 rows; longer ones re-read)
+    const int per = (hi - lo + RS_BLOCK - 1) / RS_BLOCK;
+    const int i0 = min(lo + t * per, hi), i1 = min(i0 + per, hi);
+    const bool masked = per <= 32;
+    unsigned m_fg = 0u, m_bg = 0u;
     int cf = 0, cb = 0;
     for (int i = i0; i < i1; ++i) {
         const int c = cls(i);
         cf += c == 1;
         cb += c == 0;
+        if (masked) { m_fg |= (unsigned)(c == 1) << (i - i0);  m_bg |= (unsigned)(c == 0) << (i - i0); }
     }
+    auto class_of = [&](int i) { return masked ? (int)((m_fg >> (i - i0)) & 1u) - (int)(1u & ~((m_fg | m_bg) >> (i - i0))) : cls(i); };
     int have_fg, have_bg;
     rs_block_exclusive_scan(cf, s_wave, have_fg);
     rs_block_exclusive_scan(cb, s_wave, have_bg);
@@ -241,13 +262,13 @@ __global__ __launch_bounds__(RS_BLOCK) void roi_sample_kernel(
     // the fg rows, workgroup (s, 1) the bg rows (and the padding) -- half the latency of the chain
     const bool do_fg = gridDim.y == 1 || blockIdx.y == 0, do_bg = gridDim.y == 1 || blockIdx.y == 1;
     unsigned long long t_fg = 0ull, t_bg = 0ull;
-    if (do_fg) t_fg = rs_select(cls, Rc, 1, have_fg, n_fg, seed, sc);
-    if (do_bg) t_bg = rs_select(cls, Rc, 0, have_bg, n_bg, seed ^ 0x5bd1e995ull, sc);
+    if (do_fg) t_fg = rs_select(cls, lo, hi, 1, have_fg, n_fg, seed, sc);
+    if (do_bg) t_bg = rs_select(cls, lo, hi, 0, have_bg, n_bg, seed ^ 0x5bd1e995ull, sc);
     const bool emit_fg = do_fg && n_fg > 0, emit_bg = do_bg && n_bg > 0;
     cf = cb = 0;
     if (emit_fg || emit_bg)
         for (int i = i0; i < i1; ++i) {
-            const int c = cls(i);
+            const int c = class_of(i);
             if (c == 1) cf += (emit_fg && rs_key(seed, cls.img, i) <= t_fg);
             else if (c == 0) cb += (emit_bg && rs_key(seed ^ 0x5bd1e995ull, cls.img, i) <= t_bg);
         }
@@ -258,7 +279,7 @@ __global__ __launch_bounds__(RS_BLOCK) void roi_sample_kernel(
     unsigned char *fp = is_fg + (size_t)s * rois_per_image;
     if (emit_fg || emit_bg)
         for (int i = i0; i < i1; ++i) {
-            const int c = cls(i);
+            const int c = class_of(i);
             if (c == 1 && emit_fg && rs_key(seed, cls.img, i) <= t_fg) { kp[pf] = i; fp[pf] = 1; ++pf; }
             else if (c == 0 && emit_bg && rs_key(seed ^ 0x5bd1e995ull, cls.img, i) <= t_bg) { kp[pb] = i; fp[pb] = 0; ++pb; }
         }
