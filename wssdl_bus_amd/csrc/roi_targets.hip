@@ -233,9 +233,16 @@ __global__ __launch_bounds__(RS_BLOCK) void roi_sample_kernel(
     __syncthreads();
     {
         int my_lo = Rc, my_hi = 0;
+#pragma unroll 4
         for (int i = t; i < Rc; i += RS_BLOCK)
             if ((int)cand[(size_t)i * 5] == cls.img) { my_lo = min(my_lo, i);  my_hi = i + 1; }
-        if (my_hi > 0) { atomicMin(&s_lo, my_lo);  atomicMax(&s_hi, my_hi); }
+        // wave minimum / maximum first: ~1000 lanes on the two LDS words cost more than the passes this saves
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+            my_lo = min(my_lo, __shfl_xor(my_lo, off, 64));
+            my_hi = max(my_hi, __shfl_xor(my_hi, off, 64));
+        }
+        if ((t & 63) == 0 && my_hi > 0) { atomicMin(&s_lo, my_lo);  atomicMax(&s_hi, my_hi); }
     }
     __syncthreads();
     const int lo = min(s_lo, s_hi), hi = s_hi;
