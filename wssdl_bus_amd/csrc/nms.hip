@@ -308,21 +308,21 @@ constexpr int SWEEP_FIRST_HELPER = 6;                                   // wave 
 constexpr int SWEEP_GROUP = (SWEEP_BLOCK / 64 - SWEEP_FIRST_HELPER) / 2 * 64;   // threads per helper group
 constexpr int SWEEP_AHEAD = 4;          // words right of the diagonal that wave 0 handles itself
 // Band of mask words right of the diagonal that the pipelined sweep reads whatever the summary says:
-// the stagers fetch words c+1..c+SWEEP_AHEAD of chunk c's rows, and a helper fetching word c+3 at
-// iteration c still sees the placeholder summary (all ones) of the boxes kept in chunks c-2 and c-3,
-// whose real summary is flushed at iterations c+1 and c: distances 5 and 6.
-constexpr int NMS_DENSE_AHEAD = SWEEP_AHEAD + 2;
+// the stagers fetch words c+1..c+SWEEP_AHEAD of chunk c's rows.
+constexpr int NMS_DENSE_AHEAD = SWEEP_AHEAD;
+constexpr int SWEEP_MAX_CHUNKS = SWEEP_GROUP;     // a helper lane per chunk
 
-int nms_summary_words(int n_max) { return cdiv(cdiv(n_max, 64), 64); }
+// Row pitch of the suppression matrix in u64 words: whole 128-byte lines per segment of MASK_SEG = 16
+// column blocks, so that no line holds words of two segments (the fused launch hands the matrix over
+// segment by segment; a line fetched while a neighbour segment is still being written would go stale
+// in the reader's L2).
+int nms_mask_pitch(int n_max) { return (cdiv(n_max, 64) + 15) / 16 * 16; }
 
 // Whether launch_nms_sweep will take the role-pipelined kernel (which reads mask words beyond the
 // dense band only where the summary has a bit) or the general one (which reads every word).
 static bool nms_sweep_is_pipelined(int n_max, int max_keep, const void *diag_t, const void *summ) {
-    const int ncb = cdiv(n_max, 64);
-    const int sw = nms_summary_words(n_max);
-    const size_t lds_p = ((size_t)max_keep + 64) * (sizeof(int) + sizeof(unsigned long long) * sw);
-    return diag_t && summ && sw <= 4 && lds_p <= SWEEP_LDS_LIMIT && max_keep <= SWEEP_LH * SWEEP_GROUP &&
-           n_max < (1 << 24) && (long long)n_max * ncb < (1LL << 31);
+    (void)max_keep;
+    return diag_t && summ && cdiv(n_max, 64) <= SWEEP_MAX_CHUNKS && (long long)n_max * nms_mask_pitch(n_max) < (1LL << 31);
 }
 
 constexpr int MASK_WAVES = 4;
@@ -341,8 +341,8 @@ constexpr int MASK_SEG = 16;     // column blocks per workgroup
 // the LDS slice of the calling wave.
 struct MaskArgs {
     const float *boxes;  int box_stride_img;  const int *n_dev;  int n_max;
-    double thresh;  unsigned long long *mask;  int ncb;
-    unsigned long long *diag_t;  unsigned long long *summ;  int sw;
+    double thresh;  unsigned long long *mask;  int ncb;          // ncb: row pitch of mask (nms_mask_pitch)
+    unsigned long long *diag_t;  unsigned long long *summ;      // summ: [n_images][ncb column blocks][ncb row blocks]
     int n_limit;  int cb_min;  const int *done;  int dense_ahead;
 };
 
@@ -360,7 +360,7 @@ template <bool COHERENT>
 __device__ __forceinline__ void nms_mask_block(const MaskArgs &A, int rb, int seg, int img, int wave, int lane,
                                                float (*cbox_w)[64] /* [5][64] */, nms_float4v *cgeo_w /* [64] */) {
     const float *__restrict__ boxes = A.boxes;
-    const int box_stride_img = A.box_stride_img, n_max = A.n_max, ncb = A.ncb, sw = A.sw, n_limit = A.n_limit,
+    const int box_stride_img = A.box_stride_img, n_max = A.n_max, ncb = A.ncb, n_limit = A.n_limit,
               cb_min = A.cb_min, dense_ahead = A.dense_ahead;
     const double thresh = A.thresh;
     unsigned long long *__restrict__ mask = A.mask, *__restrict__ diag_t = A.diag_t, *__restrict__ summ = A.summ;
@@ -508,10 +508,14 @@ __device__ __forceinline__ void nms_mask_block(const MaskArgs &A, int rb, int se
         // read that band without looking at the summary); dense_ahead < 0 stores every word.
         if (row_ok && (bits != 0ull || dense_ahead < 0 || cb - rb <= dense_ahead))
             nms_store_word<COHERENT>(&mask[((size_t)img * n_max + i) * ncb + cb], bits);
-        // summary: which words of the row are non-zero at all (most are zero: a box overlaps few
-        // others), so that the sweep only fetches those
-        if (row_ok && bits != 0ull && summ)
-            atomicOr(&summ[((size_t)img * n_max + i) * sw + (cb >> 6)], 1ull << (cb & 63));
+        // summary: which words of this column block are non-zero at all (most are zero: a box overlaps
+        // few others), one bit per row, one u64 per (column block, row block) -- every entry of the upper
+        // triangle is written exactly once (nothing to zero, no atomics); the sweep's helpers fetch a
+        // column's summary for all rows at once and only load the words it names
+        if (summ) {
+            const unsigned long long nz = __ballot(row_ok && bits != 0ull);
+            if (lane == 0) nms_store_word<COHERENT>(&summ[((size_t)img * ncb + cb) * ncb + rb], nz);
+        }
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -529,15 +533,11 @@ int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, in
                     int n_images, double thresh, unsigned long long *mask,
                     unsigned long long *diag_t, unsigned long long *summ, hipStream_t st,
                     int n_limit, int cb_min, const int *done, int max_keep) {
-    int ncb = cdiv(n_max, 64);
-    if (ncb == 0 || n_images == 0) return WSSDL_OK;
-    const int sw = nms_summary_words(n_max);
-    // (the second pass of a two-pass run adds to the summary of the first)
-    if (summ && cb_min == 0 &&
-        hipMemsetAsync(summ, 0, sizeof(unsigned long long) * (size_t)n_images * n_max * sw, st) != hipSuccess)
-        return WSSDL_ERR_LAUNCH;
+    if (n_max <= 0 || n_images == 0) return WSSDL_OK;
+    const int ncb = nms_mask_pitch(n_max);
+    // (the second pass of a two-pass run adds the column blocks >= cb_min to the summary of the first)
     const int ncb_eff = cdiv(min(n_max, n_limit), 64);      // row / column blocks this pass can touch
-    const MaskArgs A = {boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, sw, n_limit, cb_min, done,
+    const MaskArgs A = {boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, n_limit, cb_min, done,
                         nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) ? NMS_DENSE_AHEAD : -1};
     hipLaunchKernelGGL(nms_mask_kernel, dim3(ncb_eff, cdiv(ncb_eff, MASK_SEG), n_images), dim3(64 * MASK_WAVES), 0, st, A);
     return check_launch();
@@ -724,6 +724,7 @@ __device__ __forceinline__ void lds_only_barrier() {
 struct SweepShared {
     unsigned long long ring[8];
     unsigned long long rowbuf[2][SWEEP_AHEAD + 1][64];   // [parity][0 = T, j = word c+j][row]
+    unsigned long long keptbits[SWEEP_MAX_CHUNKS];       // kept bitmask of every resolved chunk (the helpers' list)
     struct __attribute__((aligned(16))) Publish {   // written by the resolver with one 16-byte store
         unsigned long long kept;                    // kept bitmask of the chunk
         int base;                                   // boxes kept before the chunk
@@ -733,8 +734,8 @@ struct SweepShared {
 };
 
 struct SweepArgs {
-    const unsigned long long *mask, *diag_t, *summ;  int sw;
-    const int *n_dev;  int n_max, ncb, max_keep;  const int *order;  int order_stride_img;
+    const unsigned long long *mask, *diag_t, *summ;
+    const int *n_dev;  int n_max, ncb, max_keep;  const int *order;  int order_stride_img;     // ncb: row pitch
     int *keep, *num_keep;  const float *boxes;  int box_stride_img;  float *rois_padded;
     int n_limit;  const int *done_in;  int *done_out;
     // fused with the mask kernel (nms_mask_sweep_fused_kernel): rowdone[img * ncb + rb] counts the
@@ -756,26 +757,21 @@ __device__ __forceinline__ void sweep_wait_rows(const int *rowdone, int expected
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
-__device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, int img, unsigned long long *sweep_dyn,
-                                                          SweepShared &sh) {
+__device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, int img, SweepShared &sh) {
     const unsigned long long *__restrict__ mask = A.mask, *__restrict__ diag_t = A.diag_t, *__restrict__ summ = A.summ;
-    const int sw = A.sw, n_max = A.n_max, ncb = A.ncb, max_keep = A.max_keep, order_stride_img = A.order_stride_img,
+    const int n_max = A.n_max, ncb = A.ncb, max_keep = A.max_keep, order_stride_img = A.order_stride_img,
               box_stride_img = A.box_stride_img, n_limit = A.n_limit;
     const int *__restrict__ n_dev = A.n_dev, *__restrict__ order = A.order, *__restrict__ done_in = A.done_in;
     int *__restrict__ keep = A.keep, *__restrict__ num_keep = A.num_keep, *__restrict__ done_out = A.done_out;
     const float *__restrict__ boxes = A.boxes;
     float *__restrict__ rois_padded = A.rois_padded;
     if (done_in && done_in[img]) return;
-    // dynamic LDS: per kept box the summary of its non-zero mask words [max_keep + 64][sw], then
-    // the kept list [max_keep + 64]
-    unsigned long long *ksum = sweep_dyn;
-    int *kept_rows = reinterpret_cast<int *>(sweep_dyn + (size_t)(max_keep + 64) * sw);
     if (threadIdx.x == 0) sh.timed_out = 0;
     const int n = min(min(n_dev[img], n_max), n_limit);
     const int nchunks = (n + 63) / 64;
     const unsigned long long *m = mask + (size_t)img * n_max * ncb;
     const unsigned long long *dt = diag_t + (size_t)img * n_max;
-    const unsigned long long *sm = summ + (size_t)img * n_max * sw;
+    const unsigned long long *cs = summ + (size_t)img * ncb * ncb;        // [column block][row block]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 8) sh.ring[tid] = 0ull;
     if (tid < 2) { sh.pub[tid].kept = 0ull; sh.pub[tid].base = 0; sh.pub[tid].count = 0; }
@@ -789,16 +785,15 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
     const int role = wave == 5 ? 4 : 0;
     const int hw = wave - SWEEP_FIRST_HELPER;
     const int group = helper ? (hw & 1) : (wave & 1);
-    const int hidx = (hw >> 1) * 64 + lane;                   // index inside the helper group
-    // A wave has ONE role, so the loop-carried 64-bit registers of the three roles share one array
-    // (separate arrays are all live across the loop for every wave: 95 VGPRs instead of 77):
-    //   stager  rows[0..4]    T + words of one chunk's rows
-    //   helper  pend[0..6]    one word of kept boxes
-    //   scribe  out_sum[0..3] summary of one kept box, fetched but not yet stored
-    static_assert(SWEEP_AHEAD + 1 <= SWEEP_LH && 4 <= SWEEP_LH, "roles share pend[]");
+    const int hidx = (hw >> 1) * 64 + lane;                   // index inside the helper group = the lane's chunk
+    // A wave has ONE role, so the loop-carried 64-bit registers of the roles share one array
+    // (separate arrays are all live across the loop for every wave):
+    //   stager  rows[0..4]   T + words of one chunk's rows
+    //   helper  pend[0..6]   one word of up to seven kept boxes of the lane's chunk
+    static_assert(SWEEP_AHEAD + 1 <= SWEEP_LH, "roles share pend[]");
     unsigned long long pend[SWEEP_LH];
     unsigned long long (&rows)[SWEEP_LH] = pend;
-    unsigned long long (&out_sum)[SWEEP_LH] = pend;
+    unsigned long long col_summary = 0ull;                    // helper: summary of a column block, in flight
     // scribe: outputs of one kept box, fetched but not yet stored
     int out_pos = -1, out_idx = 0;
     float out_box[4] = {0.f, 0.f, 0.f, 0.f};
@@ -817,7 +812,7 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
                 if (chunk + j < nchunks) rows[j] = m[(size_t)row * ncb + chunk + j];
         }
     };
-    // kept bitmask of `chunk` -> kept list (LDS, at once) + fetch of the global outputs
+    // kept bitmask of `chunk` -> positions in the output + fetch of what the global outputs need
     auto expand = [&](int chunk) {
         const unsigned long long kept = sh.pub[chunk & 1].kept;
         const int base = sh.pub[chunk & 1].base;
@@ -826,12 +821,6 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
             const int row = chunk * 64 + lane;
             const int pos = base + __popcll(kept & ((1ull << lane) - 1ull));
             if (pos < max_keep) {
-                kept_rows[pos] = row;
-                // until the real summary arrives (flush, two iterations on) every word counts
-                // as non-zero (the mask kernel stores those words unconditionally: NMS_DENSE_AHEAD)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (q < sw) { ksum[(size_t)pos * sw + q] = ~0ull; out_sum[q] = sm[(size_t)row * sw + q]; }
                 out_pos = pos;
                 out_idx = row;
                 if (keep && order) out_idx = order[(size_t)img * order_stride_img + row];
@@ -844,9 +833,6 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
     };
     auto flush = [&]() {
         if (out_pos >= 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (q < sw) ksum[(size_t)out_pos * sw + q] = out_sum[q];
             if (keep) keep[(size_t)img * max_keep + out_pos] = out_idx;
             if (rois_padded) {
                 float *o = rois_padded + ((size_t)img * max_keep + out_pos) * 5;
@@ -896,6 +882,7 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
                 SweepShared::Publish pr;
                 pr.kept = kept;  pr.base = count;  pr.count = count + __popcll(kept);
                 sh.pub[c & 1] = pr;
+                sh.keptbits[c] = kept;
             }
             count += __popcll(kept);                   // the resolver keeps its own running count
         } else if (role == 4) {
@@ -909,32 +896,41 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
                 for (int j = 0; j <= SWEEP_AHEAD; ++j) sh.rowbuf[(c + 1) & 1][j][lane] = rows[j];
                 load_rows(c + 3);
             } else {
-                {
-                // consume word c+1 (issued at iteration c-2; slots beyond the list were zeroed)
+                // Helpers: word w of the boxes kept five or more chunks before it.  Lane k of the group = chunk k.
+                // (1) consume word c+1 (issued at iteration c-2);
                 unsigned long long acc = 0ull;
 #pragma unroll
                 for (int j = 0; j < SWEEP_LH; ++j) acc |= pend[j];
                 acc = wave_or_u64(acc);
                 if (lane == 0 && acc != 0ull) atomicOr(&sh.ring[(c + 1) & 7], acc);
-                // issue word c+3 of every box in the kept list (chunks <= c-2); 32-bit word
-                // offsets (n_max * ncb < 2^31 checked by the launcher)
-                const int lim = (c >= 1 && c + 3 < nchunks) ? min(sh.pub[(c - 1) & 1].base, max_keep) : 0;
-                unsigned off[SWEEP_LH];
-                const int wq = (c + 3) >> 6, wb = (c + 3) & 63;
-#pragma unroll
-                for (int j = 0; j < SWEEP_LH; ++j) {
-                    const int i = hidx + j * SWEEP_GROUP;
-                    off[j] = 0xffffffffu;
-                    // only boxes whose word c+3 is non-zero need the (gather) load
-                    if (i < lim && ((ksum[(size_t)i * sw + wq] >> wb) & 1ull))
-                        off[j] = __umul24((unsigned)kept_rows[i], (unsigned)ncb) + (unsigned)(c + 3);
-                }
+                // (2) word c+3: the kept boxes of chunk k <= c-2 whose word c+3 is non-zero are the bits of
+                // kept[k] & summary[c+3][k] (fetched at iteration c-2): one gather load per bit, seven in
+                // registers, the rare rest at once;
+                unsigned long long todo = 0ull;
+                if (hidx <= c - 2 && c + 3 < nchunks) todo = sh.keptbits[hidx] & col_summary;
+                const unsigned base_off = (unsigned)hidx * 64u * (unsigned)ncb + (unsigned)(c + 3);
 #pragma unroll
                 for (int j = 0; j < SWEEP_LH; ++j) {
                     pend[j] = 0ull;
-                    if (off[j] != 0xffffffffu) pend[j] = m[off[j]];
+                    if (todo != 0ull) {
+                        const unsigned b = (unsigned)__ffsll((long long)todo) - 1u;
+                        todo &= todo - 1ull;
+                        pend[j] = m[base_off + b * (unsigned)ncb];
+                    }
                 }
+                if (__builtin_expect(__ballot(todo != 0ull) != 0ull, 0)) {
+                    unsigned long long extra = 0ull;
+                    while (todo != 0ull) {
+                        const unsigned b = (unsigned)__ffsll((long long)todo) - 1u;
+                        todo &= todo - 1ull;
+                        extra |= m[base_off + b * (unsigned)ncb];
+                    }
+                    extra = wave_or_u64(extra);
+                    if (lane == 0 && extra != 0ull) atomicOr(&sh.ring[(c + 3) & 7], extra);
                 }
+                // (3) the summary of column block c+5 for the next turn of this group (chunks <= c by then)
+                col_summary = 0ull;
+                if (hidx <= c && c + 5 < nchunks) col_summary = cs[(size_t)(c + 5) * ncb + hidx];
             }
         }
         lds_only_barrier();
@@ -954,9 +950,8 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
 }
 
 __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(SweepArgs A) {
-    extern __shared__ unsigned long long sweep_dyn[];
     __shared__ SweepShared sh;
-    nms_sweep_pipelined_block(A, blockIdx.x, sweep_dyn, sh);
+    nms_sweep_pipelined_block(A, blockIdx.x, sh);
 }
 
 // Mask and sweep in ONE launch.  The sweep of an image is a single workgroup walking 64-box chunks
@@ -976,7 +971,7 @@ __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     extern __shared__ unsigned long long sweep_dyn[];
     __shared__ SweepShared sh;
     if ((int)blockIdx.x < n_images) {
-        nms_sweep_pipelined_block(S, blockIdx.x, sweep_dyn, sh);
+        nms_sweep_pipelined_block(S, blockIdx.x, sh);
         return;
     }
     // 16 waves = 4 mask blocks; mask block v = (rb * n_images + img) * nseg + seg
@@ -1001,15 +996,13 @@ int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *d
                      int max_keep, const int *order, int order_stride_img, int *keep,
                      int *num_keep, const float *boxes, int box_stride_img, float *rois_padded,
                      int *kept_scratch, hipStream_t st, int n_limit, const int *done_in, int *done_out) {
-    int ncb = cdiv(n_max, 64);
+    const int ncb = nms_mask_pitch(n_max);
     if (n_images == 0) return WSSDL_OK;
     size_t lds = ((size_t)max_keep + 64) * sizeof(int);
-    const int sw = nms_summary_words(n_max);
-    const size_t lds_p = ((size_t)max_keep + 64) * (sizeof(int) + sizeof(unsigned long long) * sw);
     if (nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ)) {
-        const SweepArgs S = {mask, diag_t, summ, sw, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
+        const SweepArgs S = {mask, diag_t, summ, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
                              boxes, box_stride_img, rois_padded, n_limit, done_in, done_out, nullptr, 0};
-        hipLaunchKernelGGL(nms_sweep_pipelined_kernel, dim3(n_images), dim3(SWEEP_BLOCK), lds_p, st, S);
+        hipLaunchKernelGGL(nms_sweep_pipelined_kernel, dim3(n_images), dim3(SWEEP_BLOCK), 0, st, S);
         return check_launch();
     }
     if (lds > SWEEP_LDS_LIMIT) {
@@ -1042,32 +1035,32 @@ int nms_probe_size(int n_max, int max_keep) {
     return (p * 2 <= (long long)n_max) ? (int)p : n_max;
 }
 
-// rowdone counters of the fused launch live behind the summary: [n_images * ceil(n_max / 64)] ints
+// the column summaries [n_images][pitch][pitch] and, behind them, the counters of the fused launch
+// [n_images * pitch] ints
 size_t nms_summary_alloc_words(int n_images, int n_max) {
-    return (size_t)n_images * n_max * nms_summary_words(n_max) + ((size_t)n_images * cdiv(n_max, 64) + 1) / 2;
+    const size_t pitch = (size_t)nms_mask_pitch(n_max);
+    return (size_t)n_images * pitch * pitch + ((size_t)n_images * pitch + 1) / 2;
 }
 
 static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n_dev, int n_max, int n_images,
                             double thresh, unsigned long long *mask, unsigned long long *diag_t,
                             unsigned long long *summ, int max_keep, const int *order, int order_stride_img,
                             int *keep, int *num_keep, float *rois_padded, hipStream_t st) {
-    const int ncb = cdiv(n_max, 64), sw = nms_summary_words(n_max);
-    const int nseg = cdiv(ncb, MASK_SEG);
-    int *rowdone = reinterpret_cast<int *>(summ + (size_t)n_images * n_max * sw);
-    // summary and counters = 0 (one memset: they are contiguous)
-    if (hipMemsetAsync(summ, 0, sizeof(unsigned long long) * nms_summary_alloc_words(n_images, n_max), st) != hipSuccess)
-        return WSSDL_ERR_LAUNCH;
-    const MaskArgs M = {boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, sw, 0x7fffffff, 0, nullptr,
+    const int ncb = nms_mask_pitch(n_max), nrb = cdiv(n_max, 64);
+    const int nseg = cdiv(nrb, MASK_SEG);
+    int *rowdone = reinterpret_cast<int *>(summ + (size_t)n_images * ncb * ncb);
+    // the counters = 0 (the summaries need no initialisation: every entry that is read is written)
+    if (hipMemsetAsync(rowdone, 0, sizeof(int) * (size_t)n_images * ncb, st) != hipSuccess) return WSSDL_ERR_LAUNCH;
+    const MaskArgs M = {boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, 0x7fffffff, 0, nullptr,
                         NMS_DENSE_AHEAD};
-    const SweepArgs S = {mask, diag_t, summ, sw, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
+    const SweepArgs S = {mask, diag_t, summ, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
                          boxes, box_stride_img, rois_padded, 0x7fffffff, nullptr, nullptr, rowdone, nseg * MASK_WAVES};
-    const size_t lds_sweep = ((size_t)max_keep + 64) * (sizeof(int) + sizeof(unsigned long long) * sw);
     const size_t lds_mask = (size_t)(SWEEP_BLOCK / 64) * (5 * 64 * sizeof(float) + 64 * sizeof(nms_float4v));
-    const long long vblocks = (long long)ncb * n_images * nseg;
+    const long long vblocks = (long long)nrb * n_images * nseg;
     const long long blocks = n_images + (vblocks + SWEEP_BLOCK / 64 / MASK_WAVES - 1) / (SWEEP_BLOCK / 64 / MASK_WAVES);
     if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(nms_mask_sweep_fused_kernel, dim3((unsigned)blocks), dim3(SWEEP_BLOCK),
-                       lds_sweep > lds_mask ? lds_sweep : lds_mask, st, M, S, n_images, ncb, nseg, rowdone);
+    hipLaunchKernelGGL(nms_mask_sweep_fused_kernel, dim3((unsigned)blocks), dim3(SWEEP_BLOCK), lds_mask, st, M, S, n_images,
+                       nrb, nseg, rowdone);
     return check_launch();
 }
 
@@ -1135,7 +1128,7 @@ struct NmsWs {
 
 static size_t carve_nms(void *ws, int n, NmsWs *out) {
     Carver c(ws);
-    int ncb = cdiv(n, 64);
+    const int ncb = nms_mask_pitch(n);
     NmsWs w;
     w.keys = c.take<unsigned long long>(n);
     w.cand = c.take<unsigned long long>(n);
@@ -1146,7 +1139,7 @@ static size_t carve_nms(void *ws, int n, NmsWs *out) {
     w.kept = c.take<int>((size_t)n + 64);
     w.boxes = c.take<float>((size_t)n * 4);
     w.mask = c.take<unsigned long long>((size_t)n * ncb);
-    w.summ = c.take<unsigned long long>((size_t)n * nms_summary_words(n));
+    w.summ = c.take<unsigned long long>(nms_summary_alloc_words(1, n));
     if (out) *out = w;
     return c.off;
 }
@@ -1177,7 +1170,7 @@ extern "C" int wssdl_nms(const float *dets, int n, double thresh, int max_keep, 
                        w.n_sorted, w.cand_fill);
     int rc = check_launch();
     if (rc) return rc;
-    const size_t mask_bytes = sizeof(unsigned long long) * (size_t)n * cdiv(n, 64);
+    const size_t mask_bytes = sizeof(unsigned long long) * (size_t)n * nms_mask_pitch(n);
     if (tuning().topk_sort != 0 && order_sort_supported(n, 1) && order_sort_scratch_bytes(1, n) <= mask_bytes)
         rc = launch_order_sort(w.keys, n, 1, n, w.order, w.n_sorted, w.cand_fill, w.mask, mask_bytes, st);
     else

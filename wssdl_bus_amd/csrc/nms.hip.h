@@ -40,16 +40,16 @@ int launch_order_rank(const unsigned long long *sorted_runs, int M, int n_images
                       const float *boxes, float *sorted_boxes, hipStream_t st);
 
 // boxes: per image [n_max, 4] f32 in score order (image stride box_stride_img floats);
-// mask: per image [n_max, ceil(n_max/64)] u64, upper triangle written -- every word when the sweep
+// mask: per image [n_max, nms_mask_pitch(n_max)] u64, upper triangle written -- every word when the sweep
 // for (n_max, max_keep) is the general one; only the non-zero words and the band next to the diagonal
 // when it is the pipelined one, which finds the others through summ.
 // diag_t (optional): per image [n_max] u64, for box i the boxes of ITS OWN 64-chunk with a lower
 // index that suppress it (the transposed diagonal block), consumed by the pipelined sweep.
-// summ (optional): per image [n_max, nms_summary_words(n_max)] u64, bit w of a row = its mask
-// word w is non-zero (zeroed here); lets the sweep skip the loads of all-zero words.
-int nms_summary_words(int n_max);
-// u64 words to allocate for `summ` of launch_nms_two_pass: the summary plus the row-block counters of
-// the fused mask + sweep launch behind it
+// summ (optional): per image [pitch column blocks][pitch row blocks] u64, bit r of entry (cb, rb) = mask
+// word cb of row 64 rb + r is non-zero; lets the sweep skip the loads of all-zero words.
+int nms_mask_pitch(int n_max);       // row pitch of mask in u64 words: ceil(n_max / 64) rounded up to 16
+// u64 words to allocate for `summ` of launch_nms_two_pass: the summaries plus the counters of
+// the fused mask + sweep launch behind them
 size_t nms_summary_alloc_words(int n_images, int n_max);
 int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, int n_max,
                     int n_images, double thresh, unsigned long long *mask,

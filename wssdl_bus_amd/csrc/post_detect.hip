@@ -26,7 +26,7 @@ struct PostWs {
 static size_t carve_post(void *ws, int R, int nc, PostWs *out) {
     Carver c(ws);
     PostWs w;
-    const int ncb = cdiv(R, 64);
+    const int ncb = nms_mask_pitch(R);
     w.keys = c.take<unsigned long long>((size_t)nc * R);
     w.cand = c.take<unsigned long long>((size_t)nc * R);
     w.thresh = c.take<unsigned long long>((size_t)nc + 32);
@@ -147,7 +147,7 @@ extern "C" int wssdl_post_detections(const float *scores, const float *boxes, in
     int rc = check_launch();
     if (rc) return rc;
     if ((rc = launch_rank_topk(w.keys, R, nc, R, w.cand, w.thresh, w.cand_fill, w.sorted_index, w.n_sorted, w.mask,
-                               sizeof(unsigned long long) * (size_t)nc * R * cdiv(R, 64), st)))
+                               sizeof(unsigned long long) * (size_t)nc * R * nms_mask_pitch(R), st)))
         return rc;
     hipLaunchKernelGGL(post_gather_kernel, dim3(blocks), dim3(256), 0, st, w.boxes, w.sorted_index, w.n_sorted, R, nc,
                        w.sorted_boxes);

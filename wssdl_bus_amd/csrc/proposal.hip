@@ -155,7 +155,7 @@ struct ProposalWs {
 static size_t carve_proposal(void *ws, int N, int M, int topn, ProposalWs *out) {
     Carver c(ws);
     ProposalWs w;
-    int ncb = cdiv(topn, 64);
+    const int ncb = nms_mask_pitch(topn);
     w.keys = c.take<unsigned long long>((size_t)N * M);
     w.boxes = c.take<float>((size_t)N * M * 4);
     w.sorted_index = c.take<int>((size_t)N * topn);
@@ -229,7 +229,7 @@ static int proposal_layer_impl(int from_logits, const float *rpn_cls_prob, const
     // run sort and the gather of the ranked boxes into the rank kernel: two launches in front of the NMS.  Scratch
     // (the sorted runs) = the suppression matrix, which is written later.  topk_sort = 2: decode, one device-wide
     // library sort, gather; topk_sort = 0: decode, the select + sample sort of nms.hip, gather.
-    const size_t mask_bytes = sizeof(unsigned long long) * (size_t)N * topn * cdiv(topn, 64);
+    const size_t mask_bytes = sizeof(unsigned long long) * (size_t)N * topn * nms_mask_pitch(topn);
     const bool sortable = order_sort_supported(M, N) && order_sort_scratch_bytes(N, M) <= mask_bytes;
     if (tuning().topk_sort == 1 && sortable) {
         const int runs = order_runs_of(M);
