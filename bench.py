@@ -313,6 +313,8 @@ def main():
     ap.add_argument("--padded-rois", action="store_true",
                     help="fixed-shape RoI blob (dead rows carry batch index -1): no device->host copy between "
                          "the backbone and the loss; the per-RoI head then runs on the padded row count")
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT",
+                    help="wssdl_set_tuning(KEY, INT) before the run, for A/B comparisons (e.g. nms_fused=0); repeatable")
     ap.add_argument("--roi-bwd-plan", type=int, default=-1,
                     help="force a plan of the list-driven RoI-pool backward (wssdl_set_tuning roi_bwd_plan; -1 = automatic)")
     args = ap.parse_args()
@@ -335,6 +337,9 @@ def main():
     _lib.lib()
     if args.roi_bwd_plan >= 0:
         _lib.set_tuning("roi_bwd_plan", args.roi_bwd_plan)
+    for kv in args.tuning:
+        key, _, val = kv.partition("=")
+        _lib.set_tuning(key, int(val))
     ctx = DistContext()
     if ctx.world_size != args.gpus:
         if ctx.world_size == 1 and args.gpus > 1:

@@ -738,19 +738,19 @@ struct SweepArgs {
     const int *n_dev;  int n_max, ncb, max_keep;  const int *order;  int order_stride_img;     // ncb: row pitch
     int *keep, *num_keep;  const float *boxes;  int box_stride_img;  float *rois_padded;
     int n_limit;  const int *done_in;  int *done_out;
-    // fused with the mask kernel (nms_mask_sweep_fused_kernel): rowdone[img * ncb + rb] counts the
-    // waves of the mask blocks of row block rb that have finished; a row block is complete at
-    // `rowdone_expected`.  NULL: the mask is complete before the sweep starts.
-    const int *rowdone;  int rowdone_expected;
+    // fused with the mask kernel (nms_mask_sweep_fused_kernel): segdone[img * ncb + s] counts the waves of
+    // the mask blocks of column segment s (MASK_SEG column blocks, all row blocks above the diagonal) that
+    // have finished; the segment is complete at MASK_WAVES * min((s + 1) * MASK_SEG, nrb).  NULL: the mask is
+    // complete before the sweep starts.
+    const int *segdone;  int nrb;
 };
 
-// Wait (one wave, before it reads rows of 64-row block `chunk`) until the mask kernel running beside
-// this sweep has finished that row block.  Bounded: after ~0.5 s without progress the wave gives up
+// Wait (one wave, before it reads words of column segment `index`) until the mask blocks running beside
+// this sweep have finished that segment.  Bounded: after ~0.5 s without progress the wave gives up
 // and raises *timed_out (the caller then reports zero kept boxes: a loud failure instead of a hang).
-__device__ __forceinline__ void sweep_wait_rows(const int *rowdone, int expected, int index, int *timed_out) {
-    if (!rowdone) return;
+__device__ __forceinline__ void sweep_wait_segment(const int *segdone, int expected, int index, int *timed_out) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();           // 100 MHz
-    while (__hip_atomic_load(rowdone + index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+    while (__hip_atomic_load(segdone + index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
         __builtin_amdgcn_s_sleep(16);
         if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) { *timed_out = 1;  break; }
     }
@@ -800,8 +800,20 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
 #pragma unroll
     for (int j = 0; j < SWEEP_LH; ++j) pend[j] = 0ull;
 
+    // stagers (fused launch): the leading column segments known to be complete.  Everything the sweep reads
+    // at iteration c lies in column blocks <= c + 3 + SWEEP_AHEAD, which the stager that loads chunk c + 3
+    // waits for here; what the scribes fetch at iteration c (summary of column c + 6) was covered one
+    // iteration earlier (chunk c + 2: column c + 6), a barrier ago.
+    int seg_ready = 0;
     auto load_rows = [&](int chunk) {
-        if (chunk < nchunks) sweep_wait_rows(A.rowdone, A.rowdone_expected, img * ncb + chunk, &sh.timed_out);
+        if (A.segdone && chunk < nchunks) {
+            const int want = min(chunk + SWEEP_AHEAD, nchunks - 1) / MASK_SEG + 1;
+            while (seg_ready < want) {
+                sweep_wait_segment(A.segdone, MASK_WAVES * min((seg_ready + 1) * MASK_SEG, A.nrb), img * ncb + seg_ready,
+                                   &sh.timed_out);
+                ++seg_ready;
+            }
+        }
         const int row = chunk * 64 + lane;
 #pragma unroll
         for (int j = 0; j <= SWEEP_AHEAD; ++j) rows[j] = 0ull;
@@ -955,40 +967,52 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(SweepA
 }
 
 // Mask and sweep in ONE launch.  The sweep of an image is a single workgroup walking 64-box chunks
-// (~1 us each: 0.2 ms for 188 chunks) on 8 of 256 CUs, and it only ever reads rows of blocks <= c + 3
-// at chunk c; the mask kernel fills the chip for 0.16 ms before it.  Here the first n_images
-// workgroups are the sweeps and all others compute the mask, ROW BLOCK BY ROW BLOCK (all images
-// abreast, a row block's 12 column segments next to each other), each wave counting its row block
-// up in `rowdone` when its words are stored (release); the sweep's stagers wait for the row block they
-// are about to load (acquire).  The early row blocks are the long ones (upper triangle), so the sweep
-// trails the mask by a few chunks at first and runs free for the rest: mask + sweep take about as
-// long as the longer of the two.  Workgroups are dispatched in index order, so the sweeps hold
-// n_images workgroup slots while the mask blocks flow through the rest of the chip: every wait ends.
+// (~1 us each: 0.2 ms for 188 chunks) on 8 of 256 CUs; the mask kernel fills the chip for 0.16 ms before
+// it.  At chunk c the sweep reads column blocks <= c + 7 only -- of ALL rows above the diagonal -- so the
+// matrix is handed over COLUMN SEGMENT BY COLUMN SEGMENT (16 column blocks = one 128-byte line of every
+// row): workgroups 0 .. n_images-1 are the sweeps, all others compute the mask in the order segment 0,
+// 1, 2, ... (inside a segment row block by row block, all images abreast), every wave counting its segment
+// up in `segdone` when its words are stored (release); the sweep's stagers wait for the segments a chunk's
+// loads reach into (acquire).  Segment s costs (s + 1) / 78 of the mask's work (upper triangle), so the
+// sweep starts after ~1 % of it and the mask stays ahead of it from then on.  (The first version handed
+// over ROW blocks: complete per-row summaries, but the early row blocks are the long ones, so the sweep
+// trailed the mask for the first ~90 chunks.)  Workgroups are dispatched in index order, so the
+// sweeps hold n_images workgroup slots while the mask blocks flow through the rest of the chip: every
+// wait ends.  No line of the matrix, of diag_t or of the summaries holds words of two segments (row
+// pitch and summary pitch are multiples of 16 words, n_max a multiple of 16), so the reader's caches
+// never see a line before it is complete.
 // (capped at 64 VGPRs: two 16-wave workgroups per CU, so that the mask role keeps 8 waves per SIMD -- 0.20 ->
-// 0.17 ms for the mask role; the cap costs the sweep role five spilled dwords, no measurable time)
+// 0.17 ms for the mask role; the cap costs the sweep role a few spilled dwords, no measurable time)
+constexpr int MASK_MAX_SEGS = SWEEP_MAX_CHUNKS / MASK_SEG;
+struct SegTable {
+    int start[MASK_MAX_SEGS + 1];       // start[s] = (row block, segment) pairs of the segments before s
+};
+
 __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void nms_mask_sweep_fused_kernel(MaskArgs M, SweepArgs S, int n_images,
-                                                                            int nrb, int nseg, int *rowdone) {
+                                                                            int nseg, SegTable table, int *segdone) {
     extern __shared__ unsigned long long sweep_dyn[];
     __shared__ SweepShared sh;
     if ((int)blockIdx.x < n_images) {
         nms_sweep_pipelined_block(S, blockIdx.x, sh);
         return;
     }
-    // 16 waves = 4 mask blocks; mask block v = (rb * n_images + img) * nseg + seg
+    // 16 waves = 4 mask blocks; mask block v = (pair * n_images + img), pairs ordered by segment, then row block
     const int lane = threadIdx.x & 63, pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long v = ((long long)blockIdx.x - n_images) * (SWEEP_BLOCK / 64 / MASK_WAVES) + (pw / MASK_WAVES);
-    if (v >= (long long)nrb * n_images * nseg) return;
-    const int seg = (int)(v % nseg);
-    const int img = (int)((v / nseg) % n_images);
-    const int rb = (int)(v / ((long long)nseg * n_images));
+    if (v >= (long long)table.start[nseg] * n_images) return;
+    const int img = (int)(v % n_images);
+    const int pair = (int)(v / n_images);
+    int seg = 0;
+    while (seg + 1 < nseg && pair >= table.start[seg + 1]) ++seg;
+    const int rb = pair - table.start[seg];
     float (*cbox)[5][64] = reinterpret_cast<float (*)[5][64]>(sweep_dyn);
     nms_float4v (*cgeo)[64] = reinterpret_cast<nms_float4v (*)[64]>(reinterpret_cast<char *>(sweep_dyn) +
                                                                      sizeof(float) * (SWEEP_BLOCK / 64) * 5 * 64);
     nms_mask_block<true>(M, rb, seg, img, pw % MASK_WAVES, lane, cbox[pw], cgeo[pw]);
-    // this wave's words (and its bits of the summary and of diag_t) have been written through: once they
-    // are acknowledged, count the row block up
+    // this wave's words (and its entries of the summary and of diag_t) have been written through: once they
+    // are acknowledged, count the segment up
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(rowdone + (size_t)img * M.ncb + rb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_fetch_add(segdone + (size_t)img * M.ncb + seg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *diag_t,
@@ -1048,19 +1072,24 @@ static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n
                             int *keep, int *num_keep, float *rois_padded, hipStream_t st) {
     const int ncb = nms_mask_pitch(n_max), nrb = cdiv(n_max, 64);
     const int nseg = cdiv(nrb, MASK_SEG);
-    int *rowdone = reinterpret_cast<int *>(summ + (size_t)n_images * ncb * ncb);
+    int *segdone = reinterpret_cast<int *>(summ + (size_t)n_images * ncb * ncb);
     // the counters = 0 (the summaries need no initialisation: every entry that is read is written)
-    if (hipMemsetAsync(rowdone, 0, sizeof(int) * (size_t)n_images * ncb, st) != hipSuccess) return WSSDL_ERR_LAUNCH;
+    if (hipMemsetAsync(segdone, 0, sizeof(int) * (size_t)n_images * ncb, st) != hipSuccess) return WSSDL_ERR_LAUNCH;
     const MaskArgs M = {boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, 0x7fffffff, 0, nullptr,
                         NMS_DENSE_AHEAD};
     const SweepArgs S = {mask, diag_t, summ, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
-                         boxes, box_stride_img, rois_padded, 0x7fffffff, nullptr, nullptr, rowdone, nseg * MASK_WAVES};
+                         boxes, box_stride_img, rois_padded, 0x7fffffff, nullptr, nullptr, segdone, nrb};
     const size_t lds_mask = (size_t)(SWEEP_BLOCK / 64) * (5 * 64 * sizeof(float) + 64 * sizeof(nms_float4v));
-    const long long vblocks = (long long)nrb * n_images * nseg;
+    SegTable table;
+    if (nseg > MASK_MAX_SEGS) return WSSDL_ERR_INVALID_ARGUMENT;
+    table.start[0] = 0;
+    for (int sgm = 0; sgm < MASK_MAX_SEGS; ++sgm)      // segment sgm: the row blocks 0 .. its last column block
+        table.start[sgm + 1] = table.start[sgm] + (sgm < nseg ? min((sgm + 1) * MASK_SEG, nrb) : 0);
+    const long long vblocks = (long long)table.start[nseg] * n_images;
     const long long blocks = n_images + (vblocks + SWEEP_BLOCK / 64 / MASK_WAVES - 1) / (SWEEP_BLOCK / 64 / MASK_WAVES);
     if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(nms_mask_sweep_fused_kernel, dim3((unsigned)blocks), dim3(SWEEP_BLOCK), lds_mask, st, M, S, n_images,
-                       nrb, nseg, rowdone);
+                       nseg, table, segdone);
     return check_launch();
 }
 
@@ -1074,7 +1103,7 @@ int launch_nms_two_pass(const float *boxes, int box_stride_img, const int *n_dev
     int rc;
     // (n_images <= 64: the sweeps must leave workgroup slots for the mask blocks they wait for)
     if (probe >= n_max && tuning().nms_fused != 0 && nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) &&
-        n_max >= 2048 && n_images <= 64)
+        n_max >= 2048 && n_max % 16 == 0 && n_images <= 64)
         return launch_nms_fused(boxes, box_stride_img, n_dev, n_max, n_images, thresh, mask, diag_t, summ, max_keep,
                                 order, order_stride_img, keep, num_keep, rois_padded, st);
     if (probe >= n_max) {
