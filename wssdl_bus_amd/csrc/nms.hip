@@ -321,8 +321,8 @@ int nms_mask_pitch(int n_max) { return (cdiv(n_max, 64) + 15) / 16 * 16; }
 // Whether launch_nms_sweep will take the role-pipelined kernel (which reads mask words beyond the
 // dense band only where the summary has a bit) or the general one (which reads every word).
 static bool nms_sweep_is_pipelined(int n_max, int max_keep, const void *diag_t, const void *summ) {
-    (void)max_keep;
-    return diag_t && summ && cdiv(n_max, 64) <= SWEEP_MAX_CHUNKS && (long long)n_max * nms_mask_pitch(n_max) < (1LL << 31);
+    return diag_t && summ && cdiv(n_max, 64) <= SWEEP_MAX_CHUNKS && max_keep <= SWEEP_LH * SWEEP_GROUP && n_max < (1 << 24) &&
+           (long long)n_max * nms_mask_pitch(n_max) < (1LL << 31);
 }
 
 constexpr int MASK_WAVES = 4;
@@ -724,7 +724,7 @@ __device__ __forceinline__ void lds_only_barrier() {
 struct SweepShared {
     unsigned long long ring[8];
     unsigned long long rowbuf[2][SWEEP_AHEAD + 1][64];   // [parity][0 = T, j = word c+j][row]
-    unsigned long long keptbits[SWEEP_MAX_CHUNKS];       // kept bitmask of every resolved chunk (the helpers' list)
+    unsigned long long colsum[4][SWEEP_MAX_CHUNKS];      // [column block & 3][row block]: the column's summary
     struct __attribute__((aligned(16))) Publish {   // written by the resolver with one 16-byte store
         unsigned long long kept;                    // kept bitmask of the chunk
         int base;                                   // boxes kept before the chunk
@@ -757,7 +757,8 @@ __device__ __forceinline__ void sweep_wait_segment(const int *segdone, int expec
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
-__device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, int img, SweepShared &sh) {
+__device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, int img, int *kept_rows /* LDS [max_keep + 64] */,
+                                                          SweepShared &sh) {
     const unsigned long long *__restrict__ mask = A.mask, *__restrict__ diag_t = A.diag_t, *__restrict__ summ = A.summ;
     const int n_max = A.n_max, ncb = A.ncb, max_keep = A.max_keep, order_stride_img = A.order_stride_img,
               box_stride_img = A.box_stride_img, n_limit = A.n_limit;
@@ -785,15 +786,17 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
     const int role = wave == 5 ? 4 : 0;
     const int hw = wave - SWEEP_FIRST_HELPER;
     const int group = helper ? (hw & 1) : (wave & 1);
-    const int hidx = (hw >> 1) * 64 + lane;                   // index inside the helper group = the lane's chunk
+    const int hidx = (hw >> 1) * 64 + lane;                   // index inside the helper group
     // A wave has ONE role, so the loop-carried 64-bit registers of the roles share one array
     // (separate arrays are all live across the loop for every wave):
-    //   stager  rows[0..4]   T + words of one chunk's rows
-    //   helper  pend[0..6]   one word of up to seven kept boxes of the lane's chunk
-    static_assert(SWEEP_AHEAD + 1 <= SWEEP_LH, "roles share pend[]");
+    //   stager  rows[0..4]    T + words of one chunk's rows
+    //   helper  pend[0..6]    one word of seven kept boxes
+    //   scribe  column[0..4]  the summary of one column block (entries lane, lane + 64, ...), in flight
+    constexpr int CS_PER_LANE = SWEEP_MAX_CHUNKS / 64;
+    static_assert(SWEEP_AHEAD + 1 <= SWEEP_LH && CS_PER_LANE <= SWEEP_LH, "roles share pend[]");
     unsigned long long pend[SWEEP_LH];
     unsigned long long (&rows)[SWEEP_LH] = pend;
-    unsigned long long col_summary = 0ull;                    // helper: summary of a column block, in flight
+    unsigned long long (&column)[SWEEP_LH] = pend;
     // scribe: outputs of one kept box, fetched but not yet stored
     int out_pos = -1, out_idx = 0;
     float out_box[4] = {0.f, 0.f, 0.f, 0.f};
@@ -833,6 +836,7 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
             const int row = chunk * 64 + lane;
             const int pos = base + __popcll(kept & ((1ull << lane) - 1ull));
             if (pos < max_keep) {
+                kept_rows[pos] = row;
                 out_pos = pos;
                 out_idx = row;
                 if (keep && order) out_idx = order[(size_t)img * order_stride_img + row];
@@ -842,6 +846,21 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
                 }
             }
         }
+    };
+    // scribes also stage the column summaries for the helpers: the summary of column block cb (one u64 per row
+    // block <= cb) is fetched at the scribe group's turn cb - 6, written to LDS at its next turn cb - 4 and read
+    // by the helpers at iteration cb - 3 (the mask blocks have finished column cb before iteration cb - 6
+    // starts: the stager of iteration cb - 7 waited for it)
+    auto fetch_column = [&](int cb) {
+#pragma unroll
+        for (int q = 0; q < CS_PER_LANE; ++q) {
+            const int rb = lane + 64 * q;
+            column[q] = (cb < nchunks && rb <= cb) ? cs[(size_t)cb * ncb + rb] : 0ull;
+        }
+    };
+    auto store_column = [&](int cb) {
+#pragma unroll
+        for (int q = 0; q < CS_PER_LANE; ++q) sh.colsum[cb & 3][lane + 64 * q] = column[q];
     };
     auto flush = [&]() {
         if (out_pos >= 0) {
@@ -865,6 +884,11 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
         load_rows(1);
     }
     __syncthreads();
+    if (scribe && group == 1) fetch_column(5);     // the scribe of the odd iterations: stored at c = 1, read at c = 2
+    else if (scribe) {
+#pragma unroll
+        for (int q = 0; q < CS_PER_LANE; ++q) column[q] = 0ull;
+    }
 
     int count = 0, last = -1;
     for (int c = 0; c < nchunks; ++c) {
@@ -894,7 +918,6 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
                 SweepShared::Publish pr;
                 pr.kept = kept;  pr.base = count;  pr.count = count + __popcll(kept);
                 sh.pub[c & 1] = pr;
-                sh.keptbits[c] = kept;
             }
             count += __popcll(kept);                   // the resolver keeps its own running count
         } else if (role == 4) {
@@ -902,47 +925,43 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
         } else if ((c & 1) == group) {
             if (scribe) {
                 flush();                               // outputs fetched two iterations ago
+                store_column(c + 4);                   // fetched two iterations ago
                 if (c > 0) expand(c - 1);
+                fetch_column(c + 6);
             } else if (stager) {
 #pragma unroll
                 for (int j = 0; j <= SWEEP_AHEAD; ++j) sh.rowbuf[(c + 1) & 1][j][lane] = rows[j];
                 load_rows(c + 3);
             } else {
-                // Helpers: word w of the boxes kept five or more chunks before it.  Lane k of the group = chunk k.
-                // (1) consume word c+1 (issued at iteration c-2);
+                // Helpers: word w of the boxes kept five or more chunks before it.
+                // consume word c+1 (issued at iteration c-2; slots beyond the list were zeroed)
                 unsigned long long acc = 0ull;
 #pragma unroll
                 for (int j = 0; j < SWEEP_LH; ++j) acc |= pend[j];
                 acc = wave_or_u64(acc);
                 if (lane == 0 && acc != 0ull) atomicOr(&sh.ring[(c + 1) & 7], acc);
-                // (2) word c+3: the kept boxes of chunk k <= c-2 whose word c+3 is non-zero are the bits of
-                // kept[k] & summary[c+3][k] (fetched at iteration c-2): one gather load per bit, seven in
-                // registers, the rare rest at once;
-                unsigned long long todo = 0ull;
-                if (hidx <= c - 2 && c + 3 < nchunks) todo = sh.keptbits[hidx] & col_summary;
-                const unsigned base_off = (unsigned)hidx * 64u * (unsigned)ncb + (unsigned)(c + 3);
+                // issue word c+3 of every box in the kept list (chunks <= c-2) for which the column's summary
+                // has a bit (the others are zero, and were not even stored); 32-bit word offsets
+                // (n_max * pitch < 2^31 checked by the launcher).  (A lane per CHUNK, walking the bits of
+                // kept & summary, needs no list -- but a chunk can hold more such boxes than a lane has
+                // registers, and the overflow loads sat inside the iteration: 0.49 against 0.37 ms in the step.)
+                const int lim = (c >= 1 && c + 3 < nchunks) ? min(sh.pub[(c - 1) & 1].base, max_keep) : 0;
+                const unsigned long long *colsum_now = sh.colsum[(c + 3) & 3];
+                unsigned off[SWEEP_LH];
+#pragma unroll
+                for (int j = 0; j < SWEEP_LH; ++j) {
+                    const int i = hidx + j * SWEEP_GROUP;
+                    off[j] = 0xffffffffu;
+                    if (i < lim) {
+                        const unsigned row = (unsigned)kept_rows[i];
+                        if ((colsum_now[row >> 6] >> (row & 63u)) & 1ull) off[j] = __umul24(row, (unsigned)ncb) + (unsigned)(c + 3);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < SWEEP_LH; ++j) {
                     pend[j] = 0ull;
-                    if (todo != 0ull) {
-                        const unsigned b = (unsigned)__ffsll((long long)todo) - 1u;
-                        todo &= todo - 1ull;
-                        pend[j] = m[base_off + b * (unsigned)ncb];
-                    }
+                    if (off[j] != 0xffffffffu) pend[j] = m[off[j]];
                 }
-                if (__builtin_expect(__ballot(todo != 0ull) != 0ull, 0)) {
-                    unsigned long long extra = 0ull;
-                    while (todo != 0ull) {
-                        const unsigned b = (unsigned)__ffsll((long long)todo) - 1u;
-                        todo &= todo - 1ull;
-                        extra |= m[base_off + b * (unsigned)ncb];
-                    }
-                    extra = wave_or_u64(extra);
-                    if (lane == 0 && extra != 0ull) atomicOr(&sh.ring[(c + 3) & 7], extra);
-                }
-                // (3) the summary of column block c+5 for the next turn of this group (chunks <= c by then)
-                col_summary = 0ull;
-                if (hidx <= c && c + 5 < nchunks) col_summary = cs[(size_t)(c + 5) * ncb + hidx];
             }
         }
         lds_only_barrier();
@@ -962,8 +981,9 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
 }
 
 __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(SweepArgs A) {
+    extern __shared__ unsigned long long sweep_dyn[];        // the kept list
     __shared__ SweepShared sh;
-    nms_sweep_pipelined_block(A, blockIdx.x, sh);
+    nms_sweep_pipelined_block(A, blockIdx.x, reinterpret_cast<int *>(sweep_dyn), sh);
 }
 
 // Mask and sweep in ONE launch.  The sweep of an image is a single workgroup walking 64-box chunks
@@ -993,7 +1013,7 @@ __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     extern __shared__ unsigned long long sweep_dyn[];
     __shared__ SweepShared sh;
     if ((int)blockIdx.x < n_images) {
-        nms_sweep_pipelined_block(S, blockIdx.x, sh);
+        nms_sweep_pipelined_block(S, blockIdx.x, reinterpret_cast<int *>(sweep_dyn), sh);
         return;
     }
     // 16 waves = 4 mask blocks; mask block v = (pair * n_images + img), pairs ordered by segment, then row block
@@ -1026,7 +1046,7 @@ int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *d
     if (nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ)) {
         const SweepArgs S = {mask, diag_t, summ, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
                              boxes, box_stride_img, rois_padded, n_limit, done_in, done_out, nullptr, 0};
-        hipLaunchKernelGGL(nms_sweep_pipelined_kernel, dim3(n_images), dim3(SWEEP_BLOCK), 0, st, S);
+        hipLaunchKernelGGL(nms_sweep_pipelined_kernel, dim3(n_images), dim3(SWEEP_BLOCK), lds, st, S);
         return check_launch();
     }
     if (lds > SWEEP_LDS_LIMIT) {
@@ -1088,8 +1108,9 @@ static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n
     const long long vblocks = (long long)table.start[nseg] * n_images;
     const long long blocks = n_images + (vblocks + SWEEP_BLOCK / 64 / MASK_WAVES - 1) / (SWEEP_BLOCK / 64 / MASK_WAVES);
     if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(nms_mask_sweep_fused_kernel, dim3((unsigned)blocks), dim3(SWEEP_BLOCK), lds_mask, st, M, S, n_images,
-                       nseg, table, segdone);
+    const size_t lds_sweep = ((size_t)max_keep + 64) * sizeof(int);
+    hipLaunchKernelGGL(nms_mask_sweep_fused_kernel, dim3((unsigned)blocks), dim3(SWEEP_BLOCK),
+                       lds_sweep > lds_mask ? lds_sweep : lds_mask, st, M, S, n_images, nseg, table, segdone);
     return check_launch();
 }
 
