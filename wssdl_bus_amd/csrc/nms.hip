@@ -1015,7 +1015,13 @@ constexpr int MASK_MAX_SEGS = SWEEP_MAX_CHUNKS / MASK_SEG;
 struct SegTable {
     int start[MASK_MAX_SEGS + 1];       // start[s] = (row block, segment) pairs of the segments before s
 };
-constexpr int FUSED_BLOCKS_PER_DRAW = SWEEP_BLOCK / 64 / MASK_WAVES;      // 4
+// Same-address atomics are served one at a time at the memory side (~90 ns each): a draw per four mask
+// blocks (2500 draws for 8 x 12000 boxes) and a count per wave (up to 752 on one segment's word) made
+// the launch 1.15 ms.  A draw is therefore 16 mask blocks -- four rounds of one block per 4 waves -- and a
+// block is counted once, by one lane, after a workgroup barrier behind the waves' own store waits.
+constexpr int FUSED_BLOCKS_PER_ROUND = SWEEP_BLOCK / 64 / MASK_WAVES;     // 4
+constexpr int FUSED_ROUNDS_PER_DRAW = 4;
+constexpr int FUSED_BLOCKS_PER_DRAW = FUSED_BLOCKS_PER_ROUND * FUSED_ROUNDS_PER_DRAW;
 
 // control words of a fused launch, all in the int region behind the summaries (zeroed by the launcher):
 //   ctl[img * ncb + s]        s < nseg: finished waves of column segment s
@@ -1071,19 +1077,23 @@ __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
             if (tid < n_images)
                 finished = __hip_atomic_load(ctl + (size_t)tid * ncb + ncb - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // mask block v = (pair * n_images + img), pairs ordered by segment, then row block
-        const long long v = (long long)draw * FUSED_BLOCKS_PER_DRAW + (pw / MASK_WAVES);
-        if (v < blocks_total) {
-            const int img = (int)(v % n_images);
-            const int pair = (int)(v / n_images);
-            int seg = 0;
-            while (seg + 1 < nseg && pair >= table.start[seg + 1]) ++seg;
-            const int rb = pair - table.start[seg];
-            if (!s_done[img]) nms_mask_block<true>(M, rb, seg, img, pw % MASK_WAVES, lane, cbox[pw], cgeo[pw]);
-            // this wave's words (and its entries of the summary and of diag_t) have been written through: once
-            // they are acknowledged, count the segment up
+        for (int round = 0; round < FUSED_ROUNDS_PER_DRAW; ++round) {
+            // mask block v = (pair * n_images + img), pairs ordered by segment, then row block
+            const long long v = (long long)draw * FUSED_BLOCKS_PER_DRAW + round * FUSED_BLOCKS_PER_ROUND + (pw / MASK_WAVES);
+            int img = 0, seg = 0;
+            if (v < blocks_total) {
+                img = (int)(v % n_images);
+                const int pair = (int)(v / n_images);
+                while (seg + 1 < nseg && pair >= table.start[seg + 1]) ++seg;
+                const int rb = pair - table.start[seg];
+                if (!s_done[img]) nms_mask_block<true>(M, rb, seg, img, pw % MASK_WAVES, lane, cbox[pw], cgeo[pw]);
+            }
+            // the waves' words (and their entries of the summary and of diag_t) have been written through: once
+            // they are acknowledged, count the block's segment up by its MASK_WAVES waves
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(ctl + (size_t)img * ncb + seg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (v < blocks_total && (pw % MASK_WAVES) == 0 && lane == 0)
+                __hip_atomic_fetch_add(ctl + (size_t)img * ncb + seg, MASK_WAVES, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (retiring) break;                            // that was the draw taken before the look that retired us
         __syncthreads();                                // every wave is done with s_done and s_draw
