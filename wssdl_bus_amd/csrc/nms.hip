@@ -1003,31 +1003,29 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(SweepA
 // never see a line before it is complete.
 // (capped at 64 VGPRs: two 16-wave workgroups per CU, so that the mask role keeps 8 waves per SIMD -- 0.20 ->
 // 0.17 ms for the mask role; the cap costs the sweep role a few spilled dwords, no measurable time)
-// The mask workgroups are WORKERS that draw their mask blocks from a queue (an atomic counter, four blocks
-// = one per 4 waves a draw, the next draw in flight while one is computed), as many workers as the chip
-// holds.  Measured with static blocks: the sweep ran at 1.97 us per chunk while mask blocks were running
-// and 1.4 after them -- a 16-wave mask workgroup shares the sweep's CU (two workgroups fit), and its VALU
-// and LDS-broadcast stream sits in front of the resolver's chain.  A worker therefore looks at where it
-// runs (HW_ID / XCC_ID) before every draw and retires when it shares a CU with a sweep, whose CU then stays
-// its own.  A worker also skips the blocks of an image whose sweep has finished (kept max_keep boxes
-// before the last chunk): in training with a trained RPN that is most of the matrix.
+// Two more things the mask workgroups do for the sweeps:
+// * keep off their CUs.  Two 16-wave workgroups fit a CU, so a mask workgroup shares the CU of every sweep,
+//   and its VALU and LDS-broadcast stream sits in front of the resolver's chain: measured, the sweep walked
+//   a chunk in 1.97 us while mask blocks were running and in 1.4 us after them.  A sweep publishes where it
+//   runs (HW_ID / XCC_ID); a mask workgroup of the first generation (the ones dispatched before any slot has
+//   been freed) that finds itself on a sweep's CU computes its blocks like any other and then PARKS -- one
+//   wave polling the sweeps' finished flags between long sleeps, fifteen waiting at a barrier -- so that the
+//   slot is never handed to another mask workgroup.  Nothing waits for a parked workgroup, and the sweeps it
+//   waits for only wait for mask blocks, which wait for nothing.
+//   (Mask workers that draw their blocks from a queue and simply retire were tried first: any loop around the
+//   mask block -- queue, static stride, a single trip -- made the whole launch 7x slower, not understood.)
+// * skip the blocks of an image whose sweep has finished (it kept max_keep boxes before the last chunk): in
+//   training with a trained RPN that is most of the matrix.  The block is still counted.
+// Control words, all in the int region behind the summaries (zeroed by the launcher):
+//   ctl[img * ncb + s]        s < nseg: finished waves of column segment s
+//   ctl[img * ncb + ncb - 1]  1 + the CU the image's sweep runs on
+//   ctl[img * ncb + ncb - 2]  1 once the image's sweep has finished
 constexpr int MASK_MAX_SEGS = SWEEP_MAX_CHUNKS / MASK_SEG;
 struct SegTable {
     int start[MASK_MAX_SEGS + 1];       // start[s] = (row block, segment) pairs of the segments before s
 };
-// Same-address atomics are served one at a time at the memory side (~90 ns each): a draw per four mask
-// blocks (2500 draws for 8 x 12000 boxes) and a count per wave (up to 752 on one segment's word) made
-// the launch 1.15 ms.  A draw is therefore 16 mask blocks -- four rounds of one block per 4 waves -- and a
-// block is counted once, by one lane, after a workgroup barrier behind the waves' own store waits.
-constexpr int FUSED_BLOCKS_PER_ROUND = SWEEP_BLOCK / 64 / MASK_WAVES;     // 4
-constexpr int FUSED_ROUNDS_PER_DRAW = 4;
-constexpr int FUSED_BLOCKS_PER_DRAW = FUSED_BLOCKS_PER_ROUND * FUSED_ROUNDS_PER_DRAW;
+constexpr int FUSED_FIRST_GENERATION = 1024;      // >= the workgroups any chip holds at once
 
-// control words of a fused launch, all in the int region behind the summaries (zeroed by the launcher):
-//   ctl[img * ncb + s]        s < nseg: finished waves of column segment s
-//   ctl[img * ncb + ncb - 1]  1 + the CU the image's sweep runs on
-//   ctl[img * ncb + ncb - 2]  1 once the image's sweep has finished
-//   ctl[n_images * ncb]       the queue: next draw
 __device__ __forceinline__ int fused_cu_key() {
     // HW_ID (id 4): CU_ID [11:8], SH_ID [12], SE_ID [15:13]; XCC_ID (id 20) [3:0]
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
@@ -1039,7 +1037,7 @@ __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
                                                                             int nseg, SegTable table, int *ctl) {
     extern __shared__ unsigned long long sweep_dyn[];
     __shared__ SweepShared sh;
-    __shared__ int s_draw, s_done[64];
+    __shared__ int s_done[64];
     const int ncb = M.ncb;
     if ((int)blockIdx.x < n_images) {
         if (threadIdx.x == 0)
@@ -1049,59 +1047,43 @@ __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
             __hip_atomic_store(ctl + (size_t)blockIdx.x * ncb + ncb - 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
+    // 16 waves = 4 mask blocks; mask block v = (pair * n_images + img), pairs ordered by segment, then row block
     const int tid = threadIdx.x, lane = tid & 63, pw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 64)
+        s_done[tid] = tid < n_images ? __hip_atomic_load(ctl + (size_t)tid * ncb + ncb - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    __syncthreads();
+    const long long v = ((long long)blockIdx.x - n_images) * (SWEEP_BLOCK / 64 / MASK_WAVES) + (pw / MASK_WAVES);
+    const bool live = v < (long long)table.start[nseg] * n_images;
+    const int img = (int)(v % n_images);
+    const int pair = (int)(v / n_images);
+    int seg = 0;
+    while (seg + 1 < nseg && pair >= table.start[seg + 1]) ++seg;
+    const int rb = pair - table.start[seg];
     float (*cbox)[5][64] = reinterpret_cast<float (*)[5][64]>(sweep_dyn);
     nms_float4v (*cgeo)[64] = reinterpret_cast<nms_float4v (*)[64]>(reinterpret_cast<char *>(sweep_dyn) +
                                                                      sizeof(float) * (SWEEP_BLOCK / 64) * 5 * 64);
-    int *queue = ctl + (size_t)n_images * ncb;
-    const long long blocks_total = (long long)table.start[nseg] * n_images;
-    const int draws_total = (int)((blocks_total + FUSED_BLOCKS_PER_DRAW - 1) / FUSED_BLOCKS_PER_DRAW);
+    if (live && !s_done[img]) nms_mask_block<true>(M, rb, seg, img, pw % MASK_WAVES, lane, cbox[pw], cgeo[pw]);
+    // this wave's words (and its entries of the summary and of diag_t) have been written through: once they
+    // are acknowledged, count the segment up
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (live && lane == 0) __hip_atomic_fetch_add(ctl + (size_t)img * ncb + seg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)blockIdx.x >= n_images + FUSED_FIRST_GENERATION) return;
+    // first generation: park on a sweep's CU (the sweeps published their CUs long before this block's work was done)
     const int my_cu = fused_cu_key();
-    // what thread `tid` watches for the workgroup: image tid's sweep CU and its finished flag
-    auto shares_cu = [&]() -> int {
-        return tid < n_images &&
-               __hip_atomic_load(ctl + (size_t)tid * ncb + ncb - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_cu;
-    };
-    if (__syncthreads_or(shares_cu())) return;
-    if (tid < 64) s_done[tid] = 0;
-    if (tid == 0) s_draw = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    int draw = s_draw;
-    bool retiring = false;
-    while (draw < draws_total) {
-        // the next draw and the next look at the sweeps' words, in flight while this draw is computed
-        int next = draws_total, shared = 0, finished = 0;
-        if (!retiring) {
-            if (tid == 0) next = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            shared = shares_cu();
-            if (tid < n_images)
-                finished = __hip_atomic_load(ctl + (size_t)tid * ncb + ncb - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int mine = tid < n_images &&
+                     __hip_atomic_load(ctl + (size_t)tid * ncb + ncb - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_cu;
+    if (!__syncthreads_or(mine)) return;
+    if (pw == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            const int running = lane < n_images &&
+                                __hip_atomic_load(ctl + (size_t)lane * ncb + ncb - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+            if (__ballot(running) == 0ull) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) break;        // 1 s: never hold a launch for good
+            __builtin_amdgcn_s_sleep(127);
         }
-        for (int round = 0; round < FUSED_ROUNDS_PER_DRAW; ++round) {
-            // mask block v = (pair * n_images + img), pairs ordered by segment, then row block
-            const long long v = (long long)draw * FUSED_BLOCKS_PER_DRAW + round * FUSED_BLOCKS_PER_ROUND + (pw / MASK_WAVES);
-            int img = 0, seg = 0;
-            if (v < blocks_total) {
-                img = (int)(v % n_images);
-                const int pair = (int)(v / n_images);
-                while (seg + 1 < nseg && pair >= table.start[seg + 1]) ++seg;
-                const int rb = pair - table.start[seg];
-                if (!s_done[img]) nms_mask_block<true>(M, rb, seg, img, pw % MASK_WAVES, lane, cbox[pw], cgeo[pw]);
-            }
-            // the waves' words (and their entries of the summary and of diag_t) have been written through: once
-            // they are acknowledged, count the block's segment up by its MASK_WAVES waves
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (v < blocks_total && (pw % MASK_WAVES) == 0 && lane == 0)
-                __hip_atomic_fetch_add(ctl + (size_t)img * ncb + seg, MASK_WAVES, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (retiring) break;                            // that was the draw taken before the look that retired us
-        __syncthreads();                                // every wave is done with s_done and s_draw
-        if (tid == 0) s_draw = next;
-        if (tid < n_images) s_done[tid] = finished;
-        retiring = __syncthreads_or(shared) != 0;
-        draw = s_draw;
     }
+    __syncthreads();
 }
 
 int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *diag_t,
@@ -1148,23 +1130,11 @@ int nms_probe_size(int n_max, int max_keep) {
     return (p * 2 <= (long long)n_max) ? (int)p : n_max;
 }
 
-// the column summaries [n_images][pitch][pitch] and, behind them, the control words of the fused launch
-// [n_images * pitch + 1] ints
+// the column summaries [n_images][pitch][pitch] and, behind them, the counters of the fused launch
+// [n_images * pitch] ints
 size_t nms_summary_alloc_words(int n_images, int n_max) {
     const size_t pitch = (size_t)nms_mask_pitch(n_max);
-    return (size_t)n_images * pitch * pitch + ((size_t)n_images * pitch + 2) / 2;
-}
-
-// CUs of the current device (asked once per device)
-static int fused_cu_count() {
-    static int count[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (count[dev] == 0) {
-        int n = 0;
-        count[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-    }
-    return count[dev];
+    return (size_t)n_images * pitch * pitch + ((size_t)n_images * pitch + 1) / 2;
 }
 
 static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n_dev, int n_max, int n_images,
@@ -1175,7 +1145,7 @@ static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n
     const int nseg = cdiv(nrb, MASK_SEG);
     int *segdone = reinterpret_cast<int *>(summ + (size_t)n_images * ncb * ncb);
     // the control words = 0 (the summaries need no initialisation: every entry that is read is written)
-    if (hipMemsetAsync(segdone, 0, sizeof(int) * ((size_t)n_images * ncb + 1), st) != hipSuccess) return WSSDL_ERR_LAUNCH;
+    if (hipMemsetAsync(segdone, 0, sizeof(int) * (size_t)n_images * ncb, st) != hipSuccess) return WSSDL_ERR_LAUNCH;
     const MaskArgs M = {boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, 0x7fffffff, 0, nullptr,
                         NMS_DENSE_AHEAD};
     const SweepArgs S = {mask, diag_t, summ, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
@@ -1187,12 +1157,8 @@ static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n
     for (int sgm = 0; sgm < MASK_MAX_SEGS; ++sgm)      // segment sgm: the row blocks 0 .. its last column block
         table.start[sgm + 1] = table.start[sgm] + (sgm < nseg ? min((sgm + 1) * MASK_SEG, nrb) : 0);
     const long long vblocks = (long long)table.start[nseg] * n_images;
-    const long long draws = (vblocks + FUSED_BLOCKS_PER_DRAW - 1) / FUSED_BLOCKS_PER_DRAW;
-    if (draws > 0x3fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
-    // as many workers as the chip holds beside the sweeps (two 16-wave workgroups per CU); more would only find
-    // the queue empty
-    const long long workers = std::min<long long>(draws, std::max(1, 2 * fused_cu_count() - n_images));
-    const long long blocks = n_images + workers;
+    const long long blocks = n_images + (vblocks + SWEEP_BLOCK / 64 / MASK_WAVES - 1) / (SWEEP_BLOCK / 64 / MASK_WAVES);
+    if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
     const size_t lds_sweep = ((size_t)max_keep + 64) * sizeof(int);
     hipLaunchKernelGGL(nms_mask_sweep_fused_kernel, dim3((unsigned)blocks), dim3(SWEEP_BLOCK),
                        lds_sweep > lds_mask ? lds_sweep : lds_mask, st, M, S, n_images, nseg, table, segdone);
