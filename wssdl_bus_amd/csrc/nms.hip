@@ -1001,47 +1001,34 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(SweepA
 // wait ends.  No line of the matrix, of diag_t or of the summaries holds words of two segments (row
 // pitch and summary pitch are multiples of 16 words, n_max a multiple of 16), so the reader's caches
 // never see a line before it is complete.
-// (capped at 64 VGPRs: two 16-wave workgroups per CU, so that the mask role keeps 8 waves per SIMD -- 0.20 ->
-// 0.17 ms for the mask role; the cap costs the sweep role a few spilled dwords, no measurable time)
-// Two more things the mask workgroups do for the sweeps:
-// * keep off their CUs.  Two 16-wave workgroups fit a CU, so a mask workgroup shares the CU of every sweep,
-//   and its VALU and LDS-broadcast stream sits in front of the resolver's chain: measured, the sweep walked
-//   a chunk in 1.97 us while mask blocks were running and in 1.4 us after them.  A sweep publishes where it
-//   runs (HW_ID / XCC_ID); a mask workgroup of the first generation (the ones dispatched before any slot has
-//   been freed) that finds itself on a sweep's CU computes its blocks like any other and then PARKS -- one
-//   wave polling the sweeps' finished flags between long sleeps, fifteen waiting at a barrier -- so that the
-//   slot is never handed to another mask workgroup.  Nothing waits for a parked workgroup, and the sweeps it
-//   waits for only wait for mask blocks, which wait for nothing.
-//   (Mask workers that draw their blocks from a queue and simply retire were tried first: any loop around the
-//   mask block -- queue, static stride, a single trip -- made the whole launch 7x slower, not understood.)
-// * skip the blocks of an image whose sweep has finished (it kept max_keep boxes before the last chunk): in
-//   training with a trained RPN that is most of the matrix.  The block is still counted.
+// A mask workgroup skips the blocks of an image whose sweep has finished (it kept max_keep boxes before the
+// last chunk; the block is still counted): in training with a trained RPN that is most of the matrix.
 // Control words, all in the int region behind the summaries (zeroed by the launcher):
 //   ctl[img * ncb + s]        s < nseg: finished waves of column segment s
-//   ctl[img * ncb + ncb - 1]  1 + the CU the image's sweep runs on
 //   ctl[img * ncb + ncb - 2]  1 once the image's sweep has finished
+// What did NOT help the sweep (it walks a chunk in ~2 us while mask blocks run, 1.1 us alone):
+// * keeping the mask workgroups off its CU (a first-generation mask workgroup that found itself on a sweep's
+//   CU -- HW_ID / XCC_ID against a word the sweep published -- parked after its own blocks, one wave polling
+//   the finished flags between long sleeps): no change, so it is not the shared CU;
+// * mask WORKERS that draw blocks from a queue, as many as the chip holds: any loop around the mask block --
+//   queue, static stride, even a single trip -- made the whole launch 7x slower (not understood; the same
+//   block without the loop runs at full speed).
+// What did: NOT capping the kernel at 64 VGPRs.  The cap bought the mask role 8 waves per SIMD (two workgroups
+// per CU, 0.20 -> 0.17 ms) and cost the sweep role 5 spilled VGPRs and 55 SGPRs spilled to lanes, in the
+// resolver's loop: 1.4 us per chunk even with the mask finished.  Uncapped (78 VGPRs, one workgroup per CU)
+// the bench's full-walk steps went 0.32 -> 0.25 ms for the launch.
 constexpr int MASK_MAX_SEGS = SWEEP_MAX_CHUNKS / MASK_SEG;
 struct SegTable {
     int start[MASK_MAX_SEGS + 1];       // start[s] = (row block, segment) pairs of the segments before s
 };
-constexpr int FUSED_FIRST_GENERATION = 1024;      // >= the workgroups any chip holds at once
 
-__device__ __forceinline__ int fused_cu_key() {
-    // HW_ID (id 4): CU_ID [11:8], SH_ID [12], SE_ID [15:13]; XCC_ID (id 20) [3:0]
-    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
-    return (int)(((hw >> 8) & 0xffu) | (xcc << 8)) + 1;
-}
-
-__global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void nms_mask_sweep_fused_kernel(MaskArgs M, SweepArgs S, int n_images,
-                                                                            int nseg, SegTable table, int *ctl) {
+__global__ __launch_bounds__(SWEEP_BLOCK) void nms_mask_sweep_fused_kernel(MaskArgs M, SweepArgs S, int n_images, int nseg, SegTable table,
+                                                                            int *ctl) {
     extern __shared__ unsigned long long sweep_dyn[];
     __shared__ SweepShared sh;
     __shared__ int s_done[64];
     const int ncb = M.ncb;
     if ((int)blockIdx.x < n_images) {
-        if (threadIdx.x == 0)
-            __hip_atomic_store(ctl + (size_t)blockIdx.x * ncb + ncb - 1, fused_cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         nms_sweep_pipelined_block(S, blockIdx.x, reinterpret_cast<int *>(sweep_dyn), sh);
         if (threadIdx.x == 0)
             __hip_atomic_store(ctl + (size_t)blockIdx.x * ncb + ncb - 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1053,7 +1040,7 @@ __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
         s_done[tid] = tid < n_images ? __hip_atomic_load(ctl + (size_t)tid * ncb + ncb - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     __syncthreads();
     const long long v = ((long long)blockIdx.x - n_images) * (SWEEP_BLOCK / 64 / MASK_WAVES) + (pw / MASK_WAVES);
-    const bool live = v < (long long)table.start[nseg] * n_images;
+    if (v >= (long long)table.start[nseg] * n_images) return;
     const int img = (int)(v % n_images);
     const int pair = (int)(v / n_images);
     int seg = 0;
@@ -1062,28 +1049,11 @@ __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     float (*cbox)[5][64] = reinterpret_cast<float (*)[5][64]>(sweep_dyn);
     nms_float4v (*cgeo)[64] = reinterpret_cast<nms_float4v (*)[64]>(reinterpret_cast<char *>(sweep_dyn) +
                                                                      sizeof(float) * (SWEEP_BLOCK / 64) * 5 * 64);
-    if (live && !s_done[img]) nms_mask_block<true>(M, rb, seg, img, pw % MASK_WAVES, lane, cbox[pw], cgeo[pw]);
+    if (!s_done[img]) nms_mask_block<true>(M, rb, seg, img, pw % MASK_WAVES, lane, cbox[pw], cgeo[pw]);
     // this wave's words (and its entries of the summary and of diag_t) have been written through: once they
     // are acknowledged, count the segment up
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (live && lane == 0) __hip_atomic_fetch_add(ctl + (size_t)img * ncb + seg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((int)blockIdx.x >= n_images + FUSED_FIRST_GENERATION) return;
-    // first generation: park on a sweep's CU (the sweeps published their CUs long before this block's work was done)
-    const int my_cu = fused_cu_key();
-    const int mine = tid < n_images &&
-                     __hip_atomic_load(ctl + (size_t)tid * ncb + ncb - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_cu;
-    if (!__syncthreads_or(mine)) return;
-    if (pw == 0) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        for (;;) {
-            const int running = lane < n_images &&
-                                __hip_atomic_load(ctl + (size_t)lane * ncb + ncb - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-            if (__ballot(running) == 0ull) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) break;        // 1 s: never hold a launch for good
-            __builtin_amdgcn_s_sleep(127);
-        }
-    }
-    __syncthreads();
+    if (lane == 0) __hip_atomic_fetch_add(ctl + (size_t)img * ncb + seg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *diag_t,
