@@ -292,6 +292,20 @@ def test_nms_large_n_uses_global_kept_list(torch_cuda):
     assert hip_nms(d, 0.5) == O.nms(d, 0.5)
 
 
+@pytest.mark.gpu
+def test_nms_pipelined_sweep_at_its_size_limits(torch_cuda):
+    """The role-pipelined sweep takes up to 320 chunks (a helper lane per chunk of the column summaries, five
+    summary words per scribe lane) and 2240 kept boxes: sizes just inside and just outside both limits (outside,
+    the general sweep runs), and candidate counts that are not a multiple of the 16-word row pitch."""
+    from wssdl_bus_amd.nms.hip_nms import hip_nms
+    rs = np.random.RandomState(13)
+    for n, keep in ((20480, 1500), (20479, 2240), (20481, 1500), (16385, 2241), (4100, 2000)):
+        c = rs.uniform(0, 3000, size=(n, 2))
+        wh = rs.uniform(10, 90, size=(n, 2))
+        d = np.hstack((c, c + wh, rs.permutation(n)[:, None] / float(n))).astype(np.float32)
+        assert hip_nms(d, 0.5, max_keep=keep) == O.nms(d, 0.5)[:keep], (n, keep)
+
+
 # ---------------------------------------------------------------- device RoI sampling ---
 @pytest.mark.gpu
 def test_proposal_target_device_sampling(torch_cuda):
