@@ -22,19 +22,15 @@
 
 namespace wssdl {
 
-__global__ __launch_bounds__(256) void roi_gt_assign_kernel(
-    const float *__restrict__ rois, int R, const float *__restrict__ gt_boxes, int max_gt,
-    const int *__restrict__ num_pos, int n_images, double *__restrict__ max_overlap,
-    int *__restrict__ assignment) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    const float *b = rois + (size_t)r * 5;
+// IoU arg-max of one candidate row (batch index, box) over the positive boxes of its image (:236-240)
+__device__ __forceinline__ void roi_gt_assign_row(const float *b, const float *__restrict__ gt_boxes, int max_gt, int n_pos,
+                                                  int n_images, double &best, int &arg) {
     const int img = (int)b[0];
-    double best = 0.0;
-    int arg = -1;
+    best = 0.0;
+    arg = -1;
     if (img >= 0 && img < n_images) {
         const double bx1 = b[1], by1 = b[2], bx2 = b[3], by2 = b[4];
-        const int np = min(num_pos[img], max_gt);
+        const int np = min(n_pos, max_gt);
         const float *g = gt_boxes + (size_t)img * max_gt * 5;
         for (int k = 0; k < np; ++k) {
             const double qx1 = g[k * 5 + 0], qy1 = g[k * 5 + 1], qx2 = g[k * 5 + 2], qy2 = g[k * 5 + 3];
@@ -51,6 +47,19 @@ __global__ __launch_bounds__(256) void roi_gt_assign_kernel(
             if (k == 0 || ov > best) { best = ov; arg = k; }   // numpy argmax: first maximum
         }
     }
+}
+
+__global__ __launch_bounds__(256) void roi_gt_assign_kernel(
+    const float *__restrict__ rois, int R, const float *__restrict__ gt_boxes, int max_gt,
+    const int *__restrict__ num_pos, int n_images, double *__restrict__ max_overlap,
+    int *__restrict__ assignment) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float *b = rois + (size_t)r * 5;
+    const int img = (int)b[0];
+    double best;
+    int arg;
+    roi_gt_assign_row(b, gt_boxes, max_gt, (img >= 0 && img < n_images) ? num_pos[img] : 0, n_images, best, arg);
     max_overlap[r] = best;
     assignment[r] = arg;
 }
@@ -120,7 +129,8 @@ __global__ __launch_bounds__(256) void roi_targets_kernel(
 __global__ __launch_bounds__(256) void roi_candidates_kernel(
     const float *__restrict__ rois, int R, const float *__restrict__ gt_boxes, int max_gt,
     const int *__restrict__ num_gt, int n_images, const int *__restrict__ images, int S,
-    int append_gt, float *__restrict__ cand, int *__restrict__ num_pos) {
+    int append_gt, float *__restrict__ cand, int *__restrict__ num_pos, double *__restrict__ max_overlap /* or NULL */,
+    int *__restrict__ assignment) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     auto count_pos = [&](int img) {
         const int ng = min(max(num_gt[img], 0), max_gt);
@@ -132,16 +142,28 @@ __global__ __launch_bounds__(256) void roi_candidates_kernel(
     const int total = R + (append_gt ? S * max_gt : 0);
     if (row >= total) return;
     float *o = cand + (size_t)row * 5;
+    float c[5];
     if (row < R) {
         const float *b = rois + (size_t)row * 5;
-        o[0] = b[0]; o[1] = b[1]; o[2] = b[2]; o[3] = b[3]; o[4] = b[4];
-        return;
+        c[0] = b[0]; c[1] = b[1]; c[2] = b[2]; c[3] = b[3]; c[4] = b[4];
+    } else {
+        const int s = (row - R) / max_gt, k = (row - R) % max_gt;
+        const int img = images[s];
+        const float *g = gt_boxes + ((size_t)img * max_gt + k) * 5;
+        c[0] = (k < count_pos(img)) ? (float)img : -1.0f;
+        c[1] = g[0]; c[2] = g[1]; c[3] = g[2]; c[4] = g[3];
     }
-    const int s = (row - R) / max_gt, k = (row - R) % max_gt;
-    const int img = images[s];
-    const float *g = gt_boxes + ((size_t)img * max_gt + k) * 5;
-    o[0] = (k < count_pos(img)) ? (float)img : -1.0f;
-    o[1] = g[0]; o[2] = g[1]; o[3] = g[2]; o[4] = g[3];
+    o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3]; o[4] = c[4];
+    if (max_overlap) {
+        // the assignment of wssdl_roi_gt_assign in the same launch (the row's own count of positives: the
+        // num_pos array is written by other threads of this launch)
+        const int img = (int)c[0];
+        double best;
+        int arg;
+        roi_gt_assign_row(c, gt_boxes, max_gt, (img >= 0 && img < n_images) ? count_pos(img) : 0, n_images, best, arg);
+        max_overlap[row] = best;
+        assignment[row] = arg;
+    }
 }
 
 // ------------------------------------------------------- device sampling ---
@@ -360,7 +382,7 @@ extern "C" int wssdl_roi_candidates(const float *rois, int R, const float *gt_bo
     const int threads = total > n_images ? total : n_images;
     hipLaunchKernelGGL(roi_candidates_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, as_stream(stream),
                        rois, R, gt_boxes, max_gt, num_gt_boxes, n_images, images, n_sample_images,
-                       append_gt, cand, num_pos_boxes);
+                       append_gt, cand, num_pos_boxes, static_cast<double *>(nullptr), static_cast<int *>(nullptr));
     return check_launch();
 }
 
@@ -418,10 +440,13 @@ extern "C" int wssdl_proposal_target_device(
     const int n_keep = n_sample_images * rois_per_image;
     wssdl::PtWs w;
     wssdl::carve_pt(workspace, Rc, n_images, n_keep, n_sample_images, &w);
-    int rc = wssdl_roi_candidates(rois, R, gt_boxes, max_gt, num_gt_boxes, n_images, images, n_sample_images, append_gt,
-                                  w.cand, w.num_pos, stream);
+    if (!gt_boxes || !num_gt_boxes || (R > 0 && !rois) || !images) return WSSDL_ERR_INVALID_ARGUMENT;
+    // candidates + assignment in one launch (three launches for the layer: each costs more host time than it runs)
+    hipLaunchKernelGGL(wssdl::roi_candidates_kernel, dim3(cdiv(Rc > n_images ? Rc : n_images, 256)), dim3(256), 0,
+                       as_stream(stream), rois, R, gt_boxes, max_gt, num_gt_boxes, n_images, images, n_sample_images,
+                       append_gt, w.cand, w.num_pos, w.max_ov, w.assign);
+    int rc = check_launch();
     if (rc) return rc;
-    if ((rc = wssdl_roi_gt_assign(w.cand, Rc, gt_boxes, max_gt, w.num_pos, n_images, w.max_ov, w.assign, stream))) return rc;
     if ((rc = wssdl_roi_sample_device(w.cand, w.max_ov, Rc, images, n_sample_images, rois_per_image, fg_rois_per_image,
                                       fg_thresh, bg_thresh_hi, bg_thresh_lo, seed, w.keep, w.is_fg, w.counts, stream)))
         return rc;
