@@ -116,7 +116,10 @@ def test_force_dist_single_rank_rccl_step_equals_plain_step():
     if res["repeat"] == 0.0:
         assert res["dist"] == 0.0, res                        # deterministic backward: bit-for-bit
     else:
-        assert res["dist"] <= 4 * res["repeat"], res
+        # (the repeat's own difference is one sample of the backbone's atomic-order noise and can come out small:
+        # also accept anything within 5 % of the distance the step moved the parameters -- a lost or unscaled
+        # bucket shows up at that scale, 20 x above)
+        assert res["dist"] <= max(4 * res["repeat"], 0.05 * res["moved"]), res
     assert abs(res["loss"][0] - res["loss"][2]) <= 4 * abs(res["loss"][0] - res["loss"][1]) + 1e-6
 
 
