@@ -72,7 +72,7 @@ WSSDL_API const char *wssdl_last_error(void);
  * "roi_bwdc_variant", "roi_bwd_cg" (shapes of the compact forward / the fallback backwards, 0 =
  * automatic), "nms_one_pass" (1: the proposal layer skips the probe pass), "nms_fused" (0: mask and sweep of a one-pass
  * NMS as two launches instead of the fused one), "topk_sort" (order of the proposal candidates: 1 sorted runs +
- * cross ranks, the default; 2 one device-wide library sort; 0 the select + sample sort).  Results do not depend on
+ * cross ranks, the default; 0 the select + sample sort).  Results do not depend on
  * any of them.  Unknown key -> WSSDL_ERR_INVALID_ARGUMENT. */
 WSSDL_API int wssdl_set_tuning(const char *key, int value);
 WSSDL_API int wssdl_get_tuning(const char *key, int *value_host);

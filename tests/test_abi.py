@@ -110,10 +110,7 @@ def test_library_does_not_read_the_environment(lib_path):
         if f.endswith((".hip", ".h")):
             text = open(os.path.join(csrc, f)).read()
             assert "_ABLATE" not in text and "_TRACE" not in text, f
-            if f == "order_sort.hip":          # mentions it once: rocPRIM's own std::getenv is mapped to a stub there
-                assert "#define getenv wssdl_no_environment" in text
-            else:
-                assert "getenv" not in text, f
+            assert "getenv" not in text, f
 
 
 def test_tuning_knobs_are_plain_ints(lib_path):

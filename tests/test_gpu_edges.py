@@ -850,8 +850,8 @@ def test_post_detections_device_op_edges(torch_cuda):
 
 
 def test_order_sort_equals_hand_written_ranking(torch_cuda):
-    """The candidates' order by sorted runs + cross ranks (order_sort.hip, the default), by the device-wide library
-    sort and by the hand-written select + sample sort (nms.hip): identical blobs and identical sorted candidate
+    """The candidates' order by sorted runs + cross ranks (order_sort.hip, the default) and by the hand-written
+    select + sample sort (nms.hip): identical blobs and identical sorted candidate
     lists -- train and test mode, 1-8 images, duplicated scores (ties go to the higher index either way), images
     with few or no candidates, scores that follow the anchor index (a run's keys then all fall into one gap of
     its neighbour's: the galloping search), a map with fewer anchors than one run."""
@@ -878,7 +878,7 @@ def test_order_sort_equals_hand_written_ranking(torch_cuda):
             info[2, :2] = [8, 8]                                              # none does
         args = [torch.from_numpy(a).cuda() for a in (prob, pred, info)]
         outs = []
-        for mode in (1, 0, 2):
+        for mode in (1, 0):
             with _lib.tuned(topk_sort=mode):
                 outs.append([t.clone() for t in proposal_layer_padded(*args, train, debug=True)])
         for other in outs[1:]:

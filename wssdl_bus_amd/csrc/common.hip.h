@@ -48,8 +48,8 @@ struct Tuning {
     int roi_bwdc_variant = 0;   // shape of the tile-owner fallback backward
     int roi_bwd_cg = 0;         // channels per workgroup of the fallback backwards (0: automatic)
     int nms_one_pass = 0;       // 1: the proposal layer never uses the probe pass
-    int topk_sort = 1;          // order of the proposal candidates: 1 sorted runs + cross ranks (order_sort.hip), 2 one
-                                //    device-wide library sort, 0 the select + sample sort of nms.hip
+    int topk_sort = 1;          // order of the proposal candidates: 1 sorted runs + cross ranks (order_sort.hip),
+                                //    0 the select + sample sort of nms.hip
     int nms_fused = 1;          // 0: mask and sweep of a one-pass NMS as two launches instead of the fused one
 };
 Tuning &tuning();

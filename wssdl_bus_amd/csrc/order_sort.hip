@@ -1,110 +1,19 @@
 // Descending order of the candidates of every image, chip-wide (the ranking of nms.hip runs one workgroup per
-// image for three of its four phases: 0.10 ms for 8 x 21 546 keys, 0.20 ms for 1 x 56 700, nearly all latency).
+// image for three of its four phases: 0.10 ms for 8 x 21 546 keys, 0.20 ms for 1 x 56 700, nearly all latency):
+// sorted runs + cross ranks, two launches.  Nothing is allocated or synchronised.
 //
-// Form 1 (tuning topk_sort = 2): ONE device-wide sort of all keys of all images by rocPRIM
-// (rocprim::radix_sort_keys_desc, a plain primitive like a GEMM) on composite keys
-//   (n_images - 1 - image) << 48 | order-preserving score bits << 16 | anchor index
-// so that one descending sort yields, image after image, the candidates by descending score with ties
-// broken towards the higher index -- exactly the total order of the 64-bit keys of nms.hip.h (score_key),
-// hence the same sorted_index as launch_rank_topk.  Non-candidates (key 0) sink to the end of their image.
-// Needs M <= 65 535 anchors per image.  0.074 ms for 8 x 21 546 keys.
-// Form 2 (topk_sort = 1, the default): sorted runs + cross ranks, below.
-// Nothing is allocated or synchronised in either.
-#include <cstdlib>
-#include <cstring>
-
+// (A first form sorted ALL keys of ALL images with one device-wide library sort, rocprim::radix_sort_keys_desc on
+// composite keys (n_images - 1 - image) << 48 | score bits << 16 | anchor index, between a pack and a finish
+// kernel.  At these sizes the library runs its merge sort -- a block sort and EIGHT merge passes of 6.5 us each:
+// 0.074 ms for 8 x 21 546 keys against 0.034 here; it needed M <= 65 535 and a stub for the library's own
+// environment look-up.  Measured in profiles/r03_order_ab.log, removed.)
 #include "order_sort.hip.h"
-
-// The C ABI promises that this library never reads the environment (include/wssdl_bus_hip.h); rocPRIM consults
-// one variable of its own (ROCPRIM_USE_ATOMIC_BLOCK_ID, device/detail/ordered_block_id.hpp).  Inside this
-// translation unit its std::getenv is a function that knows no variables, so the library keeps its default.
-namespace std {
-inline char *wssdl_no_environment(const char *) { return nullptr; }
-}  // namespace std
-#define getenv wssdl_no_environment
-#include <rocprim/device/device_radix_sort.hpp>
-#undef getenv
 
 namespace wssdl {
 
 typedef float float4v __attribute__((ext_vector_type(4)));
 
-static bool device_sort_supported(int M, int n_images) { return M >= 1 && M <= 65535 && n_images >= 1 && n_images <= 32768; }
-
-static int image_bits(int n_images) {
-    int b = 0;
-    while ((1 << b) < n_images) ++b;
-    return b;
-}
-
-static size_t sort_temp_bytes(size_t n, int end_bit) {
-    size_t bytes = 0;
-    unsigned long long *p = nullptr;
-    if (rocprim::radix_sort_keys_desc(nullptr, bytes, p, p, n, 0, end_bit, (hipStream_t)0) != hipSuccess) return 0;
-    return (bytes + 255) & ~size_t(255);
-}
-
-static size_t device_sort_scratch_bytes(int n_images, int M) {
-    if (!device_sort_supported(M, n_images)) return 0;
-    const size_t n = (size_t)n_images * M;
-    const size_t arr = (n * sizeof(unsigned long long) + 255) & ~size_t(255);
-    return 2 * arr + sort_temp_bytes(n, 48 + image_bits(n_images));
-}
-
-// keys (score_key format, 0 = not a candidate) -> composite keys
-__global__ __launch_bounds__(256) void order_pack_kernel(const unsigned long long *__restrict__ keys, int M, int n_images,
-                                                         unsigned long long *__restrict__ packed) {
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (long long)n_images * M) return;
-    const int img = (int)(g / M);
-    const unsigned long long k = keys[g];
-    packed[g] = ((unsigned long long)(n_images - 1 - img) << 48) | (k != 0ull ? (((k >> 32) << 16) | (k & 0xffffull)) : 0ull);
-}
-
-// The candidates of an image are the sorted keys with a non-zero score field (a candidate's order-preserving
-// score bits have their top bit set or are the complement of a negative float's: never 0): their count is the
-// position of the first key whose low 48 bits are zero -- a binary search per workgroup (counting them with
-// atomics in the pack kernel cost 33 us: 2700 waves on 8 counters).
-__global__ __launch_bounds__(256) void order_finish_kernel(const unsigned long long *__restrict__ sorted, int M, int topn,
-                                                           int *__restrict__ sorted_index, int *__restrict__ n_sorted) {
-    const int img = blockIdx.y;
-    const unsigned long long *seg = sorted + (size_t)img * M;
-    int lo = 0, hi = M;                        // first position with an empty score field, in [0, M]
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if ((seg[mid] & 0xffffffffffffull) != 0ull) lo = mid + 1;
-        else hi = mid;
-    }
-    const int n = min(lo, topn);
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p == 0) n_sorted[img] = n;
-    if (p < n) sorted_index[(size_t)img * topn + p] = (int)(seg[p] & 0xffffull);
-}
-
-static int launch_device_sort(const unsigned long long *keys, int M, int n_images, int topn, int *sorted_index,
-                              int *n_sorted, void *scratch, hipStream_t st) {
-    const size_t n = (size_t)n_images * M;
-    const size_t arr = (n * sizeof(unsigned long long) + 255) & ~size_t(255);
-    const int end_bit = 48 + image_bits(n_images);
-    unsigned long long *a = static_cast<unsigned long long *>(scratch);
-    unsigned long long *b = reinterpret_cast<unsigned long long *>(static_cast<char *>(scratch) + arr);
-    void *temp = static_cast<char *>(scratch) + 2 * arr;
-    size_t temp_bytes = sort_temp_bytes(n, end_bit);
-    hipLaunchKernelGGL(order_pack_kernel, dim3(cdiv((long long)n, 256)), dim3(256), 0, st, keys, M, n_images, a);
-    int rc = check_launch();
-    if (rc) return rc;
-    const hipError_t e = rocprim::radix_sort_keys_desc(temp, temp_bytes, a, b, n, 0, end_bit, st);
-    if (e != hipSuccess) { set_last_error(e);  return WSSDL_ERR_LAUNCH; }
-    hipLaunchKernelGGL(order_finish_kernel, dim3(cdiv(topn, 256), n_images), dim3(256), 0, st, b, M, topn, sorted_index,
-                       n_sorted);
-    return check_launch();
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Form 2 (the default): sorted runs + cross ranks, two launches.
-//
-// The device-wide sort above is, at these sizes (8 x 21 546 keys), the library's merge sort: one block-sort
-// launch and EIGHT merge passes of 6.5 us each -- latency again.  A candidate's final position is
+// A candidate's final position is
 //   its position in its own sorted run  +  for every other run of its image, the number of keys greater than it,
 // and the second term needs no merge passes: `order_runs_kernel` sorts runs of 2048 keys (one workgroup each,
 // rocprim::block_sort in LDS), `order_rank_kernel` gives every run a workgroup of four 256-lane groups that
@@ -247,8 +156,7 @@ __global__ __launch_bounds__(RUN_THREADS *RANK_GROUPS) void order_rank_kernel(co
 bool order_sort_supported(int M, int n_images) { return M >= 1 && runs_of(M) <= MAX_RUNS && n_images >= 1 && n_images <= 32768; }
 
 size_t order_sort_scratch_bytes(int n_images, int M) {
-    const size_t runs_bytes = (size_t)n_images * runs_of(M) * RUN * sizeof(unsigned long long);
-    return runs_bytes > device_sort_scratch_bytes(n_images, M) ? runs_bytes : device_sort_scratch_bytes(n_images, M);
+    return (size_t)n_images * runs_of(M) * RUN * sizeof(unsigned long long);
 }
 
 // Same contract as launch_rank_topk: sorted_index [n_images, topn] pre-filled with -1, n_sorted written
@@ -258,8 +166,6 @@ int launch_order_sort(const unsigned long long *keys, int M, int n_images, int t
     (void)valid;
     if (!order_sort_supported(M, n_images) || scratch_bytes < order_sort_scratch_bytes(n_images, M))
         return WSSDL_ERR_WORKSPACE;
-    if (tuning().topk_sort == 2 && device_sort_supported(M, n_images))
-        return launch_device_sort(keys, M, n_images, topn, sorted_index, n_sorted, scratch, st);
     const int runs = runs_of(M);
     unsigned long long *sorted_runs = static_cast<unsigned long long *>(scratch);
     hipLaunchKernelGGL(order_runs_kernel, dim3(n_images * runs), dim3(SORT_THREADS), 0, st, keys, M, runs, sorted_runs);
