@@ -786,11 +786,9 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
     const int role = wave == 5 ? 4 : 0;
     const int hw = wave - SWEEP_FIRST_HELPER;
     const int group = helper ? (hw & 1) : (wave & 1);
-    const int hidx = (hw >> 1) * 64 + lane;                   // index inside the helper group
     // A wave has ONE role, so the loop-carried 64-bit registers of the roles share one array
     // (separate arrays are all live across the loop for every wave):
     //   stager  rows[0..4]    T + words of one chunk's rows
-    //   helper  pend[0..6]    one word of seven kept boxes
     //   scribe  column[0..4]  the summary of one column block (entries lane, lane + 64, ...), in flight
     constexpr int CS_PER_LANE = SWEEP_MAX_CHUNKS / 64;
     static_assert(SWEEP_AHEAD + 1 <= SWEEP_LH && CS_PER_LANE <= SWEEP_LH, "roles share pend[]");
@@ -890,6 +888,83 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
         for (int q = 0; q < CS_PER_LANE; ++q) column[q] = 0ull;
     }
 
+    // Helpers: word w of the boxes kept five or more chunks before it.  ALL ten helper waves act in EVERY
+    // iteration, each lane on HELPER_SLOTS positions of the kept list (position h + j * 640): a turn is 4 slots
+    // instead of the 7 that two alternating groups of five waves needed, and the helpers' turn was the longest
+    // of an iteration (0.85 us against the resolver's 0.42).  A wave then has TWO batches of gather loads in
+    // flight, and the one issued an iteration ago must not be waited for when the one issued two iterations
+    // ago is consumed.  The compiler's wait insertion cannot express that across the loop (it waits for
+    // everything), and it may COPY a loop-carried register whose load is still in flight if the load is hidden
+    // in inline asm with an ordinary operand.  So the batches live in sixteen FIXED registers, v112-v127, that
+    // only the asm statements below name (the kernels stay far below 112 VGPRs otherwise; checked in the ISA
+    // by tests/test_abi.py): always HELPER_SLOTS loads per turn (unused slots load word 0 and are masked at the
+    // consume step), consumed behind s_waitcnt vmcnt(HELPER_SLOTS).  Helper waves issue no other vector memory
+    // operation.
+    constexpr int HELPER_SLOTS = 4;
+    constexpr int HELPER_LANES = (SWEEP_BLOCK / 64 - SWEEP_FIRST_HELPER) * 64;
+    static_assert(HELPER_SLOTS * HELPER_LANES >= SWEEP_LH * SWEEP_GROUP, "every list position has a slot");
+    struct Batch { unsigned long long w[HELPER_SLOTS]; };
+#define WSSDL_TAKE(R0, R1, R2, R3, R4, R5, R6, R7)                                                                      \
+    [&]() {                                                                                                             \
+        unsigned l0, h0, l1, h1, l2, h2, l3, h3;                                                                        \
+        asm volatile("s_waitcnt vmcnt(4)\n\tv_mov_b32 %0, " R0 "\n\tv_mov_b32 %1, " R1 "\n\tv_mov_b32 %2, " R2             \
+                     "\n\tv_mov_b32 %3, " R3 "\n\tv_mov_b32 %4, " R4 "\n\tv_mov_b32 %5, " R5 "\n\tv_mov_b32 %6, " R6       \
+                     "\n\tv_mov_b32 %7, " R7                                                                            \
+                     : "=v"(l0), "=v"(h0), "=v"(l1), "=v"(h1), "=v"(l2), "=v"(h2), "=v"(l3), "=v"(h3)                  \
+                     :                                                                                                  \
+                     : "memory");                                                                                       \
+        Batch b;                                                                                                        \
+        b.w[0] = ((unsigned long long)h0 << 32) | l0;  b.w[1] = ((unsigned long long)h1 << 32) | l1;                    \
+        b.w[2] = ((unsigned long long)h2 << 32) | l2;  b.w[3] = ((unsigned long long)h3 << 32) | l3;                    \
+        return b;                                                                                                       \
+    }
+#define WSSDL_ISSUE(P0, P1, P2, P3, C0, C1, C2, C3, C4, C5, C6, C7)                                                     \
+    [&](int j, const unsigned long long *src) {                                                                         \
+        if (j == 0) asm volatile("global_load_dwordx2 " P0 ", %0, off" : : "v"(src) : "memory", C0, C1);                \
+        else if (j == 1) asm volatile("global_load_dwordx2 " P1 ", %0, off" : : "v"(src) : "memory", C2, C3);           \
+        else if (j == 2) asm volatile("global_load_dwordx2 " P2 ", %0, off" : : "v"(src) : "memory", C4, C5);           \
+        else asm volatile("global_load_dwordx2 " P3 ", %0, off" : : "v"(src) : "memory", C6, C7);                       \
+    }
+    auto take_a = WSSDL_TAKE("v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119");
+    auto take_b = WSSDL_TAKE("v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+    auto issue_a = WSSDL_ISSUE("v[112:113]", "v[114:115]", "v[116:117]", "v[118:119]", "v112", "v113", "v114", "v115", "v116",
+                               "v117", "v118", "v119");
+    auto issue_b = WSSDL_ISSUE("v[120:121]", "v[122:123]", "v[124:125]", "v[126:127]", "v120", "v121", "v122", "v123", "v124",
+                               "v125", "v126", "v127");
+#undef WSSDL_TAKE
+#undef WSSDL_ISSUE
+    const int hall = hw * 64 + lane;
+    unsigned live_a = 0u, live_b = 0u;
+    auto helper_turn = [&](auto &take, auto &issue, unsigned &live, int c) {
+        // consume word c+1: this batch was issued at iteration c-2; the one issued at c-1 may stay in flight
+        const Batch got = take();
+        unsigned long long acc = 0ull;
+#pragma unroll
+        for (int j = 0; j < HELPER_SLOTS; ++j) acc |= ((live >> j) & 1u) ? got.w[j] : 0ull;
+        acc = wave_or_u64(acc);
+        if (lane == 0 && acc != 0ull) atomicOr(&sh.ring[(c + 1) & 7], acc);
+        // issue word c+3 of every box in the kept list (chunks <= c-2) for which the column's summary has a
+        // bit (the others are zero, and were not even stored); 32-bit word offsets (n_max * pitch < 2^31
+        // checked by the launcher).  (A lane per CHUNK, walking the bits of kept & summary, needs no list -- but
+        // a chunk can hold more such boxes than a lane has registers, and the overflow loads sat inside the
+        // iteration: 0.49 against 0.37 ms in the step.)
+        const int lim = (c >= 1 && c + 3 < nchunks) ? min(sh.pub[(c - 1) & 1].base, max_keep) : 0;
+        const unsigned long long *colsum_now = sh.colsum[(c + 3) & 3];
+        live = 0u;
+#pragma unroll
+        for (int j = 0; j < HELPER_SLOTS; ++j) {
+            const int i = hall + j * HELPER_LANES;
+            unsigned off = 0u;
+            if (i < lim) {
+                const unsigned row = (unsigned)kept_rows[i];
+                if ((colsum_now[row >> 6] >> (row & 63u)) & 1ull) {
+                    off = __umul24(row, (unsigned)ncb) + (unsigned)(c + 3);
+                    live |= 1u << j;
+                }
+            }
+            issue(j, m + off);
+        }
+    };
     int count = 0, last = -1;
     for (int c = 0; c < nchunks; ++c) {
         if (wave == 0) {
@@ -922,6 +997,9 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
             count += __popcll(kept);                   // the resolver keeps its own running count
         } else if (role == 4) {
             // spare
+        } else if (helper) {
+            if (c & 1) helper_turn(take_b, issue_b, live_b, c);
+            else helper_turn(take_a, issue_a, live_a, c);
         } else if ((c & 1) == group) {
             if (scribe) {
                 flush();                               // outputs fetched two iterations ago
@@ -932,36 +1010,6 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
 #pragma unroll
                 for (int j = 0; j <= SWEEP_AHEAD; ++j) sh.rowbuf[(c + 1) & 1][j][lane] = rows[j];
                 load_rows(c + 3);
-            } else {
-                // Helpers: word w of the boxes kept five or more chunks before it.
-                // consume word c+1 (issued at iteration c-2; slots beyond the list were zeroed)
-                unsigned long long acc = 0ull;
-#pragma unroll
-                for (int j = 0; j < SWEEP_LH; ++j) acc |= pend[j];
-                acc = wave_or_u64(acc);
-                if (lane == 0 && acc != 0ull) atomicOr(&sh.ring[(c + 1) & 7], acc);
-                // issue word c+3 of every box in the kept list (chunks <= c-2) for which the column's summary
-                // has a bit (the others are zero, and were not even stored); 32-bit word offsets
-                // (n_max * pitch < 2^31 checked by the launcher).  (A lane per CHUNK, walking the bits of
-                // kept & summary, needs no list -- but a chunk can hold more such boxes than a lane has
-                // registers, and the overflow loads sat inside the iteration: 0.49 against 0.37 ms in the step.)
-                const int lim = (c >= 1 && c + 3 < nchunks) ? min(sh.pub[(c - 1) & 1].base, max_keep) : 0;
-                const unsigned long long *colsum_now = sh.colsum[(c + 3) & 3];
-                unsigned off[SWEEP_LH];
-#pragma unroll
-                for (int j = 0; j < SWEEP_LH; ++j) {
-                    const int i = hidx + j * SWEEP_GROUP;
-                    off[j] = 0xffffffffu;
-                    if (i < lim) {
-                        const unsigned row = (unsigned)kept_rows[i];
-                        if ((colsum_now[row >> 6] >> (row & 63u)) & 1ull) off[j] = __umul24(row, (unsigned)ncb) + (unsigned)(c + 3);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < SWEEP_LH; ++j) {
-                    pend[j] = 0ull;
-                    if (off[j] != 0xffffffffu) pend[j] = m[off[j]];
-                }
             }
         }
         lds_only_barrier();
@@ -969,6 +1017,7 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
         last = c;
         if (count >= max_keep) break;
     }
+    if (helper) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (batches still in flight)
     if (scribe && last >= 0) {
         // chunk `last` was resolved but not expanded yet: it belongs to the group of last + 1
         flush();
