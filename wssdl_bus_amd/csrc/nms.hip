@@ -896,8 +896,8 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
     // ago is consumed.  The compiler's wait insertion cannot express that across the loop (it waits for
     // everything), and it may COPY a loop-carried register whose load is still in flight if the load is hidden
     // in inline asm with an ordinary operand.  So the batches live in sixteen FIXED registers, v112-v127, that
-    // only the asm statements below name (the kernels stay far below 112 VGPRs otherwise; checked in the ISA
-    // by tests/test_abi.py): always HELPER_SLOTS loads per turn (unused slots load word 0 and are masked at the
+    // only the asm statements below name (both kernels carry amdgpu_num_vgpr(112), which keeps the register
+    // allocator below them): always HELPER_SLOTS loads per turn (unused slots load word 0 and are masked at the
     // consume step), consumed behind s_waitcnt vmcnt(HELPER_SLOTS).  Helper waves issue no other vector memory
     // operation.
     constexpr int HELPER_SLOTS = 4;
@@ -1029,7 +1029,8 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
     }
 }
 
-__global__ __launch_bounds__(SWEEP_BLOCK) void nms_sweep_pipelined_kernel(SweepArgs A) {
+// (amdgpu_num_vgpr(112): the register allocator stays below v112, which the helpers' asm statements own)
+__global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_num_vgpr(112))) void nms_sweep_pipelined_kernel(SweepArgs A) {
     extern __shared__ unsigned long long sweep_dyn[];        // the kept list
     __shared__ SweepShared sh;
     nms_sweep_pipelined_block(A, blockIdx.x, reinterpret_cast<int *>(sweep_dyn), sh);
@@ -1071,7 +1072,7 @@ struct SegTable {
     int start[MASK_MAX_SEGS + 1];       // start[s] = (row block, segment) pairs of the segments before s
 };
 
-__global__ __launch_bounds__(SWEEP_BLOCK) void nms_mask_sweep_fused_kernel(MaskArgs M, SweepArgs S, int n_images, int nseg, SegTable table,
+__global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_num_vgpr(112))) void nms_mask_sweep_fused_kernel(MaskArgs M, SweepArgs S, int n_images, int nseg, SegTable table,
                                                                             int *ctl) {
     extern __shared__ unsigned long long sweep_dyn[];
     __shared__ SweepShared sh;
