@@ -1157,6 +1157,18 @@ size_t nms_summary_alloc_words(int n_images, int n_max) {
     return (size_t)n_images * pitch * pitch + ((size_t)n_images * pitch + 1) / 2;
 }
 
+// CUs of the current device (asked once per device; 0 when the runtime cannot tell: no fused launch then)
+static int device_cu_count() {
+    static int count[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (count[dev] == 0) {
+        int n = 0;
+        count[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : -1;
+    }
+    return count[dev] > 0 ? count[dev] : 0;
+}
+
 static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n_dev, int n_max, int n_images,
                             double thresh, unsigned long long *mask, unsigned long long *diag_t,
                             unsigned long long *summ, int max_keep, const int *order, int order_stride_img,
@@ -1193,9 +1205,10 @@ int launch_nms_two_pass(const float *boxes, int box_stride_img, const int *n_dev
     const int probe = done ? nms_probe_size(n_max, max_keep) : n_max;
     const int NO_LIMIT = 0x7fffffff;
     int rc;
-    // (n_images <= 64: the sweeps must leave workgroup slots for the mask blocks they wait for)
+    // (the sweeps hold one workgroup slot each -- one CU each, at 128 VGPRs -- for the whole launch and wait for
+    // mask blocks that need the other slots: at most a quarter of the device's CUs, and never more than 64)
     if (probe >= n_max && tuning().nms_fused != 0 && nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) &&
-        n_max >= 2048 && n_max % 16 == 0 && n_images <= 64)
+        n_max >= 2048 && n_max % 16 == 0 && n_images <= 64 && 4 * n_images <= device_cu_count())
         return launch_nms_fused(boxes, box_stride_img, n_dev, n_max, n_images, thresh, mask, diag_t, summ, max_keep,
                                 order, order_stride_img, keep, num_keep, rois_padded, st);
     if (probe >= n_max) {
