@@ -895,9 +895,9 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
     // flight, and the one issued an iteration ago must not be waited for when the one issued two iterations
     // ago is consumed.  The compiler's wait insertion cannot express that across the loop (it waits for
     // everything), and it may COPY a loop-carried register whose load is still in flight if the load is hidden
-    // in inline asm with an ordinary operand.  So the batches live in sixteen FIXED registers, v112-v127, that
-    // only the asm statements below name (both kernels carry amdgpu_num_vgpr(112), which keeps the register
-    // allocator below them): always HELPER_SLOTS loads per turn (unused slots load word 0 and are masked at the
+    // in inline asm with an ordinary operand.  So the batches live in sixteen FIXED registers, v80-v95, that
+    // only the asm statements below name (both kernels carry amdgpu_num_vgpr(80), which keeps the register
+    // allocator below them; 96 VGPRs in all -- see the fused kernel for why not the top of a 128 budget): always HELPER_SLOTS loads per turn (unused slots load word 0 and are masked at the
     // consume step), consumed behind s_waitcnt vmcnt(HELPER_SLOTS).  Helper waves issue no other vector memory
     // operation.
     constexpr int HELPER_SLOTS = 4;
@@ -925,12 +925,12 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
         else if (j == 2) asm volatile("global_load_dwordx2 " P2 ", %0, off" : : "v"(src) : "memory", C4, C5);           \
         else asm volatile("global_load_dwordx2 " P3 ", %0, off" : : "v"(src) : "memory", C6, C7);                       \
     }
-    auto take_a = WSSDL_TAKE("v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119");
-    auto take_b = WSSDL_TAKE("v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
-    auto issue_a = WSSDL_ISSUE("v[112:113]", "v[114:115]", "v[116:117]", "v[118:119]", "v112", "v113", "v114", "v115", "v116",
-                               "v117", "v118", "v119");
-    auto issue_b = WSSDL_ISSUE("v[120:121]", "v[122:123]", "v[124:125]", "v[126:127]", "v120", "v121", "v122", "v123", "v124",
-                               "v125", "v126", "v127");
+    auto take_a = WSSDL_TAKE("v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87");
+    auto take_b = WSSDL_TAKE("v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+    auto issue_a = WSSDL_ISSUE("v[80:81]", "v[82:83]", "v[84:85]", "v[86:87]", "v80", "v81", "v82", "v83", "v84",
+                               "v85", "v86", "v87");
+    auto issue_b = WSSDL_ISSUE("v[88:89]", "v[90:91]", "v[92:93]", "v[94:95]", "v88", "v89", "v90", "v91", "v92",
+                               "v93", "v94", "v95");
 #undef WSSDL_TAKE
 #undef WSSDL_ISSUE
     const int hall = hw * 64 + lane;
@@ -1029,8 +1029,8 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
     }
 }
 
-// (amdgpu_num_vgpr(112): the register allocator stays below v112, which the helpers' asm statements own)
-__global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_num_vgpr(112))) void nms_sweep_pipelined_kernel(SweepArgs A) {
+// (amdgpu_num_vgpr(80): the register allocator stays below v80, which the helpers' asm statements own)
+__global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_num_vgpr(80))) void nms_sweep_pipelined_kernel(SweepArgs A) {
     extern __shared__ unsigned long long sweep_dyn[];        // the kept list
     __shared__ SweepShared sh;
     nms_sweep_pipelined_block(A, blockIdx.x, reinterpret_cast<int *>(sweep_dyn), sh);
@@ -1063,16 +1063,21 @@ __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_num_vgpr(112))) 
 // * mask WORKERS that draw blocks from a queue, as many as the chip holds: any loop around the mask block --
 //   queue, static stride, even a single trip -- made the whole launch 7x slower (not understood; the same
 //   block without the loop runs at full speed).
-// What did: NOT capping the kernel at 64 VGPRs.  The cap bought the mask role 8 waves per SIMD (two workgroups
-// per CU, 0.20 -> 0.17 ms) and cost the sweep role 5 spilled VGPRs and 55 SGPRs spilled to lanes, in the
-// resolver's loop: 1.4 us per chunk even with the mask finished.  Uncapped (78 VGPRs, one workgroup per CU)
-// the bench's full-walk steps went 0.32 -> 0.25 ms for the launch.
+// What did: the register count, twice.  (1) NOT capping the kernel at 64 VGPRs: the cap bought the mask role 8
+// waves per SIMD (two workgroups per CU, 0.20 -> 0.17 ms) and cost the sweep role 5 spilled VGPRs and 55 SGPRs
+// spilled to lanes, in the resolver's loop: 1.4 us per chunk even with the mask finished.  Uncapped (78 VGPRs,
+// one workgroup per CU) the bench's full-walk steps went 0.32 -> 0.25 ms for the launch.  (2) NOT using all 128:
+// one 16-wave workgroup fits a CU from 65 to 128 VGPRs, but at 128 it owns every register of the CU and the next
+// mask workgroup cannot start before the last wave of the previous one has finished (its four mask blocks end
+// at different times); at 96 a SIMD holds five waves, so the next workgroup's waves move in while the previous
+// one drains.  With the helpers' sixteen reserved registers at v112-v127 (128 in all) the 8-image layer took
+// 0.303-0.305 ms in the bench's steps, at v80-v95 (96 in all) 0.275-0.277, same box, alternating runs.
 constexpr int MASK_MAX_SEGS = SWEEP_MAX_CHUNKS / MASK_SEG;
 struct SegTable {
     int start[MASK_MAX_SEGS + 1];       // start[s] = (row block, segment) pairs of the segments before s
 };
 
-__global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_num_vgpr(112))) void nms_mask_sweep_fused_kernel(MaskArgs M, SweepArgs S, int n_images, int nseg, SegTable table,
+__global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_num_vgpr(80))) void nms_mask_sweep_fused_kernel(MaskArgs M, SweepArgs S, int n_images, int nseg, SegTable table,
                                                                             int *ctl) {
     extern __shared__ unsigned long long sweep_dyn[];
     __shared__ SweepShared sh;
