@@ -897,7 +897,8 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
     // everything), and it may COPY a loop-carried register whose load is still in flight if the load is hidden
     // in inline asm with an ordinary operand.  So the batches live in sixteen FIXED registers, v80-v95, that
     // only the asm statements below name (both kernels carry amdgpu_num_vgpr(80), which keeps the register
-    // allocator below them; 96 VGPRs in all -- see the fused kernel for why not the top of a 128 budget): always HELPER_SLOTS loads per turn (unused slots load word 0 and are masked at the
+    // allocator below them -- a request, which tests/test_isa_reserved_registers.py checks in the built library;
+    // 96 VGPRs in all -- see the fused kernel for why not the top of a 128 budget): always HELPER_SLOTS loads per turn (unused slots load word 0 and are masked at the
     // consume step), consumed behind s_waitcnt vmcnt(HELPER_SLOTS).  Helper waves issue no other vector memory
     // operation.
     constexpr int HELPER_SLOTS = 4;
