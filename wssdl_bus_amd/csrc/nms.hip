@@ -344,6 +344,9 @@ struct MaskArgs {
     double thresh;  unsigned long long *mask;  int ncb;          // ncb: row pitch of mask (nms_mask_pitch)
     unsigned long long *diag_t;  unsigned long long *summ;      // summ: [n_images][ncb column blocks][ncb row blocks]
     int n_limit;  int cb_min;  const int *done;  int dense_ahead;
+    // fused launch: finished[img * finished_stride] != 0 once the image's sweep has all it wants (the block is
+    // skipped); NULL otherwise
+    const int *finished;  int finished_stride;
 };
 
 // COHERENT: the words are read by a sweep that runs beside this kernel, possibly on another XCD (whose
@@ -373,11 +376,16 @@ __device__ __forceinline__ void nms_mask_block(const MaskArgs &A, int rb, int se
     const float *b = boxes + (size_t)img * box_stride_img;
     const int i = rb * 64 + lane;
     const bool row_ok = i < n;
+    // (the finished flag travels beside the row boxes: one exposed latency for both)
+    int fin = 0;
+    if (COHERENT && A.finished)
+        fin = __hip_atomic_load(A.finished + (size_t)img * A.finished_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float ix1 = 0.f, iy1 = 0.f, ix2 = 0.f, iy2 = 0.f;
     if (row_ok) {
         const nms_float4v v = *reinterpret_cast<const nms_float4v *>(b + (size_t)i * 4);
         ix1 = v.x; iy1 = v.y; ix2 = v.z; iy2 = v.w;
     }
+    if (fin) return;
     const float iarea = box_area_ref(ix1, iy1, ix2, iy2);
     const float t_lo = (float)(thresh * (1.0 - 1e-4)), t_hi = (float)(thresh * (1.0 + 1e-4));
     // Prefilter.  ovr >= t  =>  inter >= f (area_i + area_j), f = t / (1 + t); with
@@ -538,7 +546,7 @@ int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, in
     // (the second pass of a two-pass run adds the column blocks >= cb_min to the summary of the first)
     const int ncb_eff = cdiv(min(n_max, n_limit), 64);      // row / column blocks this pass can touch
     const MaskArgs A = {boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, n_limit, cb_min, done,
-                        nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) ? NMS_DENSE_AHEAD : -1};
+                        nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) ? NMS_DENSE_AHEAD : -1, nullptr, 0};
     hipLaunchKernelGGL(nms_mask_kernel, dim3(ncb_eff, cdiv(ncb_eff, MASK_SEG), n_images), dim3(64 * MASK_WAVES), 0, st, A);
     return check_launch();
 }
@@ -1082,7 +1090,6 @@ __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_num_vgpr(80))) v
                                                                             int *ctl) {
     extern __shared__ unsigned long long sweep_dyn[];
     __shared__ SweepShared sh;
-    __shared__ int s_done[64];
     const int ncb = M.ncb;
     if ((int)blockIdx.x < n_images) {
         nms_sweep_pipelined_block(S, blockIdx.x, reinterpret_cast<int *>(sweep_dyn), sh);
@@ -1092,9 +1099,6 @@ __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_num_vgpr(80))) v
     }
     // 16 waves = 4 mask blocks; mask block v = (pair * n_images + img), pairs ordered by segment, then row block
     const int tid = threadIdx.x, lane = tid & 63, pw = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < 64)
-        s_done[tid] = tid < n_images ? __hip_atomic_load(ctl + (size_t)tid * ncb + ncb - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    __syncthreads();
     const long long v = ((long long)blockIdx.x - n_images) * (SWEEP_BLOCK / 64 / MASK_WAVES) + (pw / MASK_WAVES);
     if (v >= (long long)table.start[nseg] * n_images) return;
     const int img = (int)(v % n_images);
@@ -1105,7 +1109,7 @@ __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_num_vgpr(80))) v
     float (*cbox)[5][64] = reinterpret_cast<float (*)[5][64]>(sweep_dyn);
     nms_float4v (*cgeo)[64] = reinterpret_cast<nms_float4v (*)[64]>(reinterpret_cast<char *>(sweep_dyn) +
                                                                      sizeof(float) * (SWEEP_BLOCK / 64) * 5 * 64);
-    if (!s_done[img]) nms_mask_block<true>(M, rb, seg, img, pw % MASK_WAVES, lane, cbox[pw], cgeo[pw]);
+    nms_mask_block<true>(M, rb, seg, img, pw % MASK_WAVES, lane, cbox[pw], cgeo[pw]);
     // this wave's words (and its entries of the summary and of diag_t) have been written through: once they
     // are acknowledged, count the segment up
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1185,7 +1189,7 @@ static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n
     // the control words = 0 (the summaries need no initialisation: every entry that is read is written)
     if (hipMemsetAsync(segdone, 0, sizeof(int) * (size_t)n_images * ncb, st) != hipSuccess) return WSSDL_ERR_LAUNCH;
     const MaskArgs M = {boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, 0x7fffffff, 0, nullptr,
-                        NMS_DENSE_AHEAD};
+                        NMS_DENSE_AHEAD, segdone + ncb - 2, ncb};
     const SweepArgs S = {mask, diag_t, summ, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
                          boxes, box_stride_img, rois_padded, 0x7fffffff, nullptr, nullptr, segdone, nrb};
     const size_t lds_mask = (size_t)(SWEEP_BLOCK / 64) * (5 * 64 * sizeof(float) + 64 * sizeof(nms_float4v));
