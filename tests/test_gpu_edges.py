@@ -400,6 +400,57 @@ def test_proposal_target_device_sampling(torch_cuda):
         cfg.SAMPLING_RNG, cfg.DEVICE_RNG_SEED = old
 
 
+@pytest.mark.gpu
+def test_proposal_target_device_sampling_with_interleaved_images(torch_cuda):
+    """The device sampler walks the span of the candidate list that holds its image's rows (one stretch when the
+    proposal blob is ordered by image); with the images' rows INTERLEAVED the spans overlap and cover nearly the
+    whole list -- quotas, thresholds, membership and the absence of duplicates must not change."""
+    import torch
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.rpn_msr import proposal_target_layer_tf_bus as ptl
+    g = load_golden("proposal_target")
+    rois, gt, ng = g["rois_in"], g["gt_boxes"], g["num_gt"]
+    rois = rois[np.random.RandomState(3).permutation(rois.shape[0])]
+    n_img = gt.shape[0]
+    dev = torch.device("cuda", 0)
+    old = cfg.SAMPLING_RNG, cfg.DEVICE_RNG_SEED
+    cfg.SAMPLING_RNG, cfg.DEVICE_RNG_SEED = "device", 21
+    try:
+        o = ptl.proposal_target_layer(torch.from_numpy(rois).to(dev), torch.from_numpy(gt).to(dev),
+                                      torch.from_numpy(ng.astype(np.int32)).to(dev), 3, True, False)
+        out_rois, labels = o[0].cpu().numpy(), o[1].cpu().numpy()[:, 0]
+        rpi = int(cfg.TRAIN.BATCH_SIZE)
+        fg_rpi = int(np.round(cfg.TRAIN.FG_FRACTION * rpi))
+        row = 0
+        for i in range(n_img):
+            npos = int(np.sum(gt[i, :ng[i], 4] != 0))
+            cand = np.vstack([rois[rois[:, 0] == i],
+                              np.hstack([np.full((npos, 1), i, np.float32), gt[i, :npos, :4]])])
+            mo = O.c_oracle.bbox_overlaps(cand[:, 1:5].astype(np.float64), gt[i, :npos, :4].astype(np.float64)).max(axis=1)
+            n_fg = min(fg_rpi, int(np.sum(mo >= cfg.TRAIN.FG_THRESH)))
+            n_bg = min(rpi - n_fg, int(np.sum((mo < cfg.TRAIN.BG_THRESH_HI) & (mo >= cfg.TRAIN.BG_THRESH_LO))))
+            blk = out_rois[row:row + n_fg + n_bg]
+            assert np.all(blk[:, 0] == i)
+            lookup = {}
+            for j, r in enumerate(cand.tolist()):
+                lookup.setdefault(tuple(r), []).append(j)
+            idx = []
+            for r in blk.tolist():
+                assert tuple(r) in lookup
+                idx.append(lookup[tuple(r)][0])
+            idx = np.array(idx)
+            assert np.all(mo[idx[:n_fg]] >= cfg.TRAIN.FG_THRESH) and np.all(labels[row:row + n_fg] > 0)
+            assert np.all((mo[idx[n_fg:]] < cfg.TRAIN.BG_THRESH_HI) & (mo[idx[n_fg:]] >= cfg.TRAIN.BG_THRESH_LO))
+            # no candidate drawn more often than it occurs in the list
+            from collections import Counter
+            drawn = Counter(tuple(r) for r in blk.tolist())
+            assert all(drawn[k] <= len(lookup[k]) for k in drawn)
+            row += n_fg + n_bg
+        assert row == out_rois.shape[0]
+    finally:
+        cfg.SAMPLING_RNG, cfg.DEVICE_RNG_SEED = old
+
+
 # ----------------------------------------------------------- NMS: suppression chains ---
 def test_nms_suppression_chains(torch_cuda):
     """Worst cases for the sweep's fixed-point resolver: inside a 64-box chunk every box
