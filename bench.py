@@ -289,6 +289,39 @@ def hbm_traffic(kernel_key, meta):
     return None, "kernel not in profiles/hotpath_traffic.json"
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the launcher the scaling run
+    uses (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`) as a CHILD process,
+    hand on rank 0's one JSON line and the exit code.  Called before torch / HIP are imported: this process
+    never touches the GPU, and nothing is exec'ed over a process that did."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, universal_newlines=True)
+    lines = []
+    for line in proc.stdout:
+        is_result = False
+        if line.lstrip().startswith("{"):
+            try:
+                is_result = "metric" in json.loads(line)
+            except ValueError:
+                pass
+        if is_result:
+            lines.append(line.rstrip("\n"))
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    for line in lines[-1:]:
+        print(line, flush=True)
+    return rc if rc else (0 if lines else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,11 +346,16 @@ def main():
     ap.add_argument("--padded-rois", action="store_true",
                     help="fixed-shape RoI blob (dead rows carry batch index -1): no device->host copy between "
                          "the backbone and the loss; the per-RoI head then runs on the padded row count")
+    ap.add_argument("--save-fixed-rois", default="", metavar="PATH.npy",
+                    help="write the RoI set of the roofline leg (float32 [R,5]) to this file (lab use: the sets of "
+                         "the workloads other than the default are built from the run's own network)")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT",
                     help="wssdl_set_tuning(KEY, INT) before the run, for A/B comparisons (e.g. nms_fused=0); repeatable")
     ap.add_argument("--roi-bwd-plan", type=int, default=-1,
                     help="force a plan of the list-driven RoI-pool backward (wssdl_set_tuning roi_bwd_plan; -1 = automatic)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # before MIOpen initialises.  No usable find-db -> no find mode (a search costs minutes per rank)
     miopen_db, miopen_db_note = (None, "--no-miopen-benchmark") if args.no_miopen_benchmark else seed_miopen_db()
@@ -406,6 +444,7 @@ def main():
     elapsed = time.perf_counter() - t0
     _lib.timeline.enabled = False
     elapsed = ctx.max_over_ranks(elapsed)
+    n_ranks_seen = ctx.count_ranks()      # a sum of ones over the job's collective backend
     loss_val = float(out["loss"].detach()) if isinstance(out, dict) and torch.is_tensor(out.get("loss")) else None
 
     def measured_copy_gbps():
@@ -429,6 +468,8 @@ def main():
     feat_key = "conv5_3" if wl["net"].startswith("VGG") else "group2/relu"
     leg_blobs = blobs_s if mode == "alter" else blobs
     rois_fixed, roi_tag = fixed_roi_set(wl, net, leg_blobs)
+    if args.save_fixed_rois and ctx.rank == 0:
+        np.save(args.save_fixed_rois, rois_fixed)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import roofline_leg
     N_leg = int(leg_blobs["data"].shape[0])
@@ -492,7 +533,7 @@ def main():
             "metric": "images/sec (train step, 600x1000)" if mode != "test" else "images/sec (test forward, 1000x1600)",
             "value": round(images_per_step * ctx.world_size * args.steps / elapsed, 3),
             "unit": "images/s",
-            "n_gpus": ctx.world_size, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": ctx.world_size, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

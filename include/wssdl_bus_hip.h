@@ -109,6 +109,15 @@ WSSDL_API int wssdl_bbox_overlaps_ui(const double *boxes, int64_t N, int box_str
 WSSDL_API size_t wssdl_nms_workspace_bytes(int n);
 WSSDL_API int wssdl_nms(const float *dets, int n, double thresh, int max_keep, int32_t *keep,
               int32_t *num_keep, void *workspace, size_t workspace_bytes, wssdl_stream_t stream);
+/* The test path's NMS is a second file with the same rule: utils/nms.pyx:17-68 `nms` (imported as
+ * utils.cython_nms at fast_rcnn/test_bus.py:10, called at :293,366,375) == wssdl_nms.
+ * nms_new: utils/nms.pyx:70-123 (imported at test_bus.py:10, never called by the reference): box j is also
+ * suppressed when it lies almost inside the kept box i or the other way round,
+ *   ovr >= thresh  or  (double)(inter / area_i) > 0.95  or  (double)(inter / area_j) > 0.95
+ * (:118-121; ovr1 / ovr2 are untyped there, i.e. the f32 quotients widened to Python floats).
+ * Same arguments, workspace and outputs as wssdl_nms. */
+WSSDL_API int wssdl_nms_new(const float *dets, int n, double thresh, int max_keep, int32_t *keep,
+              int32_t *num_keep, void *workspace, size_t workspace_bytes, wssdl_stream_t stream);
 
 /* ------------------------------------------------------------ a6, a7, a8, a9 ---
  * proposal_layer: rpn_msr/proposal_layer_tf_bus.py:19-148 for all N images in
@@ -391,8 +400,9 @@ WSSDL_API int wssdl_mil_loss_backward(const float *instance_logits, int R, int n
  * The pinnable half of the host image path, on the device.  utils/blob.py:34-79
  * (prep_im_for_blob), :19-32 (im_list_to_blob), roi_data_layer/minibatch_bus.py:269-272 (grey plane
  * stacked three times, horizontal flip), datasets/imdb.py:106-121 (boxes of flipped images).
- * skimage.transform.resize (blob.py:74-77) is NOT part of this library (not pinnable: absent,
- * version unknown); the path is cut around it:
+ * skimage.transform.resize (blob.py:74-77) sits in the middle: the steps around it are pinned by
+ * fixtures from the reference's own blob.py, the resize follows the published algorithm of the
+ * release the reference's README pins (scikit-image 0.14.2; the library is absent: parity unpinned):
  *   wssdl_image_prep     gray [h, row_stride] u8 -> out [h,w,3] f32 = what the reference hands to
  *                        the resize: flip, /255, optional brightness (+delta, clip to [0,1]),
  *                        optional contrast ((x - mean(x)) * factor + mean(x), clip), - pixel_mean/255.
@@ -401,7 +411,34 @@ WSSDL_API int wssdl_mil_loss_backward(const float *instance_logits, int R, int n
  *   wssdl_image_to_blob  im [h,w,3] f64 (im_is_f64) or f32 = the resize's output -> blob
  *                        [n_images,Hmax,Wmax,3] f32, image `index`: x / scale (divide != 0: ResNet,
  *                        scale = pixel_std/255) or x * scale (VGG: 255), zero outside [h,w].
- *   wssdl_flip_boxes     in place on boxes [n, stride >= 4] f32: x1' = width - x2 - 1, x2' = width - x1 - 1. */
+ *   wssdl_flip_boxes     in place on boxes [n, stride >= 4] f32: x1' = width - x2 - 1, x2' = width - x1 - 1.
+ *   wssdl_image_resize   skimage.transform.resize(im, [rows, cols]) as blob.py:74-77 / fast_rcnn/test_bus.py:54-56 call
+ *                        it (0.14 defaults: order 1, mode 'constant', cval 0, clip, no anti-aliasing):
+ *                        im [h,w,channels] f32 or f64 (im_is_f64) -> out [rows,cols,channels] f64.
+ *                        out(row, col) interpolates the input bilinearly at
+ *                        (h/rows * (row + 0.5) - 0.5, w/cols * (col + 0.5) - 0.5); samples outside the
+ *                        image read 0; the result is clipped to the input's [min, max].
+ *   wssdl_image_warp     the general form = skimage.transform.warp(im, matrix, output_shape=(rows, cols),
+ *                        order=1, mode, cval, clip): `matrix` = 9 doubles in HOST memory, row-major 3x3
+ *                        inverse map (output (col,row,1) -> input (col,row,w)); serves rotate()
+ *                        (blob.py:39-41) and a caller that brings skimage's own estimated matrix.
+ *                        workspace: wssdl_image_warp_workspace_bytes (only read when clip != 0).
+ *   wssdl_image_adjust_f64  blob.py:49-60 on the float64 image rotate() returns (weak images with
+ *                        cfg.TRAIN.USE_ROTATION, :39-41): im = strided view [h,w,channels] f64 (row_stride in
+ *                        elements; the crop :43-47 is a slice), the same brightness / contrast / mean steps as
+ *                        wssdl_image_prep in f64 -> out [h,w,channels] f64 contiguous (the resize's input).
+ *                        workspace: wssdl_image_prep_workspace_bytes. */
+#define WSSDL_WARP_CONSTANT 0    /* mode='constant': cval outside the image */
+#define WSSDL_WARP_EDGE 1        /* mode='edge': nearest edge pixel */
+WSSDL_API size_t wssdl_image_warp_workspace_bytes(void);
+WSSDL_API int wssdl_image_warp(const void *im, int im_is_f64, int h, int w, int channels, const double *matrix,
+                     int rows, int cols, int mode, double cval, int clip, double *out, void *workspace,
+                     size_t workspace_bytes, wssdl_stream_t stream);
+WSSDL_API int wssdl_image_resize(const void *im, int im_is_f64, int h, int w, int channels, int rows, int cols,
+                     double *out, void *workspace, size_t workspace_bytes, wssdl_stream_t stream);
+WSSDL_API int wssdl_image_adjust_f64(const double *im, int h, int w, int channels, int64_t row_stride,
+                     int use_brightness, double brightness_delta, int use_contrast, double contrast_factor,
+                     double pixel_mean, double *out, void *workspace, size_t workspace_bytes, wssdl_stream_t stream);
 WSSDL_API size_t wssdl_image_prep_workspace_bytes(void);
 WSSDL_API int wssdl_image_prep(const uint8_t *gray, int h, int w, int row_stride, int flipped,
                      int use_brightness, float brightness_delta, int use_contrast,

@@ -9,8 +9,10 @@ deleted, so no reference source text is ever kept in this repo):
   cython_bbox.so     <- code/lib/utils/bbox.pyx     (bbox_overlaps,    unmodified)
   cython_bbox_ui.so  <- code/lib/utils/bbox_ui.pyx  (bbox_overlaps_ui, unmodified)
   cpu_nms.so         <- code/lib/nms/cpu_nms.pyx    (cpu_nms; dtype-alias patch only)
+  cython_nms.so      <- code/lib/utils/nms.pyx      (nms, nms_new: the file fast_rcnn/test_bus.py:10 imports for
+                                                     the per-class NMS of the test path; same alias patch)
 
-``cpu_nms.pyx`` names NumPy aliases that NumPy 2 no longer has.  The recipe pipes
+``cpu_nms.pyx`` and ``utils/nms.pyx`` name NumPy aliases that NumPy 2 no longer has.  The recipe pipes
 the file through three textual alias substitutions on its way to Cython (never
 written back, never stored here): ``np.int_t -> np.intp_t``, ``dtype=np.int ->
 dtype=np.intp`` and the argument annotation ``np.float thresh -> thresh`` (an
@@ -46,6 +48,7 @@ TARGETS = [
     ("cython_bbox", "utils/bbox.pyx", False),
     ("cython_bbox_ui", "utils/bbox_ui.pyx", False),
     ("cpu_nms", "nms/cpu_nms.pyx", True),
+    ("cython_nms", "utils/nms.pyx", True),
 ]
 
 _ALIAS_SUBS = [

@@ -79,8 +79,27 @@ static inline float f32min(float a, float b) { return a <= b ? a : b; }   /* cpu
  * that the tie rule is NumPy's, cpu_nms.pyx:25).  All box arithmetic is f32;
  * the threshold test is (double)ovr >= thresh (vendored cpu_nms.c:2495 compares
  * PyFloat objects).  Returns the number of kept indices written to keep[]. */
+static int64_t nms_greedy(const float *dets, int64_t n, const int64_t *order,
+                          double thresh, int64_t *keep, int contain);
+
 int64_t orc_cpu_nms(const float *dets, int64_t n, const int64_t *order,
                     double thresh, int64_t *keep)
+{
+    return nms_greedy(dets, n, order, thresh, keep, 0);
+}
+
+/* follows code/lib/utils/nms.pyx:70-123 (`nms_new`; `nms` :17-68 of that file is line for line the
+ * rule of cpu_nms.pyx, i.e. orc_cpu_nms).  ovr1 / ovr2 are not cdef'd there: the f32 quotients
+ * inter / iarea and inter / areas[j] become Python floats and are compared with 0.95 in f64
+ * (:116-118); a box is suppressed when `ovr >= thresh or ovr1 > 0.95 or ovr2 > 0.95`. */
+int64_t orc_nms_new(const float *dets, int64_t n, const int64_t *order,
+                    double thresh, int64_t *keep)
+{
+    return nms_greedy(dets, n, order, thresh, keep, 1);
+}
+
+static int64_t nms_greedy(const float *dets, int64_t n, const int64_t *order,
+                          double thresh, int64_t *keep, int contain)
 {
     float *areas = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
     unsigned char *sup = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
@@ -120,6 +139,12 @@ int64_t orc_cpu_nms(const float *dets, int64_t n, const int64_t *order,
             float ovr = inter / den;
             if ((double)ovr >= thresh)
                 sup[j] = 1;
+            else if (contain) {                               /* nms.pyx:116-121 */
+                float ovr1 = inter / iarea;
+                float ovr2 = inter / areas[j];
+                if ((double)ovr1 > 0.95 || (double)ovr2 > 0.95)
+                    sup[j] = 1;
+            }
         }
     }
     free(areas);

@@ -44,6 +44,8 @@ def lib():
             L.orc_bbox_overlaps_ui.restype = None
             L.orc_cpu_nms.argtypes = [fp, i64, lp, ctypes.c_double, lp]
             L.orc_cpu_nms.restype = i64
+            L.orc_nms_new.argtypes = [fp, i64, lp, ctypes.c_double, lp]
+            L.orc_nms_new.restype = i64
             L.orc_roi_pool_forward.argtypes = [fp, i32, i32, i32, i32, fp, i32, i32, i32,
                                                ctypes.c_float, i32, fp, ip]
             L.orc_roi_pool_forward.restype = None
@@ -93,6 +95,17 @@ def cpu_nms(dets, thresh):
     order = np.ascontiguousarray(dets[:, 4].argsort()[::-1], dtype=np.int64)  # cpu_nms.pyx:25
     keep = np.empty(max(n, 1), dtype=np.int64)
     nk = lib().orc_cpu_nms(_p(dets, ctypes.c_float), n, _p(order, ctypes.c_int64),
+                           float(thresh), _p(keep, ctypes.c_int64))
+    return [int(k) for k in keep[:nk]]
+
+
+def nms_new(dets, thresh):
+    """utils/nms.pyx:70-123."""
+    dets = np.ascontiguousarray(dets, dtype=np.float32)
+    n = dets.shape[0]
+    order = np.ascontiguousarray(dets[:, 4].argsort()[::-1], dtype=np.int64)  # nms.pyx:78
+    keep = np.empty(max(n, 1), dtype=np.int64)
+    nk = lib().orc_nms_new(_p(dets, ctypes.c_float), n, _p(order, ctypes.c_int64),
                            float(thresh), _p(keep, ctypes.c_int64))
     return [int(k) for k in keep[:nk]]
 

@@ -3,8 +3,8 @@
 bench.py's cpu_baseline leg; never by the product path).
 
 Exposes ``bbox_overlaps`` (code/lib/utils/bbox.pyx:15), ``bbox_overlaps_ui``
-(code/lib/utils/bbox_ui.pyx:12) and ``cpu_nms`` (code/lib/nms/cpu_nms.pyx:17), or
-``None`` for each when the build is absent.
+(code/lib/utils/bbox_ui.pyx:12), ``cpu_nms`` (code/lib/nms/cpu_nms.pyx:17) and the test path's
+``nms`` / ``nms_new`` (code/lib/utils/nms.pyx:17,70), or ``None`` for each when the build is absent.
 """
 import importlib.util
 import os
@@ -30,10 +30,13 @@ def _load(mod):
 _bbox = _load("cython_bbox")
 _bbox_ui = _load("cython_bbox_ui")
 _nms = _load("cpu_nms")
+_cython_nms = _load("cython_nms")
 
 bbox_overlaps = getattr(_bbox, "bbox_overlaps", None)
 bbox_overlaps_ui = getattr(_bbox_ui, "bbox_overlaps_ui", None)
 cpu_nms = getattr(_nms, "cpu_nms", None)
+nms = getattr(_cython_nms, "nms", None)                # utils/nms.pyx:17
+nms_new = getattr(_cython_nms, "nms_new", None)        # utils/nms.pyx:70
 
 
 def available():

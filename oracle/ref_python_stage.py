@@ -104,6 +104,8 @@ def stage():
                os.path.join(root, "utils", "cython_bbox_ui.so"))
     os.symlink(os.path.join(ref_so, "cpu_nms.so"),
                os.path.join(root, "nms", "cpu_nms.so"))
+    os.symlink(os.path.join(ref_so, "cython_nms.so"),
+               os.path.join(root, "utils", "cython_nms.so"))
     for name, typ in (("float", float), ("int", int), ("bool", bool)):
         if not hasattr(np, name):
             setattr(np, name, typ)
@@ -131,6 +133,7 @@ def load():
     cb = importlib.import_module("utils.cython_bbox")
     cu = importlib.import_module("utils.cython_bbox_ui")
     cn = importlib.import_module("nms.cpu_nms")
+    un = importlib.import_module("utils.cython_nms")      # the test path's NMS (fast_rcnn/test_bus.py:10)
     r.cfg = cf.cfg
     r.generate_anchors = ga.generate_anchors
     r.anchor_target_layer = at.anchor_target_layer
@@ -146,5 +149,7 @@ def load():
     r.bbox_overlaps = cb.bbox_overlaps
     r.bbox_overlaps_ui = cu.bbox_overlaps_ui
     r.cpu_nms = cn.cpu_nms
+    r.utils_nms = un.nms
+    r.utils_nms_new = un.nms_new
     r.modules = dict(at=at, pl=pl, pt=pt)
     return r

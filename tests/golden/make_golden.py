@@ -219,6 +219,48 @@ def main():
     out["unsorted/keep_07"] = np.asarray(R.cpu_nms(dets, 0.7), dtype=np.int32)
     save("nms", **out)
 
+    # ---- f3: the test path's NMS, utils/nms.pyx (`nms` :17-68, `nms_new` :70-123) --------------
+    # the same det sets as above at the test threshold 0.3 (config.py:238) and at 0.7, plus a set built
+    # for nms_new's containment terms: small boxes inside large ones (low IoU, inter / area_small = 1),
+    # pairs whose inter / area sits on either side of 0.95, and the f32 neighbours of 0.95 itself
+    # (100 x 100 against 95 x 100: 0.95 in exact arithmetic; 19 of 20 columns)
+    out2 = {}
+    for n in (1, 2, 64, 65, 300, 6000, 12000):
+        dets = out["n%d/dets" % n]
+        for th in (0.3, 0.7):
+            out2["n%d/nms_%02d" % (n, int(th * 10))] = np.asarray(R.utils_nms(dets, th), dtype=np.int32)
+            out2["n%d/nms_new_%02d" % (n, int(th * 10))] = np.asarray(R.utils_nms_new(dets, th), dtype=np.int32)
+    rs = np.random.RandomState(77)
+    big = np.hstack((rs.uniform(0, 600, size=(40, 2)), np.zeros((40, 2))))
+    big[:, 2:] = big[:, :2] + rs.uniform(120, 380, size=(40, 2))
+    rows = [big]
+    for k in range(40):
+        x1, y1, x2, y2 = big[k]
+        w, h = x2 - x1 + 1, y2 - y1 + 1
+        inner = []
+        for f in (0.2, 0.5, 0.9, 0.94, 0.96):                 # nested at the corner: inter / area_big = f * 1
+            inner.append([x1, y1, x1 + f * w - 1, y2])
+        for f in (0.02, 0.05, 0.5):                           # small box sticking out by a fraction f of its width
+            sw = 0.2 * w
+            inner.append([x2 - (1 - f) * sw, y1 + 5, x2 + f * sw, y1 + 5 + 0.2 * h])
+        rows.append(np.array(inner))
+    exact = np.array([[0, 700, 99, 799], [0, 700, 94, 799], [200, 700, 299, 799], [200, 700, 294, 798],
+                      [400, 700, 419, 719], [400, 700, 418, 719], [400, 700, 419, 718]], dtype=np.float64)
+    b = np.vstack(rows + [exact])
+    n = b.shape[0]
+    sc = rs.permutation(n).astype(np.float64) / n + rs.uniform(0, 0.1 / n, size=n)
+    dets = np.hstack((b, sc[:, None])).astype(np.float32)
+    assert len(np.unique(dets[:, 4])) == n
+    out2["contain/dets"] = dets
+    for th in (0.3, 0.5, 0.7):
+        out2["contain/nms_%02d" % int(th * 10)] = np.asarray(R.utils_nms(dets, th), dtype=np.int32)
+        out2["contain/nms_new_%02d" % int(th * 10)] = np.asarray(R.utils_nms_new(dets, th), dtype=np.int32)
+    assert out2["contain/nms_03"].tolist() != out2["contain/nms_new_03"].tolist()
+    for n in (1, 2, 64, 65, 300, 6000, 12000):                # `nms` is cpu_nms's rule in a second file
+        for th in ("03", "07"):
+            assert out2["n%d/nms_%s" % (n, th)].tolist() == out["n%d/keep_%s" % (n, th)].tolist()
+    save("nms_utils", **out2)
+
     # ---- a6/a7/a9 proposal layer ---------------------------------------------
     def rpn_inputs(H, W, N, seed):
         rs = np.random.RandomState(seed)

@@ -303,3 +303,26 @@ def test_bench_py_under_torch_distributed_run_two_ranks():
     assert rf["bound"] == "hbm" and rf["kernel"] in ("roi_pool_forward", "roi_pool_backward")
     assert 0 < rf["frac"] < 1 and rf["frac"] == rf["frac_moved"] and rf["frac_8d"] > rf["frac_moved"]
     assert r["final_loss"] is not None and r["final_loss"] == r["final_loss"]        # not NaN
+    assert r["n_ranks_seen"] == 2                            # both ranks took part in a collective
+
+
+@pytest.mark.timeout(900)
+def test_bare_bench_py_gpus_2_starts_its_own_launcher():
+    """`python3 bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command):
+    bench.py starts `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 ...` as a child
+    before it imports torch, relays rank 0's one JSON line and the exit code."""
+    import json
+    import subprocess
+    env = dict(os.environ, WSSDL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "WSSDL_FORCE_DIST", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "resnet18_sup_b2", "--no-cpu-baseline", "--roofline-iters", "3"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=840)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-2000:] + p.stderr.decode()[-4000:]
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["n_ranks_seen"] == 2 and r["steps"] == 2 and r["scaling"] == "weak"
+    assert abs(r["value"] - 2 * 2 / (r["ms_per_step"] * 1e-3)) <= 0.01 * r["value"]

@@ -100,6 +100,28 @@ def test_nms_threshold_rule_and_max_keep(torch_cuda):
     assert keep.is_cuda and keep.cpu().tolist() == full
 
 
+def test_utils_nms_and_nms_new_golden(torch_cuda):
+    """f3 on the file the reference calls: utils/nms.pyx `nms` (fast_rcnn/test_bus.py:366) and `nms_new`
+    (:70-123), fixtures produced by that file's own functions (tests/golden/make_golden.py)."""
+    from wssdl_bus_amd.utils.cython_nms import nms, nms_new
+    g = load_golden("nms_utils")
+    base = load_golden("nms")
+    for name in groups(g):
+        dets = g[name + "/dets"] if name + "/dets" in g.files else base[name + "/dets"]
+        for key in [k.split("/")[1] for k in g.files if k.startswith(name + "/") and "dets" not in k]:
+            th = int(key[-2:]) / 10.0
+            got = nms_new(dets, th) if key.startswith("nms_new") else nms(dets, th)
+            assert got == g[name + "/" + key].tolist(), (name, key)
+    assert nms_new(np.zeros((0, 5), np.float32), 0.3) == []
+    rs = np.random.RandomState(2)
+    for n in (3, 64, 65, 1000, 4097):
+        c = rs.uniform(0, 300, size=(n, 2))
+        wh = np.exp(rs.uniform(np.log(4), np.log(200), size=(n, 2)))
+        d = np.hstack((c, c + wh, rs.permutation(n)[:, None] / float(n))).astype(np.float32)
+        for th in (0.0, 0.3, 0.7, 1.5):
+            assert nms_new(d, th) == O.nms_new(d, th), (n, th)
+
+
 def test_nms_random_vs_oracle(torch_cuda):
     from wssdl_bus_amd.nms.hip_nms import hip_nms
     rs = np.random.RandomState(1)

@@ -53,7 +53,19 @@ def _kernel_listings(lib_path, tmp):
 
 def test_only_the_helpers_asm_names_the_reserved_registers():
     from wssdl_bus_amd import build
-    lib_path = build.build(verbose=False)
+    _check(build.build(verbose=False))
+
+
+@pytest.mark.gpu
+def test_loaded_library_keeps_the_reserved_registers_to_the_helpers():
+    """The same check in the GPU suite, on the library file this process has actually loaded: the
+    driver's round-end run then disassembles the very code object the GPU box executes."""
+    from wssdl_bus_amd import _lib
+    _lib.lib()
+    _check(_lib.LIB_PATH)
+
+
+def _check(lib_path):
     tmp = tempfile.mkdtemp(prefix="wssdl_isa_")
     try:
         listings = _kernel_listings(lib_path, tmp)

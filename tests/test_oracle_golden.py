@@ -95,6 +95,36 @@ def test_nms_vs_reference_cython_random():
             assert O.nms(d, th) == [int(k) for k in ref_kernels.cpu_nms(d, th)]
 
 
+def test_utils_nms_and_nms_new_golden():
+    """f3: the test path calls utils/nms.pyx (`nms` :17-68, fast_rcnn/test_bus.py:366), not cpu_nms.pyx; the
+    fixtures hold that file's own outputs (`nms` and the containment variant `nms_new` :70-123)."""
+    g = load_golden("nms_utils")
+    for name in groups(g):
+        dets = g[name + "/dets"] if name + "/dets" in g.files else load_golden("nms")[name + "/dets"]
+        for key in [k.split("/")[1] for k in g.files if k.startswith(name + "/") and "dets" not in k]:
+            th = int(key[-2:]) / 10.0
+            got = O.nms_new(dets, th) if key.startswith("nms_new") else O.nms(dets, th)
+            assert got == g[name + "/" + key].tolist(), (name, key)
+    assert O.nms_new(np.zeros((0, 5), np.float32), 0.3) == []
+    # the containment terms bite: a small box inside a large one has a low IoU and inter / area_small = 1
+    d = np.array([[0, 0, 199, 199, 0.9], [50, 50, 69, 69, 0.8], [0, 12, 199, 211, 0.7]], dtype=np.float32)
+    assert O.nms(d, 0.99) == [0, 1, 2] and O.nms_new(d, 0.99) == [0, 2]      # box 2: 188/200 = 0.94 of either area
+    d[2, 1::2] = [9, 208]                                                      # 191/200 = 0.955 > 0.95
+    assert O.nms_new(d, 0.99) == [0]
+
+
+@pytest.mark.skipif(getattr(ref_kernels, "nms_new", None) is None, reason="oracle/_ref/cython_nms.so not built")
+def test_utils_nms_vs_reference_cython_random():
+    rs = np.random.RandomState(2)
+    for n in (1, 7, 200, 1500):
+        c = rs.uniform(0, 300, size=(n, 2))
+        wh = np.exp(rs.uniform(np.log(4), np.log(200), size=(n, 2)))          # nested boxes are common
+        d = np.hstack((c, c + wh, rs.permutation(n)[:, None] / float(n))).astype(np.float32)
+        for th in (0.3, 0.5, 0.7):
+            assert O.nms(d, th) == [int(k) for k in ref_kernels.nms(d, th)]
+            assert O.nms_new(d, th) == [int(k) for k in ref_kernels.nms_new(d, th)]
+
+
 # ------------------------------------------------------------ anchor target ---
 
 @pytest.mark.parametrize("shape", ["vgg_37x62", "res_38x63", "res_63x100"])

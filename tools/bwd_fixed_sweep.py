@@ -43,8 +43,19 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--one", default="")
     ap.add_argument("--channels", type=int, default=1024)
+    ap.add_argument("--images", default="", help="subset of the set's images, e.g. 0,4,5 (1 supervised + 2 weak: "
+                    "the low-image-count regime of the VGG-16 / alternating workloads); re-indexed from 0")
+    ap.add_argument("--denormals", action="store_true",
+                    help="scale top_diff so that sums pass through the f32 denormal range (checks that every plan, "
+                         "the ds_add_f32 ones included, still equals plan 11 bit for bit)")
     args = ap.parse_args()
     rois_np, tag = load_rois()
+    if args.images:
+        import numpy as np
+        keep = [int(x) for x in args.images.split(",")]
+        rois_np = np.concatenate([np.concatenate([np.full((int((rois_np[:, 0] == k).sum()), 1), i, np.float32),
+                                                  rois_np[rois_np[:, 0] == k][:, 1:]], axis=1)
+                                  for i, k in enumerate(keep)]).astype(np.float32)
     N, H, W, C = int(rois_np[:, 0].max()) + 1, 38, 63, args.channels
     dev = torch.device("cuda")
     g = torch.Generator(device=dev).manual_seed(3)
@@ -54,6 +65,8 @@ def main():
     shape = (N, H, W, C)
     top, arg8 = op.roi_pool_compact(feat, rois, 7, 7, 1.0 / 16)
     diff = torch.randn(top.shape, device=dev, generator=g)
+    if args.denormals:
+        diff = diff * 1e-38          # |values| ~ 1e-38: below and around FLT_MIN = 1.18e-38
     del top
     mb = moved_bytes("roi_pool_backward", N, H, W, C, R)
 

@@ -32,6 +32,7 @@ SYMBOLS = {
     "wssdl_bbox_overlaps_ui": (_i, [_vp, _i64, _i, _vp, _i64, _i, _vp, _vp]),
     "wssdl_nms_workspace_bytes": (_sz, [_i]),
     "wssdl_nms": (_i, [_vp, _i, _d, _i, _vp, _vp, _vp, _sz, _vp]),
+    "wssdl_nms_new": (_i, [_vp, _i, _d, _i, _vp, _vp, _vp, _sz, _vp]),
     "wssdl_proposal_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "wssdl_proposal_layer": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _d, _f,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -69,6 +70,10 @@ SYMBOLS = {
     "wssdl_image_prep_workspace_bytes": (_sz, []),
     "wssdl_image_prep": (_i, [_vp, _i, _i, _i, _i, _i, _f, _i, _f, _d, _vp, _vp, _sz, _vp]),
     "wssdl_image_to_blob": (_i, [_vp, _i, _i, _i, _d, _i, _vp, _i, _i, _i, _i, _vp]),
+    "wssdl_image_adjust_f64": (_i, [_vp, _i, _i, _i, _i64, _i, _d, _i, _d, _d, _vp, _vp, _sz, _vp]),
+    "wssdl_image_warp_workspace_bytes": (_sz, []),
+    "wssdl_image_warp": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _d, _i, _vp, _vp, _sz, _vp]),
+    "wssdl_image_resize": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "wssdl_flip_boxes": (_i, [_vp, _i, _i, _f, _vp]),
     "wssdl_post_detections_workspace_bytes": (_sz, [_i, _i]),
     "wssdl_post_detections": (_i, [_vp, _vp, _i, _i, _f, _d, _i, _vp, _vp, _vp, _sz, _vp]),

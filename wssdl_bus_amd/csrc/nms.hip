@@ -347,6 +347,9 @@ struct MaskArgs {
     // fused launch: finished[img * finished_stride] != 0 once the image's sweep has all it wants (the block is
     // skipped); NULL otherwise
     const int *finished;  int finished_stride;
+    // 0: the rule of cpu_nms.pyx / utils/nms.pyx `nms` (ovr >= thresh); 1: utils/nms.pyx:118-121 `nms_new`
+    // (ovr >= thresh or inter / area_i > 0.95 or inter / area_j > 0.95)
+    int rule;
 };
 
 // COHERENT: the words are read by a sweep that runs beside this kernel, possibly on another XCD (whose
@@ -400,7 +403,9 @@ __device__ __forceinline__ void nms_mask_block(const MaskArgs &A, int rb, int se
     // reference's arithmetic has no geometric meaning) get an infinite radius and always pass.
     // Only used for 0.25 <= t < 1 (k > 0).
     const double fq = thresh / (1.0 + thresh);
-    const bool prefilter = thresh >= 0.25 && thresh < 1.0;
+    // nms_new's containment terms suppress a small box anywhere inside a large one: no centre-distance bound
+    const bool contain = A.rule == 1;
+    const bool prefilter = !contain && thresh >= 0.25 && thresh < 1.0;
     const float kq = (float)((0.5 - fq) * (1.0 + 1e-3));
     auto geometry = [&](float x1, float y1, float x2, float y2, bool live) -> nms_float4v {
         float w = x2 - x1;  w = w + 1.0f;
@@ -467,7 +472,10 @@ __device__ __forceinline__ void nms_mask_block(const MaskArgs &A, int rb, int se
                 den = den - inter;
                 const bool yes = inter > den * t_hi;
                 const bool no = inter < den * t_lo;
-                const bool sure = (den > 0.0f) & (yes | no);
+                bool sure = (den > 0.0f) & (yes | no);
+                // nms_new: "no" is only final for pairs that do not intersect at all (inter == 0: the two
+                // containment quotients are 0 or NaN); every other pair goes to the exact loop
+                if (contain) sure = (den > 0.0f) & (yes | ((inter == 0.0f) & no));
                 yes_bit = (sure & yes) ? 1u : 0u;
                 und_bit = sure ? 0u : 1u;
             };
@@ -503,7 +511,13 @@ __device__ __forceinline__ void nms_mask_block(const MaskArgs &A, int rb, int se
             // further away the f32 rounding of the quotient cannot cross it (the loop took 28 % of the kernel with
             // a division per candidate)
             const bool yes = inter > den * t_hi, no = inter < den * t_lo;
-            if ((den > 0.0f) & (yes | no)) {
+            if (contain) {
+                // utils/nms.pyx:115-121: ovr is a C float widened for the compare with the Python float `thresh`;
+                // ovr1 / ovr2 are untyped, i.e. the f32 quotients as Python floats, compared with 0.95 in f64
+                if (((den > 0.0f) & yes) || (double)(inter / den) >= thresh || (double)(inter / iarea) > 0.95 ||
+                    (double)(inter / cbox_w[4][j]) > 0.95)
+                    bits |= 1ull << j;
+            } else if ((den > 0.0f) & (yes | no)) {
                 if (yes) bits |= 1ull << j;
             } else if ((double)(inter / den) >= thresh) {
                 bits |= 1ull << j;
@@ -548,13 +562,13 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(MaskArgs A) {
 int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, int n_max,
                     int n_images, double thresh, unsigned long long *mask,
                     unsigned long long *diag_t, unsigned long long *summ, hipStream_t st,
-                    int n_limit, int cb_min, const int *done, int max_keep) {
+                    int n_limit, int cb_min, const int *done, int max_keep, int rule) {
     if (n_max <= 0 || n_images == 0) return WSSDL_OK;
     const int ncb = nms_mask_pitch(n_max);
     // (the second pass of a two-pass run adds the column blocks >= cb_min to the summary of the first)
     const int ncb_eff = cdiv(min(n_max, n_limit), 64);      // row / column blocks this pass can touch
     const MaskArgs A = {boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, n_limit, cb_min, done,
-                        nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) ? NMS_DENSE_AHEAD : -1, nullptr, 0};
+                        nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) ? NMS_DENSE_AHEAD : -1, nullptr, 0, rule};
     hipLaunchKernelGGL(nms_mask_kernel, dim3(ncb_eff, cdiv(ncb_eff, MASK_SEG), n_images), dim3(64 * MASK_WAVES), 0, st, A);
     return check_launch();
 }
@@ -1197,7 +1211,7 @@ static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n
     // the control words = 0 (the summaries need no initialisation: every entry that is read is written)
     if (hipMemsetAsync(segdone, 0, sizeof(int) * (size_t)n_images * ncb, st) != hipSuccess) return WSSDL_ERR_LAUNCH;
     const MaskArgs M = {boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, 0x7fffffff, 0, nullptr,
-                        NMS_DENSE_AHEAD, segdone + ncb - 2, ncb};
+                        NMS_DENSE_AHEAD, segdone + ncb - 2, ncb, 0};
     const SweepArgs S = {mask, diag_t, summ, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
                          boxes, box_stride_img, rois_padded, 0x7fffffff, nullptr, nullptr, segdone, nrb};
     const size_t lds_mask = (size_t)(SWEEP_BLOCK / 64) * (5 * 64 * sizeof(float) + 64 * sizeof(nms_float4v));
@@ -1305,9 +1319,8 @@ extern "C" size_t wssdl_nms_workspace_bytes(int n) {
     return carve_nms(nullptr, n, nullptr);
 }
 
-extern "C" int wssdl_nms(const float *dets, int n, double thresh, int max_keep, int32_t *keep,
-                         int32_t *num_keep, void *workspace, size_t workspace_bytes,
-                         wssdl_stream_t stream) {
+static int nms_entry(const float *dets, int n, double thresh, int max_keep, int32_t *keep, int32_t *num_keep,
+                     void *workspace, size_t workspace_bytes, wssdl_stream_t stream, int rule) {
     if (n < 0 || max_keep < 0 || !num_keep) return WSSDL_ERR_INVALID_ARGUMENT;
     hipStream_t st = as_stream(stream);
     if (n == 0 || max_keep == 0) {                     // nms_wrapper.py:16-17: empty -> []
@@ -1332,8 +1345,21 @@ extern "C" int wssdl_nms(const float *dets, int n, double thresh, int max_keep, 
                        w.n_sorted, n, w.boxes);
     rc = check_launch();
     if (rc) return rc;
-    rc = launch_nms_mask(w.boxes, n * 4, w.n_sorted, n, 1, thresh, w.mask, w.cand, w.summ, st, 0x7fffffff, 0, nullptr, max_keep);
+    rc = launch_nms_mask(w.boxes, n * 4, w.n_sorted, n, 1, thresh, w.mask, w.cand, w.summ, st, 0x7fffffff, 0, nullptr, max_keep,
+                         rule);
     if (rc) return rc;
     return launch_nms_sweep(w.mask, w.cand, w.summ, w.n_sorted, n, 1, max_keep, w.order, n, keep, num_keep,
                             nullptr, 0, nullptr, w.kept, st, 0x7fffffff, nullptr, nullptr);
+}
+
+extern "C" int wssdl_nms(const float *dets, int n, double thresh, int max_keep, int32_t *keep,
+                         int32_t *num_keep, void *workspace, size_t workspace_bytes,
+                         wssdl_stream_t stream) {
+    return nms_entry(dets, n, thresh, max_keep, keep, num_keep, workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" int wssdl_nms_new(const float *dets, int n, double thresh, int max_keep, int32_t *keep,
+                             int32_t *num_keep, void *workspace, size_t workspace_bytes,
+                             wssdl_stream_t stream) {
+    return nms_entry(dets, n, thresh, max_keep, keep, num_keep, workspace, workspace_bytes, stream, 1);
 }

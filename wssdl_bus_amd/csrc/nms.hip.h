@@ -54,7 +54,7 @@ size_t nms_summary_alloc_words(int n_images, int n_max);
 int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, int n_max,
                     int n_images, double thresh, unsigned long long *mask,
                     unsigned long long *diag_t, unsigned long long *summ, hipStream_t st,
-                    int n_limit, int cb_min, const int *done, int max_keep);
+                    int n_limit, int cb_min, const int *done, int max_keep, int rule = 0);
 
 // keep (optional) [n_images, max_keep] i32; rois_padded (optional) [n_images, max_keep, 5];
 // kept_scratch [n_images, max_keep + 64] i32: only needed when the kept list does not fit in

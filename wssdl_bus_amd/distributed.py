@@ -19,6 +19,9 @@ class DistContext(object):
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.bucket_bytes = bucket_bytes
         self.backend = backend
+        # any-rank has-grad patterns, per context (ids of freed parameters can be reused by a later model:
+        # the cache must not outlive the parameters it was learnt on -- cleared by GradOverlap.remove / shutdown)
+        self._any_cache = {}
         # WSSDL_FORCE_DIST=1: run the collective code path even with one rank (RCCL smoke test
         # on a single-GPU box)
         self.enabled = self.world_size > 1 or bool(os.environ.get("WSSDL_FORCE_DIST"))
@@ -98,17 +101,15 @@ class DistContext(object):
     # pattern ON THE DEVICE and add the differences to a counter that poll_patterns() looks at without
     # synchronising (the copy of the previous poll, once its event has completed): a rank whose
     # pattern ever departs raises one step later instead of training on.
-    _any_cache = {}
-
     def _write_back(self, flat, work, ps, had=None):
         work.wait()
         flags = flat[flat.numel() - len(ps):]
         key = (tuple(id(p) for p in ps), had)
-        any_grad = DistContext._any_cache.get(key) if had is not None else None
+        any_grad = self._any_cache.get(key) if had is not None else None
         if any_grad is None:
             any_grad = tuple(a > 0 for a in flags.cpu().tolist())     # first step of this kind only
             if had is not None:
-                DistContext._any_cache[key] = any_grad
+                self._any_cache[key] = any_grad
         else:
             diff = ((flags > 0).to(flat.dtype) - self._flags(any_grad, flat)).abs().sum()
             if getattr(self, "_mismatch", None) is None:
@@ -166,6 +167,11 @@ class DistContext(object):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def count_ranks(self):
+        """How many ranks the collective backend really connects: every rank adds 1 (an all-reduce over
+        RCCL / gloo), so a scaling record shows that N processes took part, not just that N were asked for."""
+        return int(round(self.sum_over_ranks(1.0)))
+
     def sum_over_ranks(self, value):
         if not self.enabled:
             return value
@@ -175,6 +181,7 @@ class DistContext(object):
         return float(t.item())
 
     def shutdown(self):
+        self._any_cache.clear()
         if self.enabled and dist.is_initialized():
             dist.destroy_process_group()
 
@@ -248,3 +255,4 @@ class GradOverlap(object):
         for h in self.handles:
             h.remove()
         self.handles = []
+        self.ctx._any_cache.clear()       # learnt on this model's parameters

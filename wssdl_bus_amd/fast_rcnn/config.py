@@ -35,7 +35,7 @@ __C.TRAIN.SCALES = (600,)                           # :109
 __C.TRAIN.MAX_SIZE = 1000                           # :112
 # augmentation of the host image path (utils/blob.py): rotation needs skimage.transform.rotate, which is
 # absent and unpinned -- the reference's default True is not available here
-__C.TRAIN.USE_ROTATION = False                      # :136 (reference: True)
+__C.TRAIN.USE_ROTATION = True                       # :136
 __C.TRAIN.ROTATION_MAX_ANGLE = 5                    # :137
 __C.TRAIN.USE_CROPPING = True                       # :140
 __C.TRAIN.CROPPING_MAX_MARGIN = 0.05                # :141

@@ -6,11 +6,16 @@ _get_image_blob_joint: grey plane stacked x3, flip, supervised images first then
 datasets/imdb.py:106-121 (box mirroring).  Same function names and argument meaning; images live
 on the device.
 
-``skimage.transform.resize`` (blob.py:74-77) is not reimplemented: the library is absent here and
-its version unpinned, so no oracle could pin it.  prep_im_for_blob therefore
-takes the resize as a callable; the default is torch's bilinear interpolation, which is a
-DIFFERENT filter than skimage's and is not parity-checked -- everything around it is.
+``skimage.transform.resize`` (blob.py:74-77) and ``skimage.transform.rotate`` (:39-41) run on the device
+too (round 4): ``wssdl_image_resize`` / ``wssdl_image_warp`` follow the published algorithm of the release
+the reference's README pins (scikit-image 0.14.2: order 1, mode 'constant', cval 0 -- the borders of an
+up-scaled image fade towards 0 --, clip to the input's range, no anti-aliasing).  The library is absent
+here, so this step is checked against a restatement of that algorithm only ("parity unpinned",
+oracle/np_oracle.py); everything around it is pinned by fixtures from the reference's own blob.py.
+prep_im_for_blob still takes the resize as a callable (``resize=``) for a caller that wants another filter.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -60,8 +65,107 @@ def prep_im_pre_resize(gray, flipped=False, brightness_delta=None, contrast_fact
     return out
 
 
+def skimage_resize_matrix(in_shape, out_shape):
+    """The inverse map of skimage.transform.resize (0.14.2, _warps.py): output (col, row, 1) -> input
+    (col_scale * (col + 0.5) - 0.5, row_scale * (row + 0.5) - 0.5); a translation to the centre for 1 x 1."""
+    rows, cols = int(out_shape[0]), int(out_shape[1])
+    h, w = int(in_shape[0]), int(in_shape[1])
+    if rows == 1 and cols == 1:
+        return np.array([[1.0, 0.0, w / 2.0 - 0.5], [0.0, 1.0, h / 2.0 - 0.5], [0.0, 0.0, 1.0]])
+    rs, cs = float(h) / rows, float(w) / cols
+    return np.array([[cs, 0.0, cs * 0.5 - 0.5], [0.0, rs, rs * 0.5 - 0.5], [0.0, 0.0, 1.0]])
+
+
+def skimage_rotate_matrix(in_shape, angle_deg):
+    """skimage.transform.rotate (resize=False): T(centre) . R(angle) . T(-centre), centre = (cols, rows)/2 - 0.5."""
+    rows, cols = int(in_shape[0]), int(in_shape[1])
+    centre = np.array((cols, rows)) / 2. - 0.5
+    a = np.deg2rad(angle_deg)
+    t1 = np.array([[1.0, 0.0, centre[0]], [0.0, 1.0, centre[1]], [0.0, 0.0, 1.0]])
+    t2 = np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])
+    t3 = np.array([[1.0, 0.0, -centre[0]], [0.0, 1.0, -centre[1]], [0.0, 0.0, 1.0]])
+    return t1.dot(t2.dot(t3))
+
+
+def skimage_warp(im, matrix, shape, mode="constant", cval=0.0, clip=True):
+    """skimage.transform.warp(im, matrix, output_shape=shape, order=1, mode, cval, clip) on the device:
+    im [h,w] or [h,w,C] f32 / f64 (GPU tensor or numpy) -> f64 GPU tensor [rows, cols(, C)]."""
+    t = _lib.to_device(im, im.dtype if isinstance(im, torch.Tensor) else
+                       (torch.float64 if np.asarray(im).dtype == np.float64 else torch.float32))
+    if t.dtype not in (torch.float32, torch.float64):
+        t = t.to(torch.float64)
+    squeeze = t.dim() == 2
+    t = (t.unsqueeze(2) if squeeze else t).contiguous()
+    h, w, C = (int(v) for v in t.shape)
+    rows, cols = int(shape[0]), int(shape[1])
+    M = (ctypes.c_double * 9)(*[float(v) for v in np.asarray(matrix, dtype=np.float64).reshape(-1)])
+    out = torch.empty((rows, cols, C), dtype=torch.float64, device=t.device)
+    L = _lib.lib()
+    with torch.cuda.device(t.device):
+        n = L.wssdl_image_warp_workspace_bytes()
+        ws = torch.empty((n,), dtype=torch.uint8, device=t.device)
+        _lib.check(L.wssdl_image_warp(_lib.ptr(t), int(t.dtype == torch.float64), h, w, C, M, rows, cols,
+                                      {"constant": 0, "edge": 1}[mode], float(cval), int(bool(clip)), _lib.ptr(out),
+                                      _lib.ptr(ws), n, _lib.stream()), "wssdl_image_warp")
+    return out[:, :, 0] if squeeze else out
+
+
+def skimage_resize(im, shape):
+    """skimage.transform.resize(im, shape) with the 0.14.2 defaults (blob.py:74-77), on the device."""
+    t = _lib.to_device(im, im.dtype if isinstance(im, torch.Tensor) else
+                       (torch.float64 if np.asarray(im).dtype == np.float64 else torch.float32))
+    if t.dtype not in (torch.float32, torch.float64):
+        t = t.to(torch.float64)
+    squeeze = t.dim() == 2
+    t = (t.unsqueeze(2) if squeeze else t).contiguous()
+    h, w, C = (int(v) for v in t.shape)
+    rows, cols = int(shape[0]), int(shape[1])
+    out = torch.empty((rows, cols, C), dtype=torch.float64, device=t.device)
+    L = _lib.lib()
+    with torch.cuda.device(t.device):
+        n = L.wssdl_image_warp_workspace_bytes()
+        ws = torch.empty((n,), dtype=torch.uint8, device=t.device)
+        _lib.check(L.wssdl_image_resize(_lib.ptr(t), int(t.dtype == torch.float64), h, w, C, rows, cols,
+                                        _lib.ptr(out), _lib.ptr(ws), n, _lib.stream()), "wssdl_image_resize")
+    return out[:, :, 0] if squeeze else out
+
+
+def skimage_rotate(im, angle_deg, cval=0.0):
+    """skimage.transform.rotate(im, angle, cval=cval) (blob.py:39-41: order 1, mode 'constant', clip), on the device."""
+    shape = tuple(int(v) for v in im.shape)
+    return skimage_warp(im, skimage_rotate_matrix(shape, angle_deg), shape[:2], cval=cval)
+
+
+def prep_im_pre_resize_rotated(gray, flipped, angle_deg, brightness_delta=None, contrast_factor=None,
+                               pixel_means=PIXEL_MEANS, crop=None):
+    """blob.py:36-60 for a weak image with cfg.TRAIN.USE_ROTATION: /255 in f32, rotate by `angle_deg` with
+    cval = pixel_mean / 255 (float64 from here on), crop [u:-d, l:-r], brightness, contrast, mean -- returns
+    the f64 [h',w',3] array the reference hands to skimage.transform.resize."""
+    mean = float(np.asarray(pixel_means).reshape(-1)[0])
+    # u8 -> f32 / 255, flipped, x3, no augmentation and no mean (pixel_mean 0): blob.py:36
+    im = prep_im_pre_resize(gray, flipped, None, None, np.zeros((1, 1, 3)))
+    rot = skimage_rotate(im, angle_deg, cval=mean / 255.)
+    H0, W0 = int(rot.shape[0]), int(rot.shape[1])
+    view = rot
+    if crop is not None:
+        u, d, l, r = (int(v) for v in crop)
+        if d < 1 or r < 1 or u < 0 or l < 0 or u + d >= H0 or l + r >= W0:
+            raise ValueError("crop offsets out of range")
+        view = rot[u:H0 - d, l:W0 - r]
+    h, w = int(view.shape[0]), int(view.shape[1])
+    out = torch.empty((h, w, 3), dtype=torch.float64, device=rot.device)
+    with torch.cuda.device(rot.device):
+        ws, n = _ws(rot.device)
+        _lib.check(_lib.lib().wssdl_image_adjust_f64(
+            _lib.ptr(view), h, w, 3, int(view.stride(0)),
+            int(brightness_delta is not None), float(brightness_delta or 0.0),
+            int(contrast_factor is not None), float(contrast_factor if contrast_factor is not None else 1.0),
+            mean, _lib.ptr(out), _lib.ptr(ws), n, _lib.stream()), "wssdl_image_adjust_f64")
+    return out
+
+
 def torch_bilinear_resize(im, shape):
-    """Stand-in for skimage.transform.resize (NOT the same filter, not parity-checked)."""
+    """torch's bilinear filter (NOT skimage's: no fading borders, no clip); kept for callers that ask for it."""
     x = im.permute(2, 0, 1).unsqueeze(0).to(torch.float64)
     y = torch.nn.functional.interpolate(x, size=tuple(int(s) for s in shape), mode="bilinear", align_corners=False)
     return y.squeeze(0).permute(1, 2, 0).contiguous()
@@ -71,15 +175,16 @@ def prep_im_for_blob(gray, net_name, pixel_means, pixel_stds, target_size, max_s
                      is_ws=False, flipped=False, rng=None, resize=None):
     """blob.py:34-79 for one grey plane.  Returns (im [h',w',3] on the GPU, im_scale).  The draws come
     from `rng` (default: numpy's global legacy stream, like the reference) in the reference's order:
-    for a weak image (is_ws) the four crop offsets (np.random.random_integers, :43-46), then -- when
-    training -- brightness (:50) and contrast (:55).  Rotation (:39-41) needs
-    skimage.transform.rotate and is not available (cfg.TRAIN.USE_ROTATION must be False)."""
+    for a weak image (is_ws) the rotation angle (np.random.uniform, :39-41), the four crop offsets
+    (np.random.random_integers, :43-46), then -- when training -- brightness (:50) and contrast (:55).
+    A rotated image is float64 from skimage.transform.rotate on, like in the reference (the f32 plane goes
+    through wssdl_image_warp, the crop is a view, the remaining steps run in wssdl_image_adjust_f64)."""
     rng = np.random if rng is None else rng
-    crop = delta = factor = None
+    crop = delta = factor = angle = None
     if is_ws:
         if cfg.TRAIN.USE_ROTATION:
-            raise NotImplementedError("rotation needs skimage.transform.rotate (absent, unpinned): "
-                                      "set cfg.TRAIN.USE_ROTATION = False")
+            a = cfg.TRAIN.ROTATION_MAX_ANGLE
+            angle = rng.uniform(-a, a)
         if cfg.TRAIN.USE_CROPPING:
             h0, w0 = (int(v) for v in gray.shape)
             m = cfg.TRAIN.CROPPING_MAX_MARGIN
@@ -93,13 +198,16 @@ def prep_im_for_blob(gray, net_name, pixel_means, pixel_stds, target_size, max_s
         if cfg.TRAIN.USE_CONTRAST_ADJUSTMENT:
             factor = rng.uniform(cfg.TRAIN.CONTRAST_ADJUSTMENT_LOWER_FACTOR,
                                  cfg.TRAIN.CONTRAST_ADJUSTMENT_UPPER_FACTOR)
-    pre = prep_im_pre_resize(gray, flipped, delta, factor, pixel_means, crop=crop)
+    if angle is None:
+        pre = prep_im_pre_resize(gray, flipped, delta, factor, pixel_means, crop=crop)
+    else:
+        pre = prep_im_pre_resize_rotated(gray, flipped, angle, delta, factor, pixel_means, crop=crop)
     h, w = pre.shape[:2]
     im_scale = float(target_size) / float(min(h, w))
     if np.round(im_scale * max(h, w)) > max_size:
         im_scale = float(max_size) / float(max(h, w))
     shape = (int(np.round(h * im_scale)), int(np.round(w * im_scale)))
-    resized = (resize or torch_bilinear_resize)(pre, shape)
+    resized = (resize or skimage_resize)(pre, shape)
     std = float(np.asarray(pixel_stds).reshape(-1)[0])
     if net_name[:6] == 'Resnet':
         im = _scale_image(resized, std / 255.0, True)
