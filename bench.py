@@ -444,6 +444,10 @@ def main():
     elapsed = time.perf_counter() - t0
     _lib.timeline.enabled = False
     elapsed = ctx.max_over_ranks(elapsed)
+    # the deferred device flags of the timed steps (RoI-pool window / list overflow, NMS time-out): the polls
+    # inside the steps run one step late and never see the last one
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op
+    roi_pooling_op.check_flags()
     n_ranks_seen = ctx.count_ranks()      # a sum of ones over the job's collective backend
     loss_val = float(out["loss"].detach()) if isinstance(out, dict) and torch.is_tensor(out.get("loss")) else None
 

@@ -60,6 +60,10 @@ enum wssdl_dataset {
 };
 
 #define WSSDL_MAX_ANCHORS 32     /* base anchors per cell (reference uses 9 or 12) */
+/* roi_counts[i] / num_keep of an image whose NMS sweep gave up waiting for the mask blocks of the fused
+ * launch (0.5 s without progress: the GPU is held by another process or kernel).  The image's rows are
+ * incomplete; every consumer must treat a negative count as an error, never as "no proposals". */
+#define WSSDL_NMS_TIMED_OUT (-1)
 #define WSSDL_MAX_GT 64          /* gt boxes per image (reference: MAX_GT_PER_IMAGE = 20) */
 
 /* library / build identification: returns a static string */
@@ -73,7 +77,9 @@ WSSDL_API const char *wssdl_last_error(void);
  * automatic), "nms_one_pass" (1: the proposal layer skips the probe pass), "nms_fused" (0: mask and sweep of a one-pass
  * NMS as two launches instead of the fused one), "topk_sort" (order of the proposal candidates: 1 sorted runs +
  * cross ranks, the default; 0 the select + sample sort).  Results do not depend on
- * any of them.  Unknown key -> WSSDL_ERR_INVALID_ARGUMENT. */
+ * any of them.  One more key is a fault injector for tests, not a knob: "nms_fused_fault" (> 0: the fused
+ * NMS launch withholds image 0's progress counts and that image's sweep gives up after this many microseconds,
+ * reporting WSSDL_NMS_TIMED_OUT).  Unknown key -> WSSDL_ERR_INVALID_ARGUMENT. */
 WSSDL_API int wssdl_set_tuning(const char *key, int value);
 WSSDL_API int wssdl_get_tuning(const char *key, int *value_host);
 
@@ -326,6 +332,22 @@ WSSDL_API int wssdl_roi_pool_backward_compact(const float *top_diff, const uint8
                             const float *rois, int R, int N, int H, int W, int C, int pooled_h,
                             int pooled_w, float spatial_scale, int rounding, float *bottom_diff,
                             void *workspace, size_t workspace_bytes, int plan, wssdl_stream_t stream);
+/* Split form of the list-driven backward: DETERMINISTIC BUT NOT BIT-ORDERED.  A launch with few images is bound
+ * by the longest slot chain one wave walks alone (every RoI of a 2000-RoI weak image reaches the tiles at the
+ * image's centre), not by bandwidth: each tile's stream is cut into `segments` pieces walked by separate waves
+ * (segment 0 into bottom_diff, the others into scratch) and the pieces are added in segment order.  The f32 sum
+ * per element is then associated differently from roi_pooling_op_gpu.cu.cc:132-186 (roi^, ph^, pw^): the same
+ * result on every run, within ~1e-7 (relative to the element's magnitude scale) of ..._backward_compact, not
+ * bit-identical to it -- north_star's tolerance for RoI pooling is 1e-5.  segments = 1 is the exact walk.
+ * wssdl_roi_pool_backward_split_segments suggests a count by launch shape (1 = keep the exact walk: more than
+ * 4 images, or fewer than 1000 RoIs per image); same plan / workspace as ..._backward_compact. */
+WSSDL_API int wssdl_roi_pool_backward_split_segments(int R, int N, int H, int W, int C);
+WSSDL_API size_t wssdl_roi_pool_backward_split_scratch_bytes(int N, int H, int W, int C, int segments);
+WSSDL_API int wssdl_roi_pool_backward_compact_split(const float *top_diff, const uint8_t *argmax8,
+                            const float *rois, int R, int N, int H, int W, int C, int pooled_h,
+                            int pooled_w, float spatial_scale, int rounding, float *bottom_diff,
+                            void *workspace, size_t workspace_bytes, int plan, int segments,
+                            void *scratch, size_t scratch_bytes, wssdl_stream_t stream);
 WSSDL_API int wssdl_roi_argmax_expand(const uint8_t *argmax8, const float *rois, int R, int H, int W,
                             int C, int pooled_h, int pooled_w, float spatial_scale, int rounding,
                             int32_t *argmax, wssdl_stream_t stream);

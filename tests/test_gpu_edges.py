@@ -833,6 +833,43 @@ def test_fused_mask_sweep_launch_equals_two_launches(torch_cuda):
     assert 2000 in seen and any(0 < c < 2000 for c in seen)      # sweeps that stop early and sweeps that walk every chunk
 
 
+def test_fused_nms_time_out_is_reported_not_swallowed(torch_cuda):
+    """The sweep of the fused launch gives up when the mask blocks it waits for make no progress (a GPU held by
+    another process): the image then reports roi count -1 (WSSDL_NMS_TIMED_OUT), never a silent 0.  Forced with
+    the fault injector `nms_fused_fault` (image 0's segment counts are withheld, wait shortened to 2 ms): the
+    blob-building path raises, the sync-free padded path raises its deferred flag, the other images are intact."""
+    torch = torch_cuda
+    from wssdl_bus_amd import _lib
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as rp
+    from wssdl_bus_amd.rpn_msr.proposal_layer_tf_bus import padded_blob, proposal_layer, proposal_layer_padded
+    rs = np.random.RandomState(6)
+    N, H, W, A = 3, 38, 63, 9
+    info = np.tile(np.array([[600, 1000, 1.0, 1]], np.float32), (N, 1))
+    logits = rs.normal(size=(N, H, W, A, 2)).astype(np.float32)
+    e = np.exp(logits - logits.max(-1, keepdims=True))
+    p = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    prob = np.concatenate((p[..., 0], p[..., 1]), axis=-1)
+    pred = rs.normal(0, 0.2, size=(N, H, W, 4 * A)).astype(np.float32)
+    good = proposal_layer(prob, pred, info, True, False)
+    rp.check_flags()
+    with _lib.tuned(nms_fused=1, nms_fused_fault=2000):
+        rois, counts = proposal_layer_padded(torch.from_numpy(prob).cuda(), torch.from_numpy(pred).cuda(),
+                                             torch.from_numpy(info).cuda(), True)
+        c = counts.cpu().numpy()
+        assert c[0] == -1 and c[1] > 0 and c[2] > 0, c
+        for i in (1, 2):            # the other images' sweeps were not disturbed
+            assert np.array_equal(rois[i, :c[i], 1:].cpu().numpy(), good[good[:, 0] == i][:, 1:])
+        with pytest.raises(_lib.HipCallError, match="timed out"):
+            proposal_layer(prob, pred, info, True, False)
+        blob = padded_blob(rois, counts)                       # the form that never reads the counts back
+        assert int((blob[:2000, 0] >= 0).sum()) == 0            # image 0: no live rows
+        with pytest.raises(_lib.HipCallError, match="NMS sweep"):
+            rp.check_flags()
+    rp.check_flags()                                            # reported once, then clean
+    assert np.array_equal(proposal_layer(prob, pred, info, True, False), good)
+
+
 def test_post_detections_device_op_edges(torch_cuda):
     """wssdl_post_detections (f3 as one C-ABI call) against the step-by-step form (which
     test_post_detection_nms_matches_oracle pins to the oracle) and against the oracle directly: more

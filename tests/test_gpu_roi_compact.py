@@ -217,6 +217,70 @@ def test_autograd_uses_compact_path_and_matches_oracle(torch_cuda):
     assert not op.compact_overflowed()
 
 
+def test_split_walk_is_deterministic_and_within_1e6_of_the_oracle(torch_cuda):
+    """wssdl_roi_pool_backward_compact_split (few images, many RoIs per image: the chain-bound launches of the
+    reference's default 1 + 2 batch and of the alternating mode): a tile's slot stream cut into K segments
+    walked by K waves, partial tiles added in segment order.  K = 1 is the exact walk (bit-equal to the C
+    oracle); K > 1 associates each element's f32 sum differently: the same bits on every run, within 1e-6 of
+    the oracle relative to the gradient's scale (north_star: 1e-5), elementwise within 1e-5 of the element's own
+    sum of magnitudes.  The library suggests K by launch shape; the autograd pair follows cfg.ROI_POOL_BWD_SPLIT."""
+    torch = torch_cuda
+    from wssdl_bus_amd import _lib
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    L = _lib.lib()
+    assert L.wssdl_roi_pool_backward_split_segments(4128, 3, 37, 62, 512) == 4        # VGG-16, 1 + 2 images
+    assert L.wssdl_roi_pool_backward_split_segments(4000, 2, 38, 63, 1024) == 4       # alternating mode, weak step
+    assert L.wssdl_roi_pool_backward_split_segments(8512, 8, 38, 63, 1024) == 1       # the default workload: exact walk
+    assert L.wssdl_roi_pool_backward_split_segments(256, 2, 38, 63, 256) == 1
+    assert L.wssdl_roi_pool_backward_split_scratch_bytes(3, 37, 62, 512, 4) == 3 * 3 * 37 * 62 * 512 * 4
+    rs = np.random.RandomState(21)
+    N, H, W, C = 2, 37, 62, 128
+    f_np = np.maximum(rs.normal(size=(N, H, W, C)), 0).astype(np.float32)
+    # heavily overlapping RoIs around the image centre (what an untrained RPN proposes): long slot chains
+    R = 2400
+    ctr = rs.normal([500, 300], [60, 40], size=(R, 2))
+    wh = np.exp(rs.normal(np.log(300), 0.25, size=(R, 2)))
+    rois_np = np.concatenate([(np.arange(R) % N)[:, None], np.clip(ctr - wh / 2, 0, None),
+                              np.minimum(ctr + wh / 2, [991, 591])], axis=1).astype(np.float32)
+    rois_np = rois_np[np.argsort(rois_np[:, 0], kind="stable")]
+    want_t, want_a = c_oracle.roi_pool_forward(f_np, rois_np, 7, 7, 1.0 / 16, "cuda", threads=16)
+    w_np = rs.normal(size=want_t.shape).astype(np.float32)
+    want_g = c_oracle.roi_pool_backward(w_np, want_a, rois_np, f_np.shape, 7, 7, 1.0 / 16)
+    # per element: the sum of |terms| (the scale its rounding errors live on)
+    mag = c_oracle.roi_pool_backward(np.abs(w_np), want_a, rois_np, f_np.shape, 7, 7, 1.0 / 16)
+    ft, rt, wt = torch.from_numpy(f_np).cuda(), torch.from_numpy(rois_np).cuda(), torch.from_numpy(w_np).cuda()
+    top, arg8 = op.roi_pool_compact(ft, rt, 7, 7, 1.0 / 16)
+    assert np.array_equal(top.cpu().numpy(), want_t)
+    scale = float(np.abs(want_g).max())
+    for plan_id in (-1, 11, 23, 21):
+        with _lib.tuned(roi_bwd_plan=plan_id):
+            plan = op.roi_pool_grad_prepare((N, H, W, C), rt, 7, 7, 1.0 / 16)
+        exact = op.roi_pool_grad_compact((N, H, W, C), rt, arg8, wt, 7, 7, 1.0 / 16, plan=plan, segments=1).cpu().numpy()
+        assert np.array_equal(exact, want_g)
+        for K in (2, 4, 7, 16):
+            a = op.roi_pool_grad_compact((N, H, W, C), rt, arg8, wt, 7, 7, 1.0 / 16, plan=plan, segments=K)
+            b = op.roi_pool_grad_compact((N, H, W, C), rt, arg8, wt, 7, 7, 1.0 / 16, plan=plan, segments=K)
+            assert torch.equal(a, b)                                                    # deterministic
+            a = a.cpu().numpy()
+            assert np.abs(a - want_g).max() <= 1e-6 * scale, (plan_id, K)
+            assert np.all(np.abs(a - want_g) <= 1e-5 * mag + 1e-30), (plan_id, K)
+    assert not op.flags_raised()
+    # the autograd pair: 'auto' takes the library's suggestion (4 here: 2 images x 1200 RoIs), 0 the exact walk
+    assert cfg.ROI_POOL_BWD_SPLIT == "auto" and op.split_segments((N, H, W, C), R) == 4
+    for split, exact_bits in (("auto", False), (0, True)):
+        cfg.ROI_POOL_BWD_SPLIT = split
+        try:
+            f = ft.clone().requires_grad_(True)
+            t, _ = op.RoiPoolFunction.apply(f, rt, 7, 7, 1.0 / 16, None)
+            (t * wt).sum().backward()
+            g = f.grad.cpu().numpy()
+            assert np.abs(g - want_g).max() <= 1e-6 * scale
+            assert np.array_equal(g, want_g) or not exact_bits
+        finally:
+            cfg.ROI_POOL_BWD_SPLIT = "auto"
+
+
 def test_compact_full_size_properties(torch_cuda):
     """BASELINE config 3 size (R = 4*128 + 4*2000 = 8512, C = 1024, 8 images 38x63): the compact pair
     equals the i32 pair bit for bit (which test_gpu_parity.py checks against the oracle by

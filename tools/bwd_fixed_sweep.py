@@ -45,18 +45,23 @@ def main():
     ap.add_argument("--channels", type=int, default=1024)
     ap.add_argument("--images", default="", help="subset of the set's images, e.g. 0,4,5 (1 supervised + 2 weak: "
                     "the low-image-count regime of the VGG-16 / alternating workloads); re-indexed from 0")
+    ap.add_argument("--rois", default="", help="another RoI set (float32 [R,5] .npy) instead of the default workload's")
+    ap.add_argument("--map", default="38,63", help="feature-map height,width")
+    ap.add_argument("--segments", default="1", help="segments of the split walk to time per plan, e.g. 1,2,4,8 (1 = the "
+                    "exact walk; > 1 is compared with it by the largest difference relative to max |bottom_diff|)")
     ap.add_argument("--denormals", action="store_true",
                     help="scale top_diff so that sums pass through the f32 denormal range (checks that every plan, "
                          "the ds_add_f32 ones included, still equals plan 11 bit for bit)")
     args = ap.parse_args()
-    rois_np, tag = load_rois()
+    rois_np, tag = load_rois(args.rois) if args.rois else load_rois()
     if args.images:
         import numpy as np
         keep = [int(x) for x in args.images.split(",")]
         rois_np = np.concatenate([np.concatenate([np.full((int((rois_np[:, 0] == k).sum()), 1), i, np.float32),
                                                   rois_np[rois_np[:, 0] == k][:, 1:]], axis=1)
                                   for i, k in enumerate(keep)]).astype(np.float32)
-    N, H, W, C = int(rois_np[:, 0].max()) + 1, 38, 63, args.channels
+    H, W = (int(v) for v in args.map.split(","))
+    N, C = int(rois_np[:, 0].max()) + 1, args.channels
     dev = torch.device("cuda")
     g = torch.Generator(device=dev).manual_seed(3)
     feat = torch.relu(torch.randn((N, H, W, C), device=dev, generator=g))
@@ -86,17 +91,24 @@ def main():
 
     ref = op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=run(11))
     timeit(lambda: op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=run(11)), 10)     # clocks up
+    scale = float(ref.abs().max())
     for p in (int(x) for x in args.plans.split(",")):
         plan = run(p)
-        got = op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan)
-        same = bool(torch.equal(got, ref))
-        del got
-        ms = timeit(lambda: op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan), args.iters)
         with _lib.tuned(roi_bwd_plan=p):
             ms_prep = timeit(lambda: op.roi_pool_grad_prepare(shape, rois, 7, 7, 1.0 / 16), 10)
-        print(json.dumps(dict(plan=p, walk_ms=round(ms, 4), prepare_ms=round(ms_prep, 4), equal_to_plan11=same,
-                              moved_TBps=round(mb / ms / 1e9, 3), frac_moved=round(mb / ms / 1e9 / 8.0, 3))), flush=True)
-        assert same, p
+        for seg in (int(x) for x in args.segments.split(",")):
+            got = op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan, segments=seg)
+            same = bool(torch.equal(got, ref))
+            rel = float((got - ref).abs().max()) / scale
+            again = op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan, segments=seg)
+            repeatable = bool(torch.equal(got, again))
+            del got, again
+            ms = timeit(lambda: op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan, segments=seg),
+                        args.iters)
+            print(json.dumps(dict(plan=p, segments=seg, walk_ms=round(ms, 4), prepare_ms=round(ms_prep, 4),
+                                  equal_to_plan11=same, max_diff_over_max_abs=rel, repeatable=repeatable,
+                                  moved_TBps=round(mb / ms / 1e9, 3), frac_moved=round(mb / ms / 1e9 / 8.0, 3))), flush=True)
+            assert repeatable and (same if seg == 1 else rel <= 1e-6), (p, seg)
     assert not op.flags_raised()
 
 

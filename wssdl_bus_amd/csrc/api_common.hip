@@ -22,6 +22,7 @@ static int *tuning_field(const char *key) {
     if (!strcmp(key, "roi_bwd_cg")) return &t.roi_bwd_cg;
     if (!strcmp(key, "nms_one_pass")) return &t.nms_one_pass;
     if (!strcmp(key, "nms_fused")) return &t.nms_fused;
+    if (!strcmp(key, "nms_fused_fault")) return &t.nms_fused_fault;
     if (!strcmp(key, "topk_sort")) return &t.topk_sort;
     return nullptr;
 }

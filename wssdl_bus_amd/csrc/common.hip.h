@@ -51,6 +51,8 @@ struct Tuning {
     int topk_sort = 1;          // order of the proposal candidates: 1 sorted runs + cross ranks (order_sort.hip),
                                 //    0 the select + sample sort of nms.hip
     int nms_fused = 1;          // 0: mask and sweep of a one-pass NMS as two launches instead of the fused one
+    int nms_fused_fault = 0;    // fault injection (tests): > 0 = the fused launch withholds image 0's segment counts
+                                //    and its sweep gives up after this many microseconds -> roi count -1
 };
 Tuning &tuning();
 

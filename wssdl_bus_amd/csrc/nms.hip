@@ -773,16 +773,22 @@ struct SweepArgs {
     // have finished; the segment is complete at MASK_WAVES * min((s + 1) * MASK_SEG, nrb).  NULL: the mask is
     // complete before the sweep starts.
     const int *segdone;  int nrb;
+    // fused run: how long a stager waits for a column segment without progress before it gives up, in ticks of
+    // the 100 MHz real-time counter (0.5 s unless the fault-injection knob shortens it)
+    unsigned long long wait_ticks;
 };
 
 // Wait (one wave, before it reads words of column segment `index`) until the mask blocks running beside
 // this sweep have finished that segment.  Bounded: after ~0.5 s without progress the wave gives up
-// and raises *timed_out (the caller then reports zero kept boxes: a loud failure instead of a hang).
-__device__ __forceinline__ void sweep_wait_segment(const int *segdone, int expected, int index, int *timed_out) {
+// and raises *timed_out; the image then reports num_keep = -1 (WSSDL_NMS_TIMED_OUT), which every consumer of
+// the counts treats as an error -- never a silent zero (the GPU shared with a long-running kernel of another
+// process is the realistic cause: the mask blocks this sweep waits for are then not being scheduled).
+__device__ __forceinline__ void sweep_wait_segment(const int *segdone, int expected, int index, int *timed_out,
+                                                   unsigned long long wait_ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();           // 100 MHz
     while (__hip_atomic_load(segdone + index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
         __builtin_amdgcn_s_sleep(16);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) { *timed_out = 1;  break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > wait_ticks) { *timed_out = 1;  break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
@@ -806,6 +812,7 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 8) sh.ring[tid] = 0ull;
     if (tid < 2) { sh.pub[tid].kept = 0ull; sh.pub[tid].base = 0; sh.pub[tid].count = 0; }
+    __syncthreads();        // sh.timed_out is reset before any stager's first wait can raise it
 
     // role and group of this wave; a group acts on the iterations with (c & 1) == group
     // (a SIMD-aware placement of the roles -- resolver alone with the light roles on its SIMD,
@@ -841,7 +848,7 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
             const int want = min(chunk + SWEEP_AHEAD, nchunks - 1) / MASK_SEG + 1;
             while (seg_ready < want) {
                 sweep_wait_segment(A.segdone, MASK_WAVES * min((seg_ready + 1) * MASK_SEG, A.nrb), img * ncb + seg_ready,
-                                   &sh.timed_out);
+                                   &sh.timed_out, A.wait_ticks);
                 ++seg_ready;
             }
         }
@@ -1055,7 +1062,7 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
         if (((last + 1) & 1) == group) { expand(last); flush(); }
     }
     if (tid == 0) {
-        num_keep[img] = sh.timed_out ? 0 : min(count, max_keep);
+        num_keep[img] = sh.timed_out ? WSSDL_NMS_TIMED_OUT : min(count, max_keep);
         if (done_out) done_out[img] = (count >= max_keep || n_dev[img] <= n_limit) ? 1 : 0;
     }
 }
@@ -1109,7 +1116,7 @@ struct SegTable {
 };
 
 __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_num_vgpr(80))) void nms_mask_sweep_fused_kernel(MaskArgs M, SweepArgs S, int n_images, int nseg, SegTable table,
-                                                                            int *ctl) {
+                                                                            int *ctl, int fault) {
     extern __shared__ unsigned long long sweep_dyn[];
     __shared__ SweepShared sh;
     const int ncb = M.ncb;
@@ -1135,7 +1142,9 @@ __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_num_vgpr(80))) v
     // this wave's words (and its entries of the summary and of diag_t) have been written through: once they
     // are acknowledged, count the segment up
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(ctl + (size_t)img * ncb + seg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (fault injection, tests only: image 0's segments are never reported, so its sweep must time out)
+    if (lane == 0 && !(fault && img == 0))
+        __hip_atomic_fetch_add(ctl + (size_t)img * ncb + seg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *diag_t,
@@ -1148,7 +1157,7 @@ int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *d
     size_t lds = ((size_t)max_keep + 64) * sizeof(int);
     if (nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ)) {
         const SweepArgs S = {mask, diag_t, summ, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
-                             boxes, box_stride_img, rois_padded, n_limit, done_in, done_out, nullptr, 0};
+                             boxes, box_stride_img, rois_padded, n_limit, done_in, done_out, nullptr, 0, 0ull};
         hipLaunchKernelGGL(nms_sweep_pipelined_kernel, dim3(n_images), dim3(SWEEP_BLOCK), lds, st, S);
         return check_launch();
     }
@@ -1207,13 +1216,17 @@ static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n
                             int *keep, int *num_keep, float *rois_padded, hipStream_t st) {
     const int ncb = nms_mask_pitch(n_max), nrb = cdiv(n_max, 64);
     const int nseg = cdiv(nrb, MASK_SEG);
+    const int fault = tuning().nms_fused_fault;
     int *segdone = reinterpret_cast<int *>(summ + (size_t)n_images * ncb * ncb);
     // the control words = 0 (the summaries need no initialisation: every entry that is read is written)
     if (hipMemsetAsync(segdone, 0, sizeof(int) * (size_t)n_images * ncb, st) != hipSuccess) return WSSDL_ERR_LAUNCH;
     const MaskArgs M = {boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, 0x7fffffff, 0, nullptr,
                         NMS_DENSE_AHEAD, segdone + ncb - 2, ncb, 0};
     const SweepArgs S = {mask, diag_t, summ, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
-                         boxes, box_stride_img, rois_padded, 0x7fffffff, nullptr, nullptr, segdone, nrb};
+                         boxes, box_stride_img, rois_padded, 0x7fffffff, nullptr, nullptr, segdone, nrb,
+                         // 0.5 s; wssdl_set_tuning("nms_fused_fault", microseconds) shortens the wait AND withholds
+                         // image 0's segment counts: the test of the time-out path
+                         fault > 0 ? (unsigned long long)fault * 100ull : 50000000ull};
     const size_t lds_mask = (size_t)(SWEEP_BLOCK / 64) * (5 * 64 * sizeof(float) + 64 * sizeof(nms_float4v));
     SegTable table;
     if (nseg > MASK_MAX_SEGS) return WSSDL_ERR_INVALID_ARGUMENT;
@@ -1225,7 +1238,7 @@ static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n
     if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
     const size_t lds_sweep = ((size_t)max_keep + 64) * sizeof(int);
     hipLaunchKernelGGL(nms_mask_sweep_fused_kernel, dim3((unsigned)blocks), dim3(SWEEP_BLOCK),
-                       lds_sweep > lds_mask ? lds_sweep : lds_mask, st, M, S, n_images, nseg, table, segdone);
+                       lds_sweep > lds_mask ? lds_sweep : lds_mask, st, M, S, n_images, nseg, table, segdone, fault);
     return check_launch();
 }
 

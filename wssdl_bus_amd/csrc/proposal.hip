@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void proposal_compact_kernel(
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= counts[img]) return;
     int off = 0;
-    for (int k = 0; k < img; ++k) off += counts[k];
+    for (int k = 0; k < img; ++k) off += max(counts[k], 0);      // (a count of -1 = WSSDL_NMS_TIMED_OUT: no rows)
     if (off + p >= total) return;
     const float *s = rois_padded + ((size_t)img * post_topn + p) * 5;
     float *d = out + (size_t)(off + p) * 5;

@@ -100,6 +100,8 @@ size_t walk_workspace_bytes(int R, int N, int H, int W, int PH, int PW);
 int walk_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, int PW, float scale, int rounding,
                  void *workspace, size_t workspace_bytes, int *plan_out, hipStream_t st);
 int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH,
-                int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, hipStream_t st);
+                int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, hipStream_t st,
+                int nseg = 1, float *partial = nullptr);
+int walk_split_segments(int R, int N, int H, int W, int C);
 
 }  // namespace wssdl

@@ -867,6 +867,32 @@ extern "C" int wssdl_roi_pool_backward_prepare(const float *rois, int R, int N, 
     return rc;
 }
 
+extern "C" int wssdl_roi_pool_backward_split_segments(int R, int N, int H, int W, int C) {
+    return walk_split_segments(R, N, H, W, C);
+}
+
+extern "C" size_t wssdl_roi_pool_backward_split_scratch_bytes(int N, int H, int W, int C, int segments) {
+    if (segments <= 1 || N < 1 || H < 1 || W < 1 || C < 1) return 0;
+    return (size_t)(segments - 1) * (size_t)N * H * W * C * sizeof(float);
+}
+
+extern "C" int wssdl_roi_pool_backward_compact_split(const float *top_diff, const uint8_t *argmax8, const float *rois,
+                                                     int R, int N, int H, int W, int C, int pooled_h, int pooled_w,
+                                                     float spatial_scale, int rounding, float *bottom_diff,
+                                                     void *workspace, size_t workspace_bytes, int plan, int segments,
+                                                     void *scratch, size_t scratch_bytes, wssdl_stream_t stream) {
+    if (N < 0 || R < 0 || !compact_supported(H, W, C, pooled_h, pooled_w)) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (rounding != WSSDL_ROI_ROUND_CUDA && rounding != WSSDL_ROI_ROUND_CPU) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (N == 0) return WSSDL_OK;
+    if (!bottom_diff || (R > 0 && (!top_diff || !argmax8 || !rois))) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (plan < 0 || !workspace || !walk_supported(R, N, H, W, C, pooled_h, pooled_w)) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (segments < 1) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (segments > 1 && (!scratch || scratch_bytes < wssdl_roi_pool_backward_split_scratch_bytes(N, H, W, C, segments)))
+        return WSSDL_ERR_WORKSPACE;
+    return launch_walk(top_diff, argmax8, R, N, H, W, C, pooled_h, pooled_w, bottom_diff, workspace, workspace_bytes, plan,
+                       as_stream(stream), segments, static_cast<float *>(scratch));
+}
+
 extern "C" int wssdl_roi_pool_backward_compact(const float *top_diff, const uint8_t *argmax8,
                                                const float *rois, int R, int N, int H, int W, int C,
                                                int pooled_h, int pooled_w, float spatial_scale,

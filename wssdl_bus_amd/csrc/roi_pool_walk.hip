@@ -44,6 +44,7 @@ namespace wssdl {
 
 constexpr unsigned ARG8_EMPTY_W = 0xffu;
 constexpr int WALK_SLOTS = 8;            // slots per record (64 B)
+constexpr int WALK_MAX_SEGMENTS = 16;    // split form: segments a tile's stream may be cut into
 
 __device__ __forceinline__ int win_start_w(int p, float bin, int rs, int limit, int rounding) {
     const float v = (float)p * bin;
@@ -411,7 +412,8 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
     const float *__restrict__ top_diff, const unsigned char *__restrict__ arg8,
     const unsigned *__restrict__ slots, const int *__restrict__ tile_off, const int *__restrict__ tile_slots,
     const int *__restrict__ order, int items, int tiles_w, int tiles, int G, int H, int W, int C,
-    unsigned total_elems, float *__restrict__ bottom_diff) {
+    unsigned total_elems, float *__restrict__ bottom_diff, int nseg, float *__restrict__ partial,
+    unsigned long long seg_stride) {
     static_assert(TH <= 8 && TW <= 8 && DEPTH >= 2 && DEPTH <= 4, "8-bit masks; 2..4 records in flight");
     __shared__ float acc[(TH * TW + 1) * CPL * 64];
     // blockIdx -> (position k in the launch order, channel group g).  Workgroups are dealt
@@ -447,8 +449,15 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
 #pragma unroll
     for (int i = 0; i < (TH * TW + 1) * CPL; ++i) acc[i * 64 + lane] = 0.0f;
 
-    const int nrec = (tile_slots[item] + WALK_SLOTS - 1) / WALK_SLOTS;
-    const unsigned *rp = slots + (size_t)tile_off[item] * 16;
+    // Split form (wssdl_roi_pool_backward_compact_split): blockIdx.y = segment s of nseg walks the records
+    // [s, s + 1) * nrec / nseg of the tile's stream into a tile of its own; segment 0 writes bottom_diff, the
+    // others partial[s - 1] (same layout), and walk_combine_kernel adds them in segment order.  nseg == 1 is the
+    // reference's summation order, bit for bit; nseg > 1 is deterministic but associates the sum differently.
+    const int seg = blockIdx.y;
+    const int nrec_all = (tile_slots[item] + WALK_SLOTS - 1) / WALK_SLOTS;
+    const int rec0 = (int)((long long)nrec_all * seg / nseg), rec1 = (int)((long long)nrec_all * (seg + 1) / nseg);
+    const int nrec = rec1 - rec0;
+    const unsigned *rp = slots + ((size_t)tile_off[item] + rec0) * 16;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char *>(arg8), 0, (int)total_elems, 0x00020000);
     const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
@@ -478,7 +487,8 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
     }
 
     if (lane_ok) {
-        float *img = bottom_diff + (size_t)n * H * W * C;
+        float *img = (seg == 0 ? bottom_diff : partial + (size_t)(seg - 1) * seg_stride) +
+                     (size_t)n * H * W * C;
 #pragma unroll
         for (int i = 0; i < TH * TW; ++i) {
             const int h = h0 + i / TW, w = w0 + i % TW;
@@ -564,6 +574,20 @@ static int walk_plan_choice(int N, int H, int W, int C) {
     return walk_plan_auto(N, H, W, C);
 }
 
+// Split form: a launch with few images is bound by the longest slot chain one wave walks alone (every RoI of a
+// 2000-RoI image touches the tiles at the image's centre: ~9000 dependent LDS read-add-write steps at ~35 ns,
+// whatever the tile shape), not by bandwidth.  Cutting every tile's stream into `segments` pieces walked by
+// separate waves shortens the chain by that factor; the pieces' tiles are then added in segment order, which
+// associates the f32 sum differently from the reference (roi_pooling_op_gpu.cu.cc:132-186 sums roi^, ph^, pw^):
+// deterministic, within ~1e-7 relative of the exact walk, NOT bit-identical -- so it is a separate entry point
+// (wssdl_roi_pool_backward_compact_split) and the exact walk stays the contract of ..._backward_compact.
+// Suggested only where it pays (extra traffic: (segments - 1) * 2 * N*H*W*C*4 bytes): at most 4 images and at
+// least 1000 RoIs per image (the weak images of the reference's default 1 + 2 batch and of the alternating mode).
+int walk_split_segments(int R, int N, int H, int W, int C) {
+    if (N < 1 || N > 4 || (C & 3) || (long long)R < 1000LL * N) return 1;
+    return 4;
+}
+
 bool walk_supported(int R, int N, int H, int W, int C, int PH, int PW) {
     if (PH > 8 || PW > 8 || (C & 1)) return false;
     const long long elems = (long long)R * PH * PW * C;
@@ -624,10 +648,23 @@ int walk_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, i
     return rc;
 }
 
+// partial sums of the split form: bottom_diff += partial[0] + partial[1] + ... in that order (4 channels per thread)
+__global__ __launch_bounds__(256) void walk_combine_kernel(float *__restrict__ bottom_diff, const float *__restrict__ partial,
+                                                           long long n4, int extra, unsigned long long seg_stride) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4v o = reinterpret_cast<const float4v *>(bottom_diff)[i];
+    for (int s = 0; s < extra; ++s) {
+        const float4v p = reinterpret_cast<const float4v *>(partial + (size_t)s * seg_stride)[i];
+        o.x = o.x + p.x;  o.y = o.y + p.y;  o.z = o.z + p.z;  o.w = o.w + p.w;
+    }
+    reinterpret_cast<float4v *>(bottom_diff)[i] = o;
+}
+
 template <int TH, int TW, int DEPTH, int MINW, int CPL>
 static int launch_walk_t(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C,
                          int PH, int PW, float *bottom_diff, void *workspace, size_t workspace_bytes,
-                         hipStream_t st) {
+                         hipStream_t st, int nseg, float *partial) {
     const int tiles_h = cdiv(H, TH), tiles_w = cdiv(W, TW), tiles = tiles_h * tiles_w;
     const int items = N * tiles;
     WalkWs ws;
@@ -640,18 +677,26 @@ static int launch_walk_t(const float *top_diff, const unsigned char *arg8, int R
     else if (G < 8 && (8 % G) == 0) blocks = 8LL * cdiv(items, 8 / G);
     else blocks = (long long)items * G;
     if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<TH, TW, DEPTH, MINW, CPL>), dim3((unsigned)blocks), dim3(64), 0, st,
-                       top_diff, arg8, reinterpret_cast<const unsigned *>(ws.slots), ws.tile_off, ws.tile_slots,
-                       ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff);
+    const unsigned long long seg_stride = (unsigned long long)N * H * W * C;
+    hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<TH, TW, DEPTH, MINW, CPL>), dim3((unsigned)blocks, (unsigned)nseg), dim3(64),
+                       0, st, top_diff, arg8, reinterpret_cast<const unsigned *>(ws.slots), ws.tile_off, ws.tile_slots,
+                       ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff, nseg, partial, seg_stride);
+    if (nseg > 1) {
+        const long long n4 = (long long)(seg_stride / 4);          // C is even and walk_split_supported asks C % 4 == 0
+        hipLaunchKernelGGL(walk_combine_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, bottom_diff, partial, n4,
+                           nseg - 1, seg_stride);
+    }
     return check_launch();
 }
 
 int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH,
-                int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, hipStream_t st) {
+                int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, hipStream_t st,
+                int nseg, float *partial) {
+    if (nseg < 1 || nseg > WALK_MAX_SEGMENTS || (nseg > 1 && (!partial || (C & 3)))) return WSSDL_ERR_INVALID_ARGUMENT;
     switch (plan) {
 #define WSSDL_X(ID, TH, TW, D, MW, CPL) \
         case ID: return launch_walk_t<TH, TW, D, MW, CPL>(top_diff, arg8, R, N, H, W, C, PH, PW, bottom_diff, workspace, \
-                                                         workspace_bytes, st);
+                                                         workspace_bytes, st, nseg, partial);
         WSSDL_WALK_PLANS(WSSDL_X)
 #undef WSSDL_X
         default: return WSSDL_ERR_INVALID_ARGUMENT;

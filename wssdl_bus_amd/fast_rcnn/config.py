@@ -104,6 +104,12 @@ __C.ROI_POOL_FLAG_CHECK = "deferred"
 # index -1) and nothing between the backbone and the loss copies to the host: the hot path can be
 # captured in a hipGraph.  The per-RoI head then runs on the padded row count (batch-norm masked to the
 # live rows).  False (default): the blob is compacted, which costs one read-back of N counts per step.
+# RoI-pool backward of the training path on launches with few images (<= 4) and many RoIs per image (>= 1000):
+# 'auto' = the library's rule (wssdl_roi_pool_backward_split_segments: 4 segments there, the exact walk
+# everywhere else), an int = that many segments, 0 = always the exact walk.  The split form is deterministic but
+# associates each element's f32 sum differently from the reference (within ~1e-7 of it; north_star's tolerance
+# for RoI pooling is 1e-5); the parity tests of the gradient run the exact walk.
+__C.ROI_POOL_BWD_SPLIT = 'auto'
 __C.PADDED_ROIS = False
 # a13: the four supervised loss terms and their gradients as one device op (csrc/loss.hip) when the
 # layers are on the GPU; False = the chain of torch ops in fast_rcnn/train_bus.py

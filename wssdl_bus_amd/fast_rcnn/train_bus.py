@@ -179,6 +179,13 @@ class SolverWrapper(object):
         if count_step:
             self.global_step += 1
 
+    def check_flags(self):
+        """Synchronising look at the deferred device flags (RoI-pool overflow, NMS time-out).  The poll in
+        _apply runs one step late -- by the time it raises, the optimiser has already applied the step before
+        it, so the parameters of that step are tainted -- and it never sees the last step: call this before
+        saving parameters (the reference's snapshot, train_bus.py:66-101) and at the end of training."""
+        roi_pooling_op.check_flags()
+
     def joint_backward(self, blobs):
         """Forward + backward of one combined mini-batch (train_bus.py:732-764): supervised images
         first, weak images after; the supervised and MIL gradients are summed per variable

@@ -106,12 +106,17 @@ _OVERFLOW_MSG = ("RoI pooling (1-byte arg-max path): a bin window exceeded 15 x 
                  "outside the feature map.  Its arg-max and gradient are invalid; clip the RoIs or use the i32 "
                  "pair (cfg.ROI_POOL_COMPACT_ARGMAX = False or cfg.ROI_POOL_FLAG_CHECK = 'eager').")
 _LISTS_MSG = "RoI pooling backward: the per-tile lists overflowed their workspace; bottom_diff is short."
+_NMS_TIMEOUT_MSG = ("proposal layer: the NMS sweep of an image gave up waiting for the mask blocks of the fused launch "
+                    "(roi count -1 = WSSDL_NMS_TIMED_OUT: the GPU was held by another process or kernel).  That "
+                    "image's proposals are incomplete; the step must not be used.")
 
 
 class _DeviceFlags(object):
     def __init__(self, dev):
-        self.flags = torch.zeros((2,), dtype=torch.int32, device=dev)
-        self.host = torch.zeros((2,), dtype=torch.int32).pin_memory()
+        # [0] forward window overflow, [1] backward lists overflow, [2] an NMS sweep timed out (raised by
+        # proposal_layer_tf_bus.padded_blob, the one consumer of the roi counts that never reads them back)
+        self.flags = torch.zeros((3,), dtype=torch.int32, device=dev)
+        self.host = torch.zeros((3,), dtype=torch.int32).pin_memory()
         self.event = None
 
     @staticmethod
@@ -120,6 +125,8 @@ class _DeviceFlags(object):
             raise _lib.HipCallError(_OVERFLOW_MSG)
         if int(v[1]) != 0:
             raise _lib.HipCallError(_LISTS_MSG)
+        if int(v[2]) != 0:
+            raise _lib.HipCallError(_NMS_TIMEOUT_MSG)
 
     def read_and_clear(self):
         v = self.flags.cpu()
@@ -130,6 +137,8 @@ class _DeviceFlags(object):
     def poll(self):
         if self.event is not None and self.event.query():
             self.event = None
+            if int(self.host.abs().sum()) != 0:
+                self.flags.zero_()            # reported once: later polls start clean
             self._raise(self.host)
         if self.event is None:
             self.host.copy_(self.flags, non_blocking=True)
@@ -149,6 +158,12 @@ def _flags(dev):
 
 def _overflow_flag(dev):
     return _flags(dev).flags[0:1]
+
+
+def note_roi_counts(counts):
+    """Sync-free: raises the deferred flag [2] when any per-image roi count is negative (WSSDL_NMS_TIMED_OUT)."""
+    f = _flags(counts.device)
+    f.flags[2:3] |= (counts.min() < 0).to(torch.int32)
 
 
 def poll_flags():
@@ -248,10 +263,22 @@ def roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scal
     return BackwardPlan(ws, nws, int(plan.value))
 
 
+def split_segments(shape, R):
+    """How many segments the list-driven backward cuts a tile's slot stream into for this launch:
+    cfg.ROI_POOL_BWD_SPLIT = 'auto' (the library's rule: few images with >= 1000 RoIs each -> 4), an int, or
+    0 / 1 for the exact walk.  > 1 is deterministic but NOT bit-identical to the reference's summation order."""
+    v = cfg.get("ROI_POOL_BWD_SPLIT", "auto")
+    N, H, W, C = shape
+    if v == "auto":
+        return int(_lib.lib().wssdl_roi_pool_backward_split_segments(int(R), N, H, W, C))
+    return max(1, int(v))
+
+
 def roi_pool_grad_compact(shape, rois, arg8, grad, pooled_height, pooled_width, spatial_scale,
-                          rounding=None, use_workspace=True, plan=None):
+                          rounding=None, use_workspace=True, plan=None, segments=1):
     """bottom_diff from the 1-byte arg-max.  `plan` = what roi_pool_grad_prepare returned for these
-    RoIs (prepared here when None and use_workspace)."""
+    RoIs (prepared here when None and use_workspace).  `segments` > 1: the split form
+    (wssdl_roi_pool_backward_compact_split; deterministic, not bit-ordered -- see split_segments)."""
     N, H, W, C = shape
     mode = _ROUNDING[cfg.ROI_POOL_ROUNDING if rounding is None else rounding]
     out = torch.empty(shape, dtype=torch.float32, device=grad.device)
@@ -261,6 +288,19 @@ def roi_pool_grad_compact(shape, rois, arg8, grad, pooled_height, pooled_width, 
         plan = roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scale, rounding)
     if plan is None or plan.plan < 0:
         plan = BackwardPlan(None, 0, -1)
+    segments = int(segments) if plan.plan >= 0 else 1
+    if segments > 1:
+        with torch.cuda.device(grad.device):
+            nscr = L.wssdl_roi_pool_backward_split_scratch_bytes(N, H, W, C, segments)
+            scratch = torch.empty((nscr,), dtype=torch.uint8, device=grad.device)
+            with _lib.timed("roi_pool_backward", dict(N=N, H=H, W=W, C=C, R=R, argmax_bytes=1, plan=plan.plan,
+                                                      segments=segments)):
+                _lib.check(L.wssdl_roi_pool_backward_compact_split(
+                    _lib.ptr(grad), _lib.ptr(arg8), _lib.ptr(rois), R, N, H, W, C,
+                    int(pooled_height), int(pooled_width), float(spatial_scale), mode, _lib.ptr(out),
+                    _lib.ptr(plan.workspace), plan.nbytes, plan.plan, segments, _lib.ptr(scratch), nscr,
+                    _lib.stream()), "wssdl_roi_pool_backward_compact_split")
+        return out
     with torch.cuda.device(grad.device):
         with _lib.timed("roi_pool_backward", dict(N=N, H=H, W=W, C=C, R=R, argmax_bytes=1, plan=plan.plan)):
             _lib.check(L.wssdl_roi_pool_backward_compact(
@@ -326,7 +366,7 @@ class RoiPoolFunction(torch.autograd.Function):
         shape, ph, pw, scale, rounding = ctx.geom
         if ctx.compact:
             bottom_diff = roi_pool_grad_compact(shape, rois, arg, grad_top.contiguous(), ph, pw, scale,
-                                                rounding, plan=ctx.plan)
+                                                rounding, plan=ctx.plan, segments=split_segments(shape, rois.shape[0]))
         else:
             bottom_diff = roi_pool_grad(torch.empty(shape, device="meta"), rois, arg,
                                         grad_top.contiguous(), ph, pw, scale)

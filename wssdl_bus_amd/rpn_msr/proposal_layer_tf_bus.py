@@ -73,6 +73,11 @@ def compact_rois(rois_padded, counts, counts_host=None):
     N, P = rois_padded.shape[:2]
     if counts_host is None:
         counts_host = counts.cpu().numpy()
+    if (np.asarray(counts_host) < 0).any():
+        # WSSDL_NMS_TIMED_OUT: the sweep of that image gave up waiting for the fused launch's mask blocks
+        raise _lib.HipCallError("proposal layer: NMS sweep timed out for image(s) %s (roi count -1): the GPU was held "
+                                "by another process or kernel; the proposals are incomplete"
+                                % np.nonzero(np.asarray(counts_host) < 0)[0].tolist())
     total = int(counts_host.sum())
     out = torch.empty((total, 5), dtype=torch.float32, device=rois_padded.device)
     with torch.cuda.device(rois_padded.device):
@@ -90,6 +95,10 @@ def padded_blob(rois_padded, counts):
     -1 on the rows an image does not use -- no device->host copy.  RoI pooling treats such rows as
     empty, the proposal-target layer never samples them, the MIL selection never matches them."""
     N, P = rois_padded.shape[:2]
+    # a negative count (WSSDL_NMS_TIMED_OUT) leaves the image without live rows here and raises the deferred
+    # flag that SolverWrapper polls before every optimiser step (roi_pooling_op.poll_flags / check_flags)
+    from ..roi_pooling_layer import roi_pooling_op as _rp
+    _rp.note_roi_counts(counts)
     live = torch.arange(P, device=rois_padded.device).view(1, P) < counts.view(N, 1).to(torch.int64)
     out = rois_padded.clone()
     out[:, :, 0] = torch.where(live, out[:, :, 0], torch.full_like(out[:, :, 0], -1.0))
