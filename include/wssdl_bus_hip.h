@@ -257,7 +257,9 @@ WSSDL_API int wssdl_roi_targets(const float *rois, const int32_t *keep, const ui
 
 /* ---------------------------------------------------------------- a11, a12 ---
  * RoiPool forward: roi_pooling_op.cc:31-52 (op), kernels roi_pooling_op_gpu.cu.cc:20-85
- * (rounding CUDA) / roi_pooling_op.cc:137-196 (rounding CPU).
+ * (rounding CUDA) / roi_pooling_op.cc:137-196 (rounding CPU).  N <= 0 = "batch size unknown": the
+ * reference's ROIPoolForwardLaucher is not told it (roi_pooling_op_gpu.h:18-22) and never range-checks
+ * rois[:, 0]; then only a negative batch index makes a RoI empty (with N > 0 an index >= N does too).
  * bottom [N,H,W,C] f32, rois [R,5] f32, top [R,PH,PW,C] f32, argmax [R,PH,PW,C] i32
  * (flat NHWC index within the roi's image, -1 for an empty bin). */
 WSSDL_API int wssdl_roi_pool_forward(const float *bottom, int N, int H, int W, int C, const float *rois,
@@ -270,6 +272,16 @@ WSSDL_API int wssdl_roi_pool_forward(const float *bottom, int N, int H, int W, i
 WSSDL_API int wssdl_roi_pool_backward(const float *top_diff, const int32_t *argmax, const float *rois,
                             int R, int N, int H, int W, int C, int pooled_h, int pooled_w,
                             float spatial_scale, float *bottom_diff, wssdl_stream_t stream);
+/* The same op with a caller-owned workspace (wssdl_roi_pool_backward_workspace_bytes(R, N, H, W, pooled_h,
+ * pooled_w); a TF launcher takes it from OpKernelContext::allocate_temp): the list-driven kernels of the training
+ * path -- per (image, tile) the candidate bins in the reference's order, one wave per (image, tile, 128 channels)
+ * -- reading the i32 arg-max.  Same bits as wssdl_roi_pool_backward; 1.7x faster on a train-sized RoI list.
+ * Shapes the lists do not cover (C not a power of two, pooled size > 8, workspace NULL or short) run the kernel
+ * of wssdl_roi_pool_backward. */
+WSSDL_API int wssdl_roi_pool_backward_ws(const float *top_diff, const int32_t *argmax, const float *rois,
+                            int R, int N, int H, int W, int C, int pooled_h, int pooled_w,
+                            float spatial_scale, float *bottom_diff, void *workspace, size_t workspace_bytes,
+                            wssdl_stream_t stream);
 
 /* ------------------------------------------------- a11, a12: training path ---
  * The same pair with a ONE-BYTE arg-max.  In the reference the arg-max tensor never leaves the
@@ -337,8 +349,9 @@ WSSDL_API int wssdl_roi_pool_backward_compact(const float *top_diff, const uint8
  * image's centre), not by bandwidth: each tile's stream is cut into `segments` pieces walked by separate waves
  * (segment 0 into bottom_diff, the others into scratch) and the pieces are added in segment order.  The f32 sum
  * per element is then associated differently from roi_pooling_op_gpu.cu.cc:132-186 (roi^, ph^, pw^): the same
- * result on every run, within ~1e-7 (relative to the element's magnitude scale) of ..._backward_compact, not
- * bit-identical to it -- north_star's tolerance for RoI pooling is 1e-5.  segments = 1 is the exact walk.
+ * result on every run, every element within 1e-6 of ..._backward_compact relative to its own sum of |terms|
+ * (measured ~2e-8) and the tensor within 1e-5 of its scale (north_star's tolerance for RoI pooling), not
+ * bit-identical to it.  segments = 1 is the exact walk.
  * wssdl_roi_pool_backward_split_segments suggests a count by launch shape (1 = keep the exact walk: more than
  * 4 images, or fewer than 1000 RoIs per image); same plan / workspace as ..._backward_compact. */
 WSSDL_API int wssdl_roi_pool_backward_split_segments(int R, int N, int H, int W, int C);

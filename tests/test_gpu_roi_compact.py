@@ -217,13 +217,63 @@ def test_autograd_uses_compact_path_and_matches_oracle(torch_cuda):
     assert not op.compact_overflowed()
 
 
+@pytest.mark.parametrize("shape,R,P", [((3, 38, 63, 1024), 1500, 7), ((2, 37, 62, 512), 2600, 7),
+                                       ((1, 20, 30, 128), 5000, 7), ((2, 38, 63, 256), 5000, 6)])
+@pytest.mark.parametrize("mode", ["cuda", "cpu"])
+def test_i32_contract_forward_on_the_wave_uniform_kernel(torch_cuda, shape, R, P, mode):
+    """wssdl_roi_pool_forward (the reference op's own two outputs: f32 top + i32 flat-index argmax) runs the
+    round-3 forward (one wave per bin row, scalar windows, shared bin columns) with an i32 store for train-sized
+    RoI lists: top and argmax bit-equal to the C oracle, RoIs reaching far outside the map included (no window
+    limit on this path), and N = 0 ("batch size unknown", the declared ROIPoolForwardLaucher signature)."""
+    torch = torch_cuda
+    from wssdl_bus_amd import _lib
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    N, H, W, C = shape
+    rs = np.random.RandomState(C + R)
+    f = np.maximum(rs.normal(size=shape), 0).astype(np.float32)
+    rois = _rois_for(rs, R, N, H, W)
+    rois[5] = [0, -4000, -3000, 16 * W + 4000, 16 * H + 3000]      # windows far larger than 15 x 16 cells
+    rois[6] = [N - 1, -500, 40, 200, 16 * H + 900]
+    et, ea = c_oracle.roi_pool_forward(f, rois, P, P, 1.0 / 16, mode, threads=16)
+    ft, rt = torch.from_numpy(f).cuda(), torch.from_numpy(rois).cuda()
+    top, arg = op.roi_pool(ft, rt, P, P, 1.0 / 16, rounding=mode)
+    assert arg.dtype == torch.int32
+    assert np.array_equal(top.cpu().numpy(), et) and np.array_equal(arg.cpu().numpy(), ea)
+    # RoiPoolGrad with the i32 arg-max on the list-driven walk (wssdl_roi_pool_backward_ws): the reference's
+    # summation order, bit for bit; without a workspace the tile-owner kernel gives the same bits
+    w_np = rs.normal(size=et.shape).astype(np.float32)
+    want_g = c_oracle.roi_pool_backward(w_np, ea, rois, shape, P, P, 1.0 / 16)
+    wt = torch.from_numpy(w_np).cuda()
+    g = op.roi_pool_grad(ft, rt, arg, wt, P, P, 1.0 / 16)
+    assert np.array_equal(g.cpu().numpy(), want_g)
+    g0 = torch.empty_like(ft)
+    _lib.check(_lib.lib().wssdl_roi_pool_backward(_lib.ptr(wt), _lib.ptr(arg), _lib.ptr(rt), R, N, H, W, C, P, P, 1.0 / 16,
+                                                  _lib.ptr(g0), _lib.stream()), "wssdl_roi_pool_backward")
+    assert torch.equal(g0, g)
+    # N = 0: no range check of the batch index (every index here is in range, so the result is the same)
+    top0 = torch.empty_like(top)
+    arg0 = torch.empty_like(arg)
+    _lib.check(_lib.lib().wssdl_roi_pool_forward(_lib.ptr(ft), 0, H, W, C, _lib.ptr(rt), R, P, P, 1.0 / 16,
+                                                 {"cuda": 0, "cpu": 1}[mode], _lib.ptr(top0), _lib.ptr(arg0), _lib.stream()),
+               "wssdl_roi_pool_forward(N=0)")
+    assert torch.equal(top0, top) and torch.equal(arg0, arg)
+    # with N given, an index >= N is an empty RoI (zeros, -1); with N = 0 it would be read (not tested: out of bounds)
+    bad = rois.copy()
+    bad[7, 0] = N + 3
+    bad[8, 0] = -1
+    tb, ab = op.roi_pool(ft, torch.from_numpy(bad).cuda(), P, P, 1.0 / 16, rounding=mode)
+    assert not tb[7].any() and not tb[8].any() and bool((ab[7] == -1).all()) and bool((ab[8] == -1).all())
+    keep = np.ones(R, bool)
+    keep[[7, 8]] = False
+    assert np.array_equal(tb.cpu().numpy()[keep], et[keep]) and np.array_equal(ab.cpu().numpy()[keep], ea[keep])
+
+
 def test_split_walk_is_deterministic_and_within_1e6_of_the_oracle(torch_cuda):
     """wssdl_roi_pool_backward_compact_split (few images, many RoIs per image: the chain-bound launches of the
     reference's default 1 + 2 batch and of the alternating mode): a tile's slot stream cut into K segments
     walked by K waves, partial tiles added in segment order.  K = 1 is the exact walk (bit-equal to the C
-    oracle); K > 1 associates each element's f32 sum differently: the same bits on every run, within 1e-6 of
-    the oracle relative to the gradient's scale (north_star: 1e-5), elementwise within 1e-5 of the element's own
-    sum of magnitudes.  The library suggests K by launch shape; the autograd pair follows cfg.ROI_POOL_BWD_SPLIT."""
+    oracle); K > 1 associates each element's f32 sum differently: the same bits on every run, every element within
+    1e-6 of the oracle relative to its own sum of |terms|, the tensor within north_star's 1e-5 of its scale.  The library suggests K by launch shape; the autograd pair follows cfg.ROI_POOL_BWD_SPLIT."""
     torch = torch_cuda
     from wssdl_bus_amd import _lib
     from wssdl_bus_amd.fast_rcnn.config import cfg
@@ -263,8 +313,11 @@ def test_split_walk_is_deterministic_and_within_1e6_of_the_oracle(torch_cuda):
             b = op.roi_pool_grad_compact((N, H, W, C), rt, arg8, wt, 7, 7, 1.0 / 16, plan=plan, segments=K)
             assert torch.equal(a, b)                                                    # deterministic
             a = a.cpu().numpy()
-            assert np.abs(a - want_g).max() <= 1e-6 * scale, (plan_id, K)
-            assert np.all(np.abs(a - want_g) <= 1e-5 * mag + 1e-30), (plan_id, K)
+            # a re-associated f32 sum of n terms differs by at most ~n * 2^-24 * sum |terms| (in practice ~sqrt(n)):
+            # every element within 1e-6 of the oracle relative to ITS OWN sum of magnitudes, and the whole
+            # tensor within north_star's 1e-5 of its scale
+            assert np.all(np.abs(a - want_g) <= 1e-6 * mag + 1e-30), (plan_id, K, float((np.abs(a - want_g) / (mag + 1e-30)).max()))
+            assert np.abs(a - want_g).max() <= 1e-5 * scale, (plan_id, K)
     assert not op.flags_raised()
     # the autograd pair: 'auto' takes the library's suggestion (4 here: 2 images x 1200 RoIs), 0 the exact walk
     assert cfg.ROI_POOL_BWD_SPLIT == "auto" and op.split_segments((N, H, W, C), R) == 4
@@ -275,7 +328,7 @@ def test_split_walk_is_deterministic_and_within_1e6_of_the_oracle(torch_cuda):
             t, _ = op.RoiPoolFunction.apply(f, rt, 7, 7, 1.0 / 16, None)
             (t * wt).sum().backward()
             g = f.grad.cpu().numpy()
-            assert np.abs(g - want_g).max() <= 1e-6 * scale
+            assert np.all(np.abs(g - want_g) <= 1e-6 * mag + 1e-30) and np.abs(g - want_g).max() <= 1e-5 * scale
             assert np.array_equal(g, want_g) or not exact_bits
         finally:
             cfg.ROI_POOL_BWD_SPLIT = "auto"

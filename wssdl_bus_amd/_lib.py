@@ -55,6 +55,7 @@ SYMBOLS = {
                                _vp]),
     "wssdl_roi_pool_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "wssdl_roi_pool_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "wssdl_roi_pool_backward_ws": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp]),
     "wssdl_roi_pool_compact_supported": (_i, [_i, _i, _i, _i, _i]),
     "wssdl_roi_pool_forward_compact": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "wssdl_roi_pool_forward_windows_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),

@@ -517,14 +517,23 @@ extern "C" int wssdl_roi_pool_forward(const float *bottom, int N, int H, int W, 
                                       const float *rois, int R, int pooled_h, int pooled_w,
                                       float spatial_scale, int rounding, float *top,
                                       int32_t *argmax, wssdl_stream_t stream) {
-    if (N < 0 || H < 1 || W < 1 || C < 1 || R < 0 || pooled_h < 1 || pooled_w < 1)
+    if (H < 1 || W < 1 || C < 1 || R < 0 || pooled_h < 1 || pooled_w < 1)
         return WSSDL_ERR_INVALID_ARGUMENT;
     if (rounding != WSSDL_ROI_ROUND_CUDA && rounding != WSSDL_ROI_ROUND_CPU)
         return WSSDL_ERR_INVALID_ARGUMENT;
     if ((long long)H * W * C > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;  // argmax is i32
     if (R == 0) return WSSDL_OK;
-    if (!bottom || !rois || !top || !argmax || N < 1) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (!bottom || !rois || !top || !argmax) return WSSDL_ERR_INVALID_ARGUMENT;
+    // N <= 0: the batch size is unknown -- the reference's ROIPoolForwardLaucher is not told it
+    // (roi_pooling_op_gpu.h:18-22) and never range-checks the batch index -- so only a negative index
+    // makes a RoI empty here; with N > 0 an index >= N does too.
+    if (N <= 0) N = 0x7fffffff;
     hipStream_t st = as_stream(stream);
+    {   // the round-3 kernel (one wave per bin row, scalar windows, shared columns) with an i32 store
+        const int rc = launch_fwd_rows_i32(bottom, N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top,
+                                           argmax, st);
+        if (rc != WSSDL_ROWS_I32_UNSUPPORTED) return rc;
+    }
     const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(bottom) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(top) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(argmax) & 15) == 0);
@@ -556,6 +565,32 @@ extern "C" int wssdl_roi_pool_forward(const float *bottom, int N, int H, int W, 
                            N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top,
                            argmax);
     return check_launch();
+}
+
+// RoiPoolGrad on the list-driven walk (roi_pool_walk.hip) with the reference's i32 arg-max: prepare + walk in one
+// call, the lists in a caller-owned workspace (wssdl_roi_pool_backward_workspace_bytes).  Shapes the walk does not
+// take (C not a power of two, pooled size > 8, ...) run the tile-owner kernel of wssdl_roi_pool_backward.
+extern "C" int wssdl_roi_pool_backward_ws(const float *top_diff, const int32_t *argmax, const float *rois, int R, int N,
+                                          int H, int W, int C, int pooled_h, int pooled_w, float spatial_scale,
+                                          float *bottom_diff, void *workspace, size_t workspace_bytes,
+                                          wssdl_stream_t stream) {
+    if (N < 0 || H < 1 || W < 1 || C < 1 || R < 0 || pooled_h < 1 || pooled_w < 1) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (N == 0) return WSSDL_OK;
+    if (!bottom_diff || (R > 0 && (!top_diff || !argmax || !rois))) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (workspace && (reinterpret_cast<uintptr_t>(top_diff) & 7) == 0 && (reinterpret_cast<uintptr_t>(argmax) & 7) == 0 &&
+        (reinterpret_cast<uintptr_t>(bottom_diff) & 7) == 0 && walk_i32_supported(R, N, H, W, C, pooled_h, pooled_w) &&
+        workspace_bytes >= walk_workspace_bytes(R, N, H, W, pooled_h, pooled_w)) {
+        hipStream_t st = as_stream(stream);
+        int plan = -1;
+        // (the window starts the lists also carry are not read on this path: the rounding mode does not matter)
+        int rc = walk_prepare(rois, R, N, H, W, C, pooled_h, pooled_w, spatial_scale, WSSDL_ROI_ROUND_CUDA, workspace,
+                              workspace_bytes, &plan, st);
+        if (rc != WSSDL_OK) return rc;
+        return launch_walk(top_diff, reinterpret_cast<const unsigned char *>(argmax), R, N, H, W, C, pooled_h, pooled_w,
+                           bottom_diff, workspace, workspace_bytes, plan, st, 1, nullptr, true);
+    }
+    return wssdl_roi_pool_backward(top_diff, argmax, rois, R, N, H, W, C, pooled_h, pooled_w, spatial_scale, bottom_diff,
+                                   stream);
 }
 
 extern "C" int wssdl_roi_pool_backward(const float *top_diff, const int32_t *argmax,

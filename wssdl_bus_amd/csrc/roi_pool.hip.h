@@ -92,6 +92,11 @@ __device__ __forceinline__ void touch_axis(int t0, int t1, int rs, int re, float
 }
 
 
+// wave-uniform forward with the i32 arg-max (roi_pool_compact.hip); WSSDL_ROWS_I32_UNSUPPORTED = shape not taken
+constexpr int WSSDL_ROWS_I32_UNSUPPORTED = -1000;
+int launch_fwd_rows_i32(const float *bottom, int N, int H, int W, int C, const float *rois, int R, int pooled_h,
+                        int pooled_w, float spatial_scale, int rounding, float *top, int32_t *argmax, hipStream_t st);
+
 // list-driven backward of the training path (roi_pool_walk.hip)
 int walk_plan_count();
 size_t walk_flags_offset(int R, int N, int H, int W, int PH, int PW);
@@ -101,7 +106,8 @@ int walk_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, i
                  void *workspace, size_t workspace_bytes, int *plan_out, hipStream_t st);
 int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH,
                 int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, hipStream_t st,
-                int nseg = 1, float *partial = nullptr);
+                int nseg = 1, float *partial = nullptr, bool i32 = false /* arg8 points at the i32 arg-max */);
+bool walk_i32_supported(int R, int N, int H, int W, int C, int PH, int PW);
 int walk_split_segments(int R, int N, int H, int W, int C);
 
 }  // namespace wssdl

@@ -171,14 +171,22 @@ struct LaneVec<2> {
     }
 };
 
+// I32 (round 4): the same kernel with the reference op's own second output, `argmax` [R,PH,PW,C] i32 = the flat NHWC
+// index inside the RoI's image, -1 for an empty bin (roi_pooling_op.cc:31-52, roi_pooling_op_gpu.cu.cc:71-79): the
+// running arg-max is then the cell index h * W + w (no window-relative code, so any window size is fine and
+// nothing can overflow), turned into (cell * C + channel) at the store.  N <= 0 means "batch size unknown": the
+// reference's ROIPoolForwardLaucher is not told it (roi_pooling_op_gpu.h:18-22), so only a negative batch
+// index makes a RoI empty.
 template <int CPL, int RPW /* waves per workgroup */, int PWS /* PW when known at compile time, else 0 */,
           bool WHOLE_ROI /* a wave walks all PH bin rows of one RoI instead of one bin row */,
-          bool TAB /* the windows come from the table of roi_windows_kernel (PH = PWS = 7, one bin row per wave) */>
+          bool TAB /* the windows come from the table of roi_windows_kernel (PH = PWS = 7, one bin row per wave) */,
+          bool I32 = false /* i32 flat-index arg-max instead of the 1-byte codes */>
 __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
     const float *__restrict__ bottom, int N, int H, int W, int C, const float *__restrict__ rois,
     int R, int PH, int PW, float scale, int rounding, float *__restrict__ top,
     unsigned char *__restrict__ arg8, int *__restrict__ overflow, int slices,
     const unsigned *__restrict__ table /* window table (7 x 7 bins, one bin row per wave) or NULL */) {
+    constexpr unsigned EMPTY = I32 ? 0xffffffffu : ARG8_EMPTY;
     typedef typename LaneVec<CPL>::vec vec;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -237,11 +245,11 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
         const unsigned long long tall = __ballot(lane < PH && lane >= ph_first && lane < ph_last && my_he - my_hs > ARG8_MAX_WIN_H);
         const unsigned long long cols = __ballot(lane < PW && my_we > my_ws);
         const unsigned long long rows_live = __ballot(lane < PH && lane >= ph_first && lane < ph_last && my_he > my_hs);
-        const bool bad0 = batch < 0 || batch >= N;
-        if (overflow && !bad0 && lane == 0 && ((wide != 0ull && rows_live != 0ull) || (tall != 0ull && cols != 0ull)))
+        const bool bad0 = batch < 0 || (N > 0 && batch >= N);
+        if (!I32 && overflow && !bad0 && lane == 0 && ((wide != 0ull && rows_live != 0ull) || (tall != 0ull && cols != 0ull)))
             atomicOr(overflow, 1);
     }
-    const bool bad = batch < 0 || batch >= N;
+    const bool bad = batch < 0 || (N > 0 && batch >= N);
     const int c0 = (slice * 64 + lane) * CPL;
     const bool lane_ok = c0 < C;
     const int voff = (lane_ok ? c0 : 0) * 4;
@@ -258,16 +266,16 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
     auto pool_bin = [&](int ws, int we, vec &mv, unsigned (&mi)[CPL]) {
         const bool empty = row_dead || (we <= ws);
 #pragma unroll
-        for (int k = 0; k < CPL; ++k) { mv[k] = empty ? 0.0f : -FLT_MAX;  mi[k] = ARG8_EMPTY; }
+        for (int k = 0; k < CPL; ++k) { mv[k] = empty ? 0.0f : -FLT_MAX;  mi[k] = EMPTY; }
         if (empty) return;
         for (int h = hs; h < he; ++h) {
             const int so_row = h * W * cell_bytes;
-            const unsigned rcode = (unsigned)(h - hs) << 4;
+            const unsigned rcode = I32 ? (unsigned)(h * W + ws) : (unsigned)(h - hs) << 4;      // code of (h, ws)
             int w = ws;
             for (; w + 1 < we; w += 2) {          // two cells in flight
                 const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
                 const vec v1 = LaneVec<CPL>::load(rs, voff, so_row + (w + 1) * cell_bytes);
-                const unsigned code0 = rcode | (unsigned)(w - ws), code1 = code0 + 1u;
+                const unsigned code0 = rcode + (unsigned)(w - ws), code1 = code0 + 1u;
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) if (v0[k] > mv[k]) { mv[k] = v0[k];  mi[k] = code0; }
 #pragma unroll
@@ -275,23 +283,31 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
             }
             if (w < we) {
                 const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
-                const unsigned code0 = rcode | (unsigned)(w - ws);
+                const unsigned code0 = rcode + (unsigned)(w - ws);
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) if (v0[k] > mv[k]) { mv[k] = v0[k];  mi[k] = code0; }
             }
         }
     };
-    auto store_bin = [&](int pw, const vec &mv, unsigned codes) {
+    auto store_bin = [&](int pw, const vec &mv, const unsigned (&m)[CPL]) {
         const size_t o = o_row + (size_t)pw * C;
         if (lane_ok)
         {
             __builtin_nontemporal_store(mv, reinterpret_cast<vec *>(top + o));
-            if (CPL == 4) __builtin_nontemporal_store(codes, reinterpret_cast<unsigned *>(arg8 + o));
-            else __builtin_nontemporal_store((unsigned short)codes, reinterpret_cast<unsigned short *>(arg8 + o));
+            if constexpr (I32) {
+                // cell index -> flat NHWC index of the lane's channels (roi_pooling_op_gpu.cu.cc:71-79), -1 = empty
+                typedef int ivec __attribute__((ext_vector_type(CPL)));
+                ivec idx;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) idx[k] = m[k] == EMPTY ? -1 : (int)(m[k] * (unsigned)C) + c0 + k;
+                __builtin_nontemporal_store(idx, reinterpret_cast<ivec *>(reinterpret_cast<int *>(arg8) + o));
+            } else {
+                const unsigned codes = (CPL == 4) ? (m[0] | (m[1] << 8) | (m[2 % CPL] << 16) | (m[3 % CPL] << 24))
+                                                  : (m[0] | (m[1] << 8));
+                if (CPL == 4) __builtin_nontemporal_store(codes, reinterpret_cast<unsigned *>(arg8 + o));
+                else __builtin_nontemporal_store((unsigned short)codes, reinterpret_cast<unsigned short *>(arg8 + o));
+            }
         }
-    };
-    auto pack = [](const unsigned (&mi)[CPL]) -> unsigned {
-        return (CPL == 4) ? (mi[0] | (mi[1] << 8) | (mi[2 % CPL] << 16) | (mi[3 % CPL] << 24)) : (mi[0] | (mi[1] << 8));
     };
     if constexpr (PWS > 0) {
         // PW known at compile time: the bin row is walked ROW BY ROW through all its bins, with the
@@ -320,7 +336,7 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
             }
             const bool empty = row_dead || (wes[pw] <= wss[pw]);
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) { res[pw][k] = empty ? 0.0f : -FLT_MAX;  mi[pw][k] = ARG8_EMPTY; }
+            for (int k = 0; k < CPL; ++k) { res[pw][k] = empty ? 0.0f : -FLT_MAX;  mi[pw][k] = EMPTY; }
         }
         auto upd = [](vec &mv, unsigned (&m)[CPL], const vec &v, unsigned code) {
 #pragma unroll
@@ -329,26 +345,27 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
         if (!row_dead) {
             for (int h = hs; h < he; ++h) {
                 const int so_row = h * W * cell_bytes;
-                const unsigned rcode = (unsigned)(h - hs) << 4;
+                const unsigned rcode0 = I32 ? (unsigned)(h * W) : (unsigned)(h - hs) << 4;
                 vec carry = (vec)(0.0f);          // cell (h, carry_w): the last one the previous bin loaded
                 int carry_w = -1;
 #pragma unroll
                 for (int pw = 0; pw < PWS; ++pw) {
                     const int ws = wss[pw], we = wes[pw];
                     if (we <= ws) continue;
+                    const unsigned rcode = I32 ? rcode0 + (unsigned)ws : rcode0;      // code of (h, ws)
                     int w = ws;
                     if (carry_w == ws) { upd(res[pw], mi[pw], carry, rcode);  w = ws + 1; }
                     for (; w + 1 < we; w += 2) {          // two cells in flight
                         const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
                         const vec v1 = LaneVec<CPL>::load(rs, voff, so_row + (w + 1) * cell_bytes);
-                        const unsigned code0 = rcode | (unsigned)(w - ws);
+                        const unsigned code0 = rcode + (unsigned)(w - ws);
                         upd(res[pw], mi[pw], v0, code0);
                         upd(res[pw], mi[pw], v1, code0 + 1u);
                         carry = v1;
                     }
                     if (w < we) {
                         const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
-                        upd(res[pw], mi[pw], v0, rcode | (unsigned)(w - ws));
+                        upd(res[pw], mi[pw], v0, rcode + (unsigned)(w - ws));
                         carry = v0;
                     }
                     carry_w = we - 1;
@@ -356,13 +373,13 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
             }
         }
 #pragma unroll
-        for (int pw = 0; pw < PWS; ++pw) store_bin(pw, res[pw], pack(mi[pw]));
+        for (int pw = 0; pw < PWS; ++pw) store_bin(pw, res[pw], mi[pw]);
     } else {
         for (int pw = 0; pw < PW; ++pw) {
             vec mv;
             unsigned mi[CPL];
             pool_bin(__builtin_amdgcn_readlane(my_ws, pw), __builtin_amdgcn_readlane(my_we, pw), mv, mi);
-            store_bin(pw, mv, pack(mi));
+            store_bin(pw, mv, mi);
         }
     }
     }
@@ -816,6 +833,36 @@ static int forward_compact(const float *bottom, int N, int H, int W, int C, cons
         hipLaunchKernelGGL(roi_pool_fwd_compact_kernel<1>, dim3((unsigned)(row_blocks * 8)), dim3(256), 0, st,
                            bottom, N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top, a8,
                            overflow, lanes_per_row, rows_per_block);
+    return check_launch();
+}
+
+// The wave-uniform forward with the reference op's i32 arg-max (wssdl_roi_pool_forward).  Returns
+// WSSDL_ROWS_I32_UNSUPPORTED when the shape is not one the kernel takes (the caller then runs the sliced kernel).
+int wssdl::launch_fwd_rows_i32(const float *bottom, int N, int H, int W, int C, const float *rois, int R, int pooled_h,
+                        int pooled_w, float spatial_scale, int rounding, float *top, int32_t *argmax, hipStream_t st) {
+    if (C % 128 != 0 || pooled_h > 64 || pooled_w > 64 || (long long)H * W * C * 4 >= 0x7fffffffLL)
+        return WSSDL_ROWS_I32_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(bottom) & 15) || (reinterpret_cast<uintptr_t>(top) & 15) ||
+        (reinterpret_cast<uintptr_t>(argmax) & 15))
+        return WSSDL_ROWS_I32_UNSUPPORTED;
+    // (a test-sized RoI list is latency-bound and faster on the sliced kernel, as on the 1-byte path)
+    if ((long long)R * pooled_h * cdiv(C, 256) < 32768) return WSSDL_ROWS_I32_UNSUPPORTED;
+    const int cpl = (C % 256 != 0) ? 2 : 4;
+    const int slices = cdiv(C, 64 * cpl);
+    if (!((slices >= 8 && slices % 8 == 0) || (slices < 8 && 8 % slices == 0))) return WSSDL_ROWS_I32_UNSUPPORTED;
+    const int rpw = 4;
+    const long long items = (long long)R * pooled_h;
+    const long long groups = (items + rpw - 1) / rpw;
+    const long long blocks = slices >= 8 ? groups * slices : 8 * ((groups + 8 / slices - 1) / (8 / slices));
+    if (blocks > 0x7fffffffLL) return WSSDL_ROWS_I32_UNSUPPORTED;
+    unsigned char *a = reinterpret_cast<unsigned char *>(argmax);
+#define WSSDL_FWD_I32(CPL, PWS) \
+    hipLaunchKernelGGL((roi_pool_fwd_rows_kernel<CPL, 4, PWS, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, \
+                       bottom, N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top, a, nullptr, slices, \
+                       nullptr)
+    if (cpl == 4) { if (pooled_w == 7) WSSDL_FWD_I32(4, 7); else WSSDL_FWD_I32(4, 0); }
+    else { if (pooled_w == 7) WSSDL_FWD_I32(2, 7); else WSSDL_FWD_I32(2, 0); }
+#undef WSSDL_FWD_I32
     return check_launch();
 }
 

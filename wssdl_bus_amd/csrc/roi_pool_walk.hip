@@ -336,8 +336,17 @@ struct SlotRec {                 // one record = 8 slots, wave-uniform (scalar r
 
 template <int CPL>
 struct SlotData {                // what a lane holds of one record
-    unsigned a[WALK_SLOTS];      // CPL 1-byte codes
+    unsigned a[WALK_SLOTS][2];   // [0]: CPL 1-byte codes; I32: the CPL flat indices in [0], [1]
     float td[WALK_SLOTS][CPL];   // CPL top_diff values
+};
+
+// I32 (round 4): the arg-max in the reference op's own layout (i32 flat NHWC index inside the image, -1 = empty
+// bin: roi_pooling_op_gpu.cu.cc:71-79) instead of the 1-byte codes -- wssdl_roi_pool_backward_ws.  A lane loads
+// CPL i32 values per slot; index -> cell by a shift (C is a power of two on this path), cell -> (h, w) by one
+// 24-bit multiply (exhaustively verified for every cell of the map on the host).
+struct WalkI32 {
+    int cshift;            // log2(C)
+    unsigned magic, shift; // cell / W = (cell * magic) >> shift
 };
 
 // a record is fetched by lanes 0..15 (one dword each) and broadcast with v_readlane: that keeps the
@@ -360,41 +369,67 @@ __device__ __forceinline__ SlotRec spread_rec(unsigned v, bool valid, unsigned t
     return r;
 }
 
-template <int CPL>
+template <int CPL, bool I32>
 __device__ __forceinline__ void issue_rec(SlotData<CPL> &d, const SlotRec &r, __amdgpu_buffer_rsrc_t ra,
                                           __amdgpu_buffer_rsrc_t rt, int voff8, int voff) {
 #pragma unroll
     for (int s = 0; s < WALK_SLOTS; ++s) {
-        if (CPL == 2) {
-            d.a[s] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(ra, voff8, (int)r.lo[s], 0);
+        if (I32) {
+            if (CPL == 2) {
+                typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+                const uint2v a = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(ra, voff, (int)(r.lo[s] << 2), 0));
+                d.a[s][0] = a.x;  d.a[s][1] = a.y;
+                const float2v t = __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(rt, voff, (int)(r.lo[s] << 2), 0));
+                d.td[s][0] = t.x;  d.td[s][CPL - 1] = t.y;
+            } else {
+                d.a[s][0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ra, voff, (int)(r.lo[s] << 2), 0);
+                d.td[s][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, voff, (int)(r.lo[s] << 2), 0));
+            }
+        } else if (CPL == 2) {
+            d.a[s][0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(ra, voff8, (int)r.lo[s], 0);
             const float2v t = __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(rt, voff, (int)(r.lo[s] << 2), 0));
             d.td[s][0] = t.x;  d.td[s][CPL - 1] = t.y;
         } else {
-            d.a[s] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(ra, voff8, (int)r.lo[s], 0);
+            d.a[s][0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(ra, voff8, (int)r.lo[s], 0);
             d.td[s][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, voff, (int)(r.lo[s] << 2), 0));
         }
     }
 }
 
-template <int TH, int TW, int CPL>
-__device__ __forceinline__ void process_rec(const SlotData<CPL> &d, const SlotRec &r, float *acc, int lane, bool lane_ok) {
+template <int TH, int TW, int CPL, bool I32>
+__device__ __forceinline__ void process_rec(const SlotData<CPL> &d, const SlotRec &r, float *acc, int lane, bool lane_ok,
+                                            const WalkI32 &q, int h0, int w0, int W) {
     constexpr int DUMMY = TH * TW;
 #pragma unroll
     for (int s = 0; s < WALK_SLOTS; ++s) {
         const unsigned w = r.hi[s];
         const unsigned rm = w & 0xffu, cm = (w >> 8) & 0xffu;
         const int hs = ((int)(w << 11)) >> 27, ws = ((int)(w << 6)) >> 27;     // sign-extended 5-bit fields
-        const unsigned a = d.a[s];
+        const unsigned a = d.a[s][0];
         int idx[CPL];
         float val[CPL];
 #pragma unroll
         for (int p = 0; p < CPL; ++p) {
-            const unsigned code = (a >> (8 * p)) & 0xffu;
-            const int th = hs + (int)(code >> 4), tw = ws + (int)(code & 15u);
+            int th, tw;
+            bool live;
+            if (I32) {
+                // flat index -> cell -> (h, w); -1 (empty bin) and anything outside the tile fail the range tests
+                const int fi = (int)d.a[s][p];
+                const unsigned cellg = (unsigned)fi >> q.cshift;
+                const unsigned hh = __umul24(cellg, q.magic) >> q.shift;
+                th = (int)hh - h0;
+                tw = (int)(cellg - hh * (unsigned)W) - w0;
+                live = (fi >= 0) & ((unsigned)th < (unsigned)TH) & ((unsigned)tw < (unsigned)TW);
+            } else {
+                const unsigned code = (a >> (8 * p)) & 0xffu;
+                th = hs + (int)(code >> 4);
+                tw = ws + (int)(code & 15u);
+                live = code != ARG8_EMPTY_W;
+            }
             // tile, in_roi and candidate-bin tests: the masks have no bits where a cell outside the
             // tile would index (th, tw in [-16, 30]; shifts use the low 5 bits)
             const unsigned bits = (rm >> (th & 31)) & (cm >> (tw & 31)) & 1u;
-            const bool ok = (bits != 0u) & (code != ARG8_EMPTY_W) & lane_ok;
+            const bool ok = (bits != 0u) & live & lane_ok;
             const int cell = ok ? th * TW + tw : DUMMY;
             idx[p] = (cell * CPL + p) * 64 + lane;
             val[p] = ok ? d.td[s][p] : 0.0f;
@@ -407,13 +442,13 @@ __device__ __forceinline__ void process_rec(const SlotData<CPL> &d, const SlotRe
     }
 }
 
-template <int TH, int TW, int DEPTH, int MINW, int CPL>
+template <int TH, int TW, int DEPTH, int MINW, int CPL, bool I32>
 __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
-    const float *__restrict__ top_diff, const unsigned char *__restrict__ arg8,
+    const float *__restrict__ top_diff, const unsigned char *__restrict__ arg8 /* I32: the i32 arg-max */,
     const unsigned *__restrict__ slots, const int *__restrict__ tile_off, const int *__restrict__ tile_slots,
     const int *__restrict__ order, int items, int tiles_w, int tiles, int G, int H, int W, int C,
     unsigned total_elems, float *__restrict__ bottom_diff, int nseg, float *__restrict__ partial,
-    unsigned long long seg_stride) {
+    unsigned long long seg_stride, WalkI32 q) {
     static_assert(TH <= 8 && TW <= 8 && DEPTH >= 2 && DEPTH <= 4, "8-bit masks; 2..4 records in flight");
     __shared__ float acc[(TH * TW + 1) * CPL * 64];
     // blockIdx -> (position k in the launch order, channel group g).  Workgroups are dealt
@@ -459,7 +494,7 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
     const int nrec = rec1 - rec0;
     const unsigned *rp = slots + ((size_t)tile_off[item] + rec0) * 16;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char *>(arg8), 0, (int)total_elems, 0x00020000);
+        const_cast<unsigned char *>(arg8), 0, (int)(I32 ? total_elems << 2 : total_elems), 0x00020000);
     const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(top_diff), 0, (int)(total_elems << 2), 0x00020000);
     const int voff8 = cl, voff = cl * 4;
@@ -471,7 +506,7 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
 #pragma unroll
     for (int j = 0; j < DEPTH - 1; ++j) {
         r[j] = spread_rec(fetch_rec(rp, j, nrec, lane), j < nrec, total_elems);
-        issue_rec(d[j], r[j], ra, rt, voff8, voff);
+        issue_rec<CPL, I32>(d[j], r[j], ra, rt, voff8, voff);
     }
     unsigned pending = fetch_rec(rp, DEPTH - 1, nrec, lane);
     for (int i = 0; i < nrec; i += DEPTH) {
@@ -480,8 +515,8 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
             const int x = (j + DEPTH - 1) % DEPTH;
             const unsigned next = fetch_rec(rp, i + j + DEPTH, nrec, lane);
             r[x] = spread_rec(pending, i + j + DEPTH - 1 < nrec, total_elems);
-            issue_rec(d[x], r[x], ra, rt, voff8, voff);
-            process_rec<TH, TW, CPL>(d[j], r[j], acc, lane, lane_ok);
+            issue_rec<CPL, I32>(d[x], r[x], ra, rt, voff8, voff);
+            process_rec<TH, TW, CPL, I32>(d[j], r[j], acc, lane, lane_ok, q, h0, w0, W);
             pending = next;
         }
     }
@@ -661,10 +696,34 @@ __global__ __launch_bounds__(256) void walk_combine_kernel(float *__restrict__ b
     reinterpret_cast<float4v *>(bottom_diff)[i] = o;
 }
 
-template <int TH, int TW, int DEPTH, int MINW, int CPL>
+// cell / W by one 24-bit multiply for every cell of the map (as in roi_pool.hip: launch_bwd), C = 2^cshift
+static bool walk_i32_params(int H, int W, int C, WalkI32 *q) {
+    int cshift = 0;
+    while ((1 << cshift) < C) ++cshift;
+    if ((1 << cshift) != C || (long long)H * W >= (1 << 16)) return false;
+    const unsigned cells = (unsigned)H * (unsigned)W;
+    for (unsigned sft = 8; sft <= 24; ++sft) {
+        const unsigned long long mg = ((1ULL << sft) + (unsigned)W - 1) / (unsigned)W;
+        if (mg >= (1ULL << 24) || mg * (cells ? cells - 1 : 0) >= (1ULL << 32)) continue;
+        bool exact = true;
+        for (unsigned n = 0; n < cells && exact; ++n) exact = (unsigned)((n * mg) >> sft) == n / (unsigned)W;
+        if (exact) {
+            q->cshift = cshift;  q->magic = (unsigned)mg;  q->shift = sft;
+            return true;
+        }
+    }
+    return false;
+}
+
+bool walk_i32_supported(int R, int N, int H, int W, int C, int PH, int PW) {
+    WalkI32 q;
+    return walk_supported(R, N, H, W, C, PH, PW) && walk_i32_params(H, W, C, &q);
+}
+
+template <int ID, int TH, int TW, int DEPTH, int MINW, int CPL>
 static int launch_walk_t(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C,
                          int PH, int PW, float *bottom_diff, void *workspace, size_t workspace_bytes,
-                         hipStream_t st, int nseg, float *partial) {
+                         hipStream_t st, int nseg, float *partial, bool i32) {
     const int tiles_h = cdiv(H, TH), tiles_w = cdiv(W, TW), tiles = tiles_h * tiles_w;
     const int items = N * tiles;
     WalkWs ws;
@@ -678,9 +737,21 @@ static int launch_walk_t(const float *top_diff, const unsigned char *arg8, int R
     else blocks = (long long)items * G;
     if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
     const unsigned long long seg_stride = (unsigned long long)N * H * W * C;
-    hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<TH, TW, DEPTH, MINW, CPL>), dim3((unsigned)blocks, (unsigned)nseg), dim3(64),
+    WalkI32 q = {0, 0u, 0u};
+    // (the i32 form is only built for the plans walk_plan_auto can pick)
+    constexpr bool I32_BUILT = ID == 11 || ID == 5 || ID == 23 || ID == 18 || ID == 22 || ID == 19 || ID == 21;
+    if (i32 && !I32_BUILT) return WSSDL_ERR_INVALID_ARGUMENT;
+    if constexpr (I32_BUILT) if (i32) {
+        if (!walk_i32_params(H, W, C, &q)) return WSSDL_ERR_INVALID_ARGUMENT;
+        hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<TH, TW, DEPTH, MINW, CPL, true>), dim3((unsigned)blocks, (unsigned)nseg),
+                           dim3(64), 0, st, top_diff, arg8, reinterpret_cast<const unsigned *>(ws.slots), ws.tile_off,
+                           ws.tile_slots, ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff, nseg, partial,
+                           seg_stride, q);
+    }
+    if (!i32)
+    hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<TH, TW, DEPTH, MINW, CPL, false>), dim3((unsigned)blocks, (unsigned)nseg), dim3(64),
                        0, st, top_diff, arg8, reinterpret_cast<const unsigned *>(ws.slots), ws.tile_off, ws.tile_slots,
-                       ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff, nseg, partial, seg_stride);
+                       ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff, nseg, partial, seg_stride, q);
     if (nseg > 1) {
         const long long n4 = (long long)(seg_stride / 4);          // C is even and walk_split_supported asks C % 4 == 0
         hipLaunchKernelGGL(walk_combine_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, bottom_diff, partial, n4,
@@ -691,12 +762,12 @@ static int launch_walk_t(const float *top_diff, const unsigned char *arg8, int R
 
 int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH,
                 int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, hipStream_t st,
-                int nseg, float *partial) {
+                int nseg, float *partial, bool i32) {
     if (nseg < 1 || nseg > WALK_MAX_SEGMENTS || (nseg > 1 && (!partial || (C & 3)))) return WSSDL_ERR_INVALID_ARGUMENT;
     switch (plan) {
 #define WSSDL_X(ID, TH, TW, D, MW, CPL) \
-        case ID: return launch_walk_t<TH, TW, D, MW, CPL>(top_diff, arg8, R, N, H, W, C, PH, PW, bottom_diff, workspace, \
-                                                         workspace_bytes, st, nseg, partial);
+        case ID: return launch_walk_t<ID, TH, TW, D, MW, CPL>(top_diff, arg8, R, N, H, W, C, PH, PW, bottom_diff, workspace, \
+                                                         workspace_bytes, st, nseg, partial, i32);
         WSSDL_WALK_PLANS(WSSDL_X)
 #undef WSSDL_X
         default: return WSSDL_ERR_INVALID_ARGUMENT;

@@ -70,11 +70,17 @@ def roi_pool_grad(bottom_data, bottom_rois, argmax, grad, pooled_height, pooled_
         raise ValueError("out_backprop must be 4-dimensional")
     N, H, W, C = shape
     out = torch.empty(shape, dtype=torch.float32, device=g.device)
-    with torch.cuda.device(g.device), _lib.timed("roi_pool_backward", dict(N=N, H=H, W=W, C=C, R=rois.shape[0])):
-        _lib.check(_lib.lib().wssdl_roi_pool_backward(
-            _lib.ptr(g), _lib.ptr(arg), _lib.ptr(rois), rois.shape[0], N, H, W, C,
-            int(pooled_height), int(pooled_width), float(spatial_scale), _lib.ptr(out),
-            _lib.stream()), "wssdl_roi_pool_backward")
+    L = _lib.lib()
+    with torch.cuda.device(g.device):
+        # the list-driven kernels read the i32 arg-max too when they get a workspace for their lists
+        # (wssdl_roi_pool_backward_ws; shapes they do not take run the kernel of wssdl_roi_pool_backward)
+        nws = L.wssdl_roi_pool_backward_workspace_bytes(rois.shape[0], N, H, W, int(pooled_height), int(pooled_width))
+        ws = torch.empty((nws,), dtype=torch.uint8, device=g.device) if nws else None
+        with _lib.timed("roi_pool_backward", dict(N=N, H=H, W=W, C=C, R=rois.shape[0])):
+            _lib.check(L.wssdl_roi_pool_backward_ws(
+                _lib.ptr(g), _lib.ptr(arg), _lib.ptr(rois), rois.shape[0], N, H, W, C,
+                int(pooled_height), int(pooled_width), float(spatial_scale), _lib.ptr(out), _lib.ptr(ws), nws,
+                _lib.stream()), "wssdl_roi_pool_backward_ws")
     return out.cpu().numpy() if as_np else out
 
 
