@@ -258,7 +258,7 @@ WSSDL_API int wssdl_roi_targets(const float *rois, const int32_t *keep, const ui
 /* ---------------------------------------------------------------- a11, a12 ---
  * RoiPool forward: roi_pooling_op.cc:31-52 (op), kernels roi_pooling_op_gpu.cu.cc:20-85
  * (rounding CUDA) / roi_pooling_op.cc:137-196 (rounding CPU).  N <= 0 = "batch size unknown": the
- * reference's ROIPoolForwardLaucher is not told it (roi_pooling_op_gpu.h:18-22) and never range-checks
+ * reference's ROIPoolForwardLaucher is not told it (roi_pooling_op_gpu.h:17-21) and never range-checks
  * rois[:, 0]; then only a negative batch index makes a RoI empty (with N > 0 an index >= N does too).
  * bottom [N,H,W,C] f32, rois [R,5] f32, top [R,PH,PW,C] f32, argmax [R,PH,PW,C] i32
  * (flat NHWC index within the roi's image, -1 for an empty bin). */
@@ -352,9 +352,13 @@ WSSDL_API int wssdl_roi_pool_backward_compact(const float *top_diff, const uint8
  * result on every run, every element within 1e-6 of ..._backward_compact relative to its own sum of |terms|
  * (measured ~2e-8) and the tensor within 1e-5 of its scale (north_star's tolerance for RoI pooling), not
  * bit-identical to it.  segments = 1 is the exact walk.
- * wssdl_roi_pool_backward_split_segments suggests a count by launch shape (1 = keep the exact walk: more than
- * 4 images, or fewer than 1000 RoIs per image); same plan / workspace as ..._backward_compact. */
+ * wssdl_roi_pool_backward_split_segments suggests a count by launch shape (8, or 1 = keep the exact walk: more
+ * than 4 images, fewer than 1000 RoIs per image, or 2048 and more (image, channel) pairs -- enough waves that the
+ * chains no longer bind); wssdl_roi_pool_backward_split_plan = the plan to prepare the lists with for the split form
+ * (set "roi_bwd_plan" to it around ..._backward_prepare: large tiles, since the chains no longer matter); same
+ * workspace as ..._backward_compact. */
 WSSDL_API int wssdl_roi_pool_backward_split_segments(int R, int N, int H, int W, int C);
+WSSDL_API int wssdl_roi_pool_backward_split_plan(void);
 WSSDL_API size_t wssdl_roi_pool_backward_split_scratch_bytes(int N, int H, int W, int C, int segments);
 WSSDL_API int wssdl_roi_pool_backward_compact_split(const float *top_diff, const uint8_t *argmax8,
                             const float *rois, int R, int N, int H, int W, int C, int pooled_h,

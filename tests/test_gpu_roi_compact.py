@@ -279,8 +279,9 @@ def test_split_walk_is_deterministic_and_within_1e6_of_the_oracle(torch_cuda):
     from wssdl_bus_amd.fast_rcnn.config import cfg
     from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
     L = _lib.lib()
-    assert L.wssdl_roi_pool_backward_split_segments(4128, 3, 37, 62, 512) == 4        # VGG-16, 1 + 2 images
-    assert L.wssdl_roi_pool_backward_split_segments(4000, 2, 38, 63, 1024) == 4       # alternating mode, weak step
+    assert L.wssdl_roi_pool_backward_split_segments(4128, 3, 37, 62, 512) == 8        # VGG-16, 1 + 2 images
+    assert L.wssdl_roi_pool_backward_split_segments(2000, 1, 38, 63, 1024) == 8       # one weak image
+    assert L.wssdl_roi_pool_backward_split_segments(4000, 2, 38, 63, 1024) == 1       # alternating weak step: enough waves
     assert L.wssdl_roi_pool_backward_split_segments(8512, 8, 38, 63, 1024) == 1       # the default workload: exact walk
     assert L.wssdl_roi_pool_backward_split_segments(256, 2, 38, 63, 256) == 1
     assert L.wssdl_roi_pool_backward_split_scratch_bytes(3, 37, 62, 512, 4) == 3 * 3 * 37 * 62 * 512 * 4
@@ -319,8 +320,8 @@ def test_split_walk_is_deterministic_and_within_1e6_of_the_oracle(torch_cuda):
             assert np.all(np.abs(a - want_g) <= 1e-6 * mag + 1e-30), (plan_id, K, float((np.abs(a - want_g) / (mag + 1e-30)).max()))
             assert np.abs(a - want_g).max() <= 1e-5 * scale, (plan_id, K)
     assert not op.flags_raised()
-    # the autograd pair: 'auto' takes the library's suggestion (4 here: 2 images x 1200 RoIs), 0 the exact walk
-    assert cfg.ROI_POOL_BWD_SPLIT == "auto" and op.split_segments((N, H, W, C), R) == 4
+    # the autograd pair: 'auto' takes the library's suggestion (8 here: 2 images x 1200 RoIs x 128 channels), 0 the exact walk
+    assert cfg.ROI_POOL_BWD_SPLIT == "auto" and op.split_segments((N, H, W, C), R) == 8
     for split, exact_bits in (("auto", False), (0, True)):
         cfg.ROI_POOL_BWD_SPLIT = split
         try:

@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--map", default="38,63", help="feature-map height,width")
     ap.add_argument("--segments", default="1", help="segments of the split walk to time per plan, e.g. 1,2,4,8 (1 = the "
                     "exact walk; > 1 is compared with it by the largest difference relative to max |bottom_diff|)")
+    ap.add_argument("--i32", action="store_true", help="time wssdl_roi_pool_backward_ws (i32 arg-max, prepare + walk in "
+                    "one call) per plan instead of the 1-byte pair; checked against the tile-owner kernel's result")
     ap.add_argument("--denormals", action="store_true",
                     help="scale top_diff so that sums pass through the f32 denormal range (checks that every plan, "
                          "the ds_add_f32 ones included, still equals plan 11 bit for bit)")
@@ -81,6 +83,25 @@ def main():
         assert plan.plan == plan_id
         return plan
 
+    if args.i32:
+        top, arg = op.roi_pool(feat, rois, 7, 7, 1.0 / 16)
+        del top
+        ref = torch.empty(shape, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        _lib.check(L.wssdl_roi_pool_backward(_lib.ptr(diff), _lib.ptr(arg), _lib.ptr(rois), R, N, H, W, C, 7, 7, 1.0 / 16,
+                                             _lib.ptr(ref), _lib.stream()), "wssdl_roi_pool_backward")
+        ab = R * 49 * C * 8 + N * H * W * C * 4
+        for p in ["auto"] + [int(x) for x in args.plans.split(",")]:
+            _lib.set_tuning("roi_bwd_plan", -1 if p == "auto" else p)
+            got = op.roi_pool_grad(feat, rois, arg, diff, 7, 7, 1.0 / 16)
+            same = bool(torch.equal(got, ref))
+            del got
+            ms = timeit(lambda: op.roi_pool_grad(feat, rois, arg, diff, 7, 7, 1.0 / 16), args.iters)
+            print(json.dumps(dict(i32=True, plan=p, prepare_plus_walk_ms=round(ms, 4), equal_to_tile_owner_kernel=same,
+                                  alg8d_TBps=round(ab / ms / 1e9, 3), frac_8d=round(ab / ms / 1e9 / 8.0, 3))), flush=True)
+            assert same, p
+        _lib.set_tuning("roi_bwd_plan", -1)
+        return
     if args.one:
         plan = run(int(args.one))
         for _ in range(5):

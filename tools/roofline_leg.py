@@ -85,13 +85,13 @@ def run(rois_np, N, H, W, C, iters=20, warmup=3, seed=3):
         else:
             top, arg = op.roi_pool(feat, rois, 7, 7, 1.0 / 16)
         diff = torch.randn(top.shape, device=dev, generator=g)
-        plan = op.roi_pool_grad_prepare(shape, rois, 7, 7, 1.0 / 16) if compact else None
         segs = op.split_segments(shape, R) if compact else 1
+        plan = op.roi_pool_grad_prepare(shape, rois, 7, 7, 1.0 / 16, segments=segs) if compact else None
 
         def one():
             if compact:
                 op.roi_pool_compact(feat, rois, 7, 7, 1.0 / 16)
-                p = op.roi_pool_grad_prepare(shape, rois, 7, 7, 1.0 / 16)
+                p = op.roi_pool_grad_prepare(shape, rois, 7, 7, 1.0 / 16, segments=segs)
                 return op.roi_pool_grad_compact(shape, rois, arg, diff, 7, 7, 1.0 / 16, plan=p, segments=segs)
             op.roi_pool(feat, rois, 7, 7, 1.0 / 16)
             return op.roi_pool_grad(feat, rois, arg, diff, 7, 7, 1.0 / 16)

@@ -68,6 +68,7 @@ SYMBOLS = {
     "wssdl_roi_pool_backward_compact": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _i,
                                              _vp]),
     "wssdl_roi_pool_backward_split_segments": (_i, [_i, _i, _i, _i, _i]),
+    "wssdl_roi_pool_backward_split_plan": (_i, []),
     "wssdl_roi_pool_backward_split_scratch_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "wssdl_roi_pool_backward_compact_split": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _i, _i,
                                                    _vp, _sz, _vp]),

@@ -525,7 +525,7 @@ extern "C" int wssdl_roi_pool_forward(const float *bottom, int N, int H, int W, 
     if (R == 0) return WSSDL_OK;
     if (!bottom || !rois || !top || !argmax) return WSSDL_ERR_INVALID_ARGUMENT;
     // N <= 0: the batch size is unknown -- the reference's ROIPoolForwardLaucher is not told it
-    // (roi_pooling_op_gpu.h:18-22) and never range-checks the batch index -- so only a negative index
+    // (roi_pooling_op_gpu.h:17-21) and never range-checks the batch index -- so only a negative index
     // makes a RoI empty here; with N > 0 an index >= N does too.
     if (N <= 0) N = 0x7fffffff;
     hipStream_t st = as_stream(stream);
@@ -582,9 +582,13 @@ extern "C" int wssdl_roi_pool_backward_ws(const float *top_diff, const int32_t *
         workspace_bytes >= walk_workspace_bytes(R, N, H, W, pooled_h, pooled_w)) {
         hipStream_t st = as_stream(stream);
         int plan = -1;
+        // 8 bytes per element instead of 5: the train-sized launch is even more bandwidth-bound than on the 1-byte
+        // path and wants the larger 6x8 tiles (fewer border re-reads): 0.83 against 0.87 ms at R = 8512 x 1024
+        // channels (tools/bwd_fixed_sweep.py --i32); "roi_bwd_plan" still overrides
+        const int force = (tuning().roi_bwd_plan < 0 && walk_plan_auto_id(N, H, W, C) == 11) ? 9 : -1;
         // (the window starts the lists also carry are not read on this path: the rounding mode does not matter)
         int rc = walk_prepare(rois, R, N, H, W, C, pooled_h, pooled_w, spatial_scale, WSSDL_ROI_ROUND_CUDA, workspace,
-                              workspace_bytes, &plan, st);
+                              workspace_bytes, &plan, st, force);
         if (rc != WSSDL_OK) return rc;
         return launch_walk(top_diff, reinterpret_cast<const unsigned char *>(argmax), R, N, H, W, C, pooled_h, pooled_w,
                            bottom_diff, workspace, workspace_bytes, plan, st, 1, nullptr, true);

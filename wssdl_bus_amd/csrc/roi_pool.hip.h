@@ -103,7 +103,9 @@ size_t walk_flags_offset(int R, int N, int H, int W, int PH, int PW);
 bool walk_supported(int R, int N, int H, int W, int C, int PH, int PW);
 size_t walk_workspace_bytes(int R, int N, int H, int W, int PH, int PW);
 int walk_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, int PW, float scale, int rounding,
-                 void *workspace, size_t workspace_bytes, int *plan_out, hipStream_t st);
+                 void *workspace, size_t workspace_bytes, int *plan_out, hipStream_t st, int force_plan = -1);
+int walk_split_plan();
+int walk_plan_auto_id(int N, int H, int W, int C);
 int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH,
                 int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, hipStream_t st,
                 int nseg = 1, float *partial = nullptr, bool i32 = false /* arg8 points at the i32 arg-max */);

@@ -175,7 +175,7 @@ struct LaneVec<2> {
 // index inside the RoI's image, -1 for an empty bin (roi_pooling_op.cc:31-52, roi_pooling_op_gpu.cu.cc:71-79): the
 // running arg-max is then the cell index h * W + w (no window-relative code, so any window size is fine and
 // nothing can overflow), turned into (cell * C + channel) at the store.  N <= 0 means "batch size unknown": the
-// reference's ROIPoolForwardLaucher is not told it (roi_pooling_op_gpu.h:18-22), so only a negative batch
+// reference's ROIPoolForwardLaucher is not told it (roi_pooling_op_gpu.h:17-21), so only a negative batch
 // index makes a RoI empty.
 template <int CPL, int RPW /* waves per workgroup */, int PWS /* PW when known at compile time, else 0 */,
           bool WHOLE_ROI /* a wave walks all PH bin rows of one RoI instead of one bin row */,
@@ -917,6 +917,8 @@ extern "C" int wssdl_roi_pool_backward_prepare(const float *rois, int R, int N, 
 extern "C" int wssdl_roi_pool_backward_split_segments(int R, int N, int H, int W, int C) {
     return walk_split_segments(R, N, H, W, C);
 }
+
+extern "C" int wssdl_roi_pool_backward_split_plan(void) { return walk_split_plan(); }
 
 extern "C" size_t wssdl_roi_pool_backward_split_scratch_bytes(int N, int H, int W, int C, int segments) {
     if (segments <= 1 || N < 1 || H < 1 || W < 1 || C < 1) return 0;

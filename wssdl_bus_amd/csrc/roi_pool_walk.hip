@@ -603,6 +603,8 @@ static int walk_plan_auto(int N, int H, int W, int C) {
     return 21;
 }
 
+int walk_plan_auto_id(int N, int H, int W, int C) { return walk_plan_auto(N, H, W, C); }
+
 static int walk_plan_choice(int N, int H, int W, int C) {
     const int v = tuning().roi_bwd_plan;
     if (v >= 0 && v < WALK_PLANS) return v;
@@ -618,10 +620,18 @@ static int walk_plan_choice(int N, int H, int W, int C) {
 // (wssdl_roi_pool_backward_compact_split) and the exact walk stays the contract of ..._backward_compact.
 // Suggested only where it pays (extra traffic: (segments - 1) * 2 * N*H*W*C*4 bytes): at most 4 images and at
 // least 1000 RoIs per image (the weak images of the reference's default 1 + 2 batch and of the alternating mode).
+// Measured (tools/bwd_fixed_sweep.py, profiles/r04_split_walk_sweeps.log): VGG-16's own 1 + 2 set (R = 4128, C = 512,
+// RoIs of ~24 x 24 cells) exact 0.31-0.34 ms (any plan) -> 0.246 with 8 segments on 8x8 / 64-channel tiles (plan 7);
+// one 2000-RoI image x 1024 channels 0.186 -> 0.155; two such images x 1024 channels (the alternating mode's weak
+// step) are NOT chain-bound any more (exact 0.289 ms = 0.44 of peak on moved bytes, split 0.285-0.30): the rule asks
+// for fewer than 2048 (image, channel) pairs.  Beyond the chain the launch is bound by the bytes neighbouring tiles
+// re-read (windows of 4.4 x 4.5 cells against 8 x 8 tiles: 2 x), which no segment count changes.
 int walk_split_segments(int R, int N, int H, int W, int C) {
-    if (N < 1 || N > 4 || (C & 3) || (long long)R < 1000LL * N) return 1;
-    return 4;
+    if (N < 1 || N > 4 || (C & 3) || (long long)R < 1000LL * N || (long long)N * C >= 2048) return 1;
+    return 8;
 }
+// the plan the split form wants (chains no longer matter: larger tiles, fewer re-read bytes)
+int walk_split_plan() { return 7; }
 
 bool walk_supported(int R, int N, int H, int W, int C, int PH, int PW) {
     if (PH > 8 || PW > 8 || (C & 1)) return false;
@@ -668,8 +678,8 @@ static int prepare_t(const float *rois, int R, int N, int H, int W, int C, int P
 }
 
 int walk_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, int PW, float scale, int rounding,
-                 void *workspace, size_t workspace_bytes, int *plan_out, hipStream_t st) {
-    const int plan = walk_plan_choice(N, H, W, C);
+                 void *workspace, size_t workspace_bytes, int *plan_out, hipStream_t st, int force_plan) {
+    const int plan = (force_plan >= 0 && force_plan < WALK_PLANS) ? force_plan : walk_plan_choice(N, H, W, C);
     const WalkPlan &p = kWalkPlans[plan];
     int rc = WSSDL_ERR_INVALID_ARGUMENT;
 #define WSSDL_PREP(TH, TW) \
@@ -739,7 +749,8 @@ static int launch_walk_t(const float *top_diff, const unsigned char *arg8, int R
     const unsigned long long seg_stride = (unsigned long long)N * H * W * C;
     WalkI32 q = {0, 0u, 0u};
     // (the i32 form is only built for the plans walk_plan_auto can pick)
-    constexpr bool I32_BUILT = ID == 11 || ID == 5 || ID == 23 || ID == 18 || ID == 22 || ID == 19 || ID == 21;
+    constexpr bool I32_BUILT = ID == 11 || ID == 5 || ID == 23 || ID == 18 || ID == 22 || ID == 19 || ID == 21 ||
+                               ID == 9 || ID == 12 || ID == 17 || ID == 4 || ID == 13 || ID == 14;      // + candidates of the i32 plan sweep
     if (i32 && !I32_BUILT) return WSSDL_ERR_INVALID_ARGUMENT;
     if constexpr (I32_BUILT) if (i32) {
         if (!walk_i32_params(H, W, C, &q)) return WSSDL_ERR_INVALID_ARGUMENT;

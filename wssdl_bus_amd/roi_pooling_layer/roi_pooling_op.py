@@ -247,9 +247,13 @@ class BackwardPlan(object):
         self.workspace, self.nbytes, self.plan = workspace, nbytes, plan
 
 
-def roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scale, rounding=None):
+def roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scale, rounding=None, segments=1):
     """Build the lists that drive the compact backward.  They depend on the RoIs and the shapes
-    only, so the autograd pair does this right behind the forward (off the backward's path)."""
+    only, so the autograd pair does this right behind the forward (off the backward's path).
+    `segments` > 1 (the split form will walk them): the lists are built for the plan that form wants."""
+    if segments > 1 and _lib.get_tuning("roi_bwd_plan") < 0:
+        with _lib.tuned(roi_bwd_plan=int(_lib.lib().wssdl_roi_pool_backward_split_plan())):
+            return roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scale, rounding)
     N, H, W, C = shape
     mode = _ROUNDING[cfg.ROI_POOL_ROUNDING if rounding is None else rounding]
     L = _lib.lib()
@@ -271,7 +275,7 @@ def roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scal
 
 def split_segments(shape, R):
     """How many segments the list-driven backward cuts a tile's slot stream into for this launch:
-    cfg.ROI_POOL_BWD_SPLIT = 'auto' (the library's rule: few images with >= 1000 RoIs each -> 4), an int, or
+    cfg.ROI_POOL_BWD_SPLIT = 'auto' (the library's rule: few images with >= 1000 RoIs each -> 8), an int, or
     0 / 1 for the exact walk.  > 1 is deterministic but NOT bit-identical to the reference's summation order."""
     v = cfg.get("ROI_POOL_BWD_SPLIT", "auto")
     N, H, W, C = shape
@@ -357,7 +361,8 @@ class RoiPoolFunction(torch.autograd.Function):
             if data.requires_grad or bottom_data.requires_grad:
                 # the backward's lists depend on the RoIs only: build them now, behind the forward
                 ctx.plan = roi_pool_grad_prepare(tuple(data.shape), rois, pooled_height, pooled_width,
-                                                 spatial_scale, rounding)
+                                                 spatial_scale, rounding,
+                                                 segments=split_segments(tuple(data.shape), rois.shape[0]))
         else:
             top, arg = roi_pool(data, rois, pooled_height, pooled_width, spatial_scale,
                                 rounding=rounding)
