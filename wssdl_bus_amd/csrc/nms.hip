@@ -1253,7 +1253,9 @@ int launch_nms_two_pass(const float *boxes, int box_stride_img, const int *n_dev
     // (the sweeps hold one workgroup slot each -- one CU each, at 128 VGPRs -- for the whole launch and wait for
     // mask blocks that need the other slots: at most a quarter of the device's CUs, and never more than 64)
     if (probe >= n_max && tuning().nms_fused != 0 && nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) &&
-        n_max >= 2048 && n_max % 16 == 0 && n_images <= 64 && 4 * n_images <= device_cu_count())
+        n_max >= 2048 && n_max % 16 == 0 && n_images <= 64 && 4 * n_images <= device_cu_count() &&
+        ((reinterpret_cast<uintptr_t>(boxes) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(diag_t) |
+          reinterpret_cast<uintptr_t>(summ)) & 127) == 0)
         return launch_nms_fused(boxes, box_stride_img, n_dev, n_max, n_images, thresh, mask, diag_t, summ, max_keep,
                                 order, order_stride_img, keep, num_keep, rois_padded, st);
     if (probe >= n_max) {

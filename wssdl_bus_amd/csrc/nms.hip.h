@@ -25,9 +25,12 @@ int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int to
                      int *sorted_index, int *n_sorted, void *scratch, size_t scratch_bytes,
                      hipStream_t st);
 
-// The same result by one device-wide radix sort of all keys of all images (order_sort.hip): faster than the
-// ranking above whenever it applies (M <= 65 535).  `valid` [n_images] i32 pre-zeroed counters; scratch =
-// order_sort_scratch_bytes (may alias memory that is only written after the ordering).
+// The same result by sorted runs + cross ranks (order_sort.hip): every image's keys are cut into runs of 2048,
+// each run sorted by one workgroup (hand-written bitonic network, order_sort.hip.h), and a candidate's position is
+// its position in its run plus, for every other run of its image, the number of greater keys (binary searches);
+// faster than the ranking above whenever it applies: at most 64 runs per image (M <= 131 072).  `valid` is unused
+// (kept for the signature); scratch = order_sort_scratch_bytes (the sorted runs; may alias memory that is only
+// written after the ordering, e.g. the suppression matrix).
 bool order_sort_supported(int M, int n_images);
 size_t order_sort_scratch_bytes(int n_images, int M);
 int launch_order_sort(const unsigned long long *keys, int M, int n_images, int topn, int *sorted_index, int *n_sorted,
@@ -67,6 +70,10 @@ int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *d
 
 // mask + sweep in two passes (a probe over the first candidates, then the rest for the images that
 // need it); `done` [n_images] i32 scratch, NULL = one pass.  See nms.hip.
+// Alignment contract of the fused one-pass form (mask and sweep in one launch, the matrix handed over column
+// segment by column segment): no 128-byte line may hold words of two segments, so `boxes`, `mask`, `diag_t` and
+// `summ` must be 128-byte aligned (every workspace slice of Carver is 256-byte aligned) and n_max % 16 == 0;
+// launch_nms_two_pass checks both and runs the two-launch form otherwise.
 int nms_probe_size(int n_max, int max_keep);
 int launch_nms_two_pass(const float *boxes, int box_stride_img, const int *n_dev, int n_max, int n_images,
                         double thresh, unsigned long long *mask, unsigned long long *diag_t,
