@@ -74,7 +74,7 @@ def _worker_force_dist(port, q):
         state0 = copy.deepcopy(net.state_dict())
         blobs = synthetic.make_batch(1, 1, 320, 480, seed=21)
         outs = []
-        for kind in ("plain", "plain", "dist"):
+        for kind in ("plain", "plain", "plain", "plain", "dist"):
             _load(net, state0)
             ctx = None
             if kind == "dist":
@@ -91,10 +91,14 @@ def _worker_force_dist(port, q):
                 assert len(solver.overlap.buckets) >= 2
                 solver.overlap.remove()
                 ctx.shutdown()
-        a, a2, b = outs
+        plain, b = outs[:-1], outs[-1]
+        a = plain[0]
         moved = float((a[0] - _flat(torch, [state0[k] for k, _ in net.named_parameters()])).abs().max())
-        q.put(dict(ok=True, repeat=float((a[0] - a2[0]).abs().max()), dist=float((a[0] - b[0]).abs().max()),
-                   moved=moved, loss=(a[1], a2[1], b[1])))
+        # the plain step's own run-to-run noise (MIOpen's weight gradients use atomics): the largest difference
+        # among four repeats, and the data-parallel step against each of them
+        repeat = max(float((x[0] - y[0]).abs().max()) for i, x in enumerate(plain) for y in plain[i + 1:])
+        dist_d = min(float((x[0] - b[0]).abs().max()) for x in plain)
+        q.put(dict(ok=True, repeat=repeat, dist=dist_d, moved=moved, loss=(a[1], plain[1][1], b[1])))
     except Exception as e:                                   # surface the child's failure in the parent
         import traceback
         q.put(dict(ok=False, err=traceback.format_exc() + repr(e)))
@@ -116,10 +120,9 @@ def test_force_dist_single_rank_rccl_step_equals_plain_step():
     if res["repeat"] == 0.0:
         assert res["dist"] == 0.0, res                        # deterministic backward: bit-for-bit
     else:
-        # (the repeat's own difference is one sample of the backbone's atomic-order noise and can come out small:
-        # also accept anything within 5 % of the distance the step moved the parameters -- a lost or unscaled
-        # bucket shows up at that scale, 20 x above)
-        assert res["dist"] <= max(4 * res["repeat"], 0.05 * res["moved"]), res
+        # `repeat` is the largest difference among FOUR plain repeats (six pairs), `dist` the distance of the RCCL
+        # step to the nearest of them: a lost or unscaled bucket shows up at the scale of `moved`, orders above
+        assert res["dist"] <= 2 * res["repeat"], res
     assert abs(res["loss"][0] - res["loss"][2]) <= 4 * abs(res["loss"][0] - res["loss"][1]) + 1e-6
 
 
