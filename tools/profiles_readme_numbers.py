@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
 """Prints the numbers the "Reading them" paragraph of profiles/README.md quotes, from the committed
-profiles/r03_bench_* files (so that the paragraph can be checked, or refreshed, against the files)."""
+profiles/<tag>_bench_* files (so that the paragraph can be checked, or refreshed, against the files).
+
+    python3 tools/profiles_readme_numbers.py [tag]        (default r04)"""
 import csv
 import json
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def line(w):
-    return json.loads(open(os.path.join(P, "r03_bench_%s.json.log" % w)).read().strip().splitlines()[-1])
+    return json.loads(open(os.path.join(P, "%s_bench_%s.json.log" % (TAG, w))).read().strip().splitlines()[-1])
 
 
 def main():
@@ -18,13 +22,14 @@ def main():
     r = d["roofline"]
     fs = r["fixed_set"]
     ks = {}
-    for row in csv.DictReader(open(os.path.join(P, "r03_bench_resnet50_joint_b8_kernel_stats.csv"))):
+    for row in csv.DictReader(open(os.path.join(P, TAG + "_bench_resnet50_joint_b8_kernel_stats.csv"))):
         ks[row["Name"].split("(")[0].replace("void ", "").replace("wssdl::", "")] = float(row["MsPerStep"])
-    g = json.load(open(os.path.join(P, "r03_bench_resnet50_joint_b8_step_gaps.json")))
+    g = json.load(open(os.path.join(P, TAG + "_bench_resnet50_joint_b8_step_gaps.json")))
     print("default: %.1f images/s, %.1f ms/step, hot path %.3f ms (+ %.3f loss ops)" % (
         d["value"], d["ms_per_step"], d["hot_path"]["gpu_ms_per_step"], d["hot_path"]["loss_op_ms_per_step"]))
     print("roofline: backward %.4f ms frac %.3f frac_8d %.3f frac_traffic %.3f; forward %.4f ms" % (
-        fs["roi_pool_backward"]["avg_ms"], r["frac"], r["frac_8d"], r["frac_traffic"], fs["roi_pool_forward"]["avg_ms"]))
+        fs["roi_pool_backward"]["avg_ms"], r["frac"], r["frac_8d"], r["frac_traffic"] or float("nan"),
+        fs["roi_pool_forward"]["avg_ms"]))
     for prefix in ("roi_pool_fwd_rows", "roi_pool_bwd_walk", "nms_mask_sweep_fused", "proposal_decode_runs", "order_rank",
                    "roi_sample", "mtl_backward", "anchor_subsample"):
         print("  in-step %-24s %.4f ms" % (prefix, sum(v for n, v in ks.items() if n.startswith(prefix))))
