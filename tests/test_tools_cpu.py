@@ -64,3 +64,26 @@ def test_bench_byte_models_agree_with_the_roofline_leg():
         assert bench.alg_bytes(op, m) == roofline_leg.alg_bytes(op, **m)
         assert roofline_leg.alg_bytes(op, **m) - roofline_leg.moved_bytes(op, **m) == m["R"] * 49 * m["C"] * 3
     assert roofline_leg.moved_bytes("roi_pool_backward", **m) == 2213937152          # the figure in DESIGN.md / profiles
+
+
+def test_bare_bench_gpus_n_starts_the_launcher_before_torch(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it must start `python -m torch.distributed.run
+    --nproc-per-node 2 ... bench.py --gpus 2` as a child (and never initialise torch / HIP itself).  Without a GPU the
+    two ranks exit with bench.py's own "needs a GPU" message: the parent relays the non-zero exit code, prints no
+    JSON line, and the message proves that rank processes were started with RANK / WORLD_SIZE set."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    err = p.stderr.decode()
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:          # on a GPU box this form is covered by tests/test_gpu_distributed.py
+        return
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert "needs a GPU" in err and "torch.distributed" in err.replace("torchrun", "torch.distributed"), err[-1500:]
