@@ -91,3 +91,33 @@ def test_rotated_prep_path_is_float64_and_draws_the_angle_first():
     want = O.prep_im_pre_resize(gray, False, delta, factor, crop=crop, rotate_angle=angle)
     assert pre.dtype == np.float64 and np.array_equal(pre, want)
     assert im.shape[0] == 600 or im.shape[1] == 1000
+
+
+def test_against_an_independent_bilinear_with_constant_padding():
+    """A second implementation of "order-1 interpolation, constant padding that takes part in the interpolation":
+    scipy.ndimage.map_coordinates(order=1, mode='grid-constant') evaluated at the coordinates the restated resize /
+    rotate maps produce.  (scipy's plain 'constant' mode does NOT interpolate beyond the edge -- skimage's own
+    _warp_fast does, which is why its up-scaled borders fade; 'grid-constant' is the matching scipy mode.)  Agreement
+    to 1e-12 before the clip; the clip is the oracle's own."""
+    from scipy import ndimage
+    rs = np.random.RandomState(6)
+    img = rs.rand(23, 31) - 0.4
+    for shape in ((23, 31), (50, 61), (11, 9), (1, 31), (40, 1)):
+        M = O.skimage_resize_matrix(img.shape, shape)
+        x = np.arange(shape[1])[None, :] * np.ones((shape[0], 1))
+        y = np.arange(shape[0])[:, None] * np.ones((1, shape[1]))
+        cols = M[0, 0] * x + M[0, 1] * y + M[0, 2]
+        rows = M[1, 0] * x + M[1, 1] * y + M[1, 2]
+        ref = ndimage.map_coordinates(img, [rows, cols], order=1, mode="grid-constant", cval=0.0)
+        got = O.skimage_warp(img, M, shape, clip=False)
+        assert np.abs(got - ref).max() <= 1e-12, shape
+        assert np.array_equal(O.skimage_resize(img, shape), np.clip(got, img.min(), img.max()))
+    for angle, cval in ((7.5, 0.3), (-33.0, -0.2)):
+        M = O.skimage_rotate_matrix(img.shape, angle)
+        x = np.arange(31)[None, :] * np.ones((23, 1))
+        y = np.arange(23)[:, None] * np.ones((1, 31))
+        cols = M[0, 0] * x + M[0, 1] * y + M[0, 2]
+        rows = M[1, 0] * x + M[1, 1] * y + M[1, 2]
+        ref = ndimage.map_coordinates(img, [rows, cols], order=1, mode="grid-constant", cval=cval)
+        got = O.skimage_warp(img, M, img.shape, cval=cval, clip=False)
+        assert np.abs(got - ref).max() <= 1e-12, angle
