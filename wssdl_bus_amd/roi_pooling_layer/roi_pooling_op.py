@@ -144,7 +144,8 @@ class _DeviceFlags(object):
         if self.event is not None and self.event.query():
             self.event = None
             if int(self.host.abs().sum()) != 0:
-                self.flags.zero_()            # reported once: later polls start clean
+                # reported once: the bits this raise names are cleared, bits raised since the copy stay up
+                self.flags.bitwise_and_(torch.bitwise_not(self.host.clone().to(self.flags.device)))
             self._raise(self.host)
         if self.event is None:
             self.host.copy_(self.flags, non_blocking=True)
