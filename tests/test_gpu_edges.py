@@ -870,6 +870,31 @@ def test_fused_nms_time_out_is_reported_not_swallowed(torch_cuda):
     assert np.array_equal(proposal_layer(prob, pred, info, True, False), good)
 
 
+def test_deferred_flags_poll_raises_one_step_late_and_only_once(torch_cuda):
+    """roi_pooling_op.poll_flags (what SolverWrapper._apply calls before every optimiser step): no read-back -- a poll
+    starts an async copy of the flags, the NEXT poll looks at it -- so a raised flag surfaces one poll later, names its
+    cause, clears exactly the bits it reported and leaves later ones up."""
+    torch = torch_cuda
+    from wssdl_bus_amd import _lib
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as rp
+    rp.check_flags()
+    rp.poll_flags()
+    torch.cuda.synchronize()
+    rp.poll_flags()                                                   # nothing up: no raise
+    rp.note_roi_counts(torch.tensor([5, -1, 7], dtype=torch.int32, device="cuda"))
+    rp.poll_flags()                                                   # starts the copy that holds the flag
+    torch.cuda.synchronize()
+    rp._flags(torch.device("cuda", torch.cuda.current_device())).flags[0:1].fill_(1)      # a second flag, after the copy
+    with pytest.raises(_lib.HipCallError, match="NMS sweep"):
+        rp.poll_flags()
+    with pytest.raises(_lib.HipCallError, match="15 x 16"):            # the later flag was not wiped by the first report
+        rp.check_flags()
+    rp.poll_flags()
+    torch.cuda.synchronize()
+    rp.poll_flags()                                                   # clean again
+    rp.check_flags()
+
+
 def test_post_detections_device_op_edges(torch_cuda):
     """wssdl_post_detections (f3 as one C-ABI call) against the step-by-step form (which
     test_post_detection_nms_matches_oracle pins to the oracle) and against the oracle directly: more
