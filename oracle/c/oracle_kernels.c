@@ -91,7 +91,7 @@ int64_t orc_cpu_nms(const float *dets, int64_t n, const int64_t *order,
 /* follows code/lib/utils/nms.pyx:70-123 (`nms_new`; `nms` :17-68 of that file is line for line the
  * rule of cpu_nms.pyx, i.e. orc_cpu_nms).  ovr1 / ovr2 are not cdef'd there: the f32 quotients
  * inter / iarea and inter / areas[j] become Python floats and are compared with 0.95 in f64
- * (:116-118); a box is suppressed when `ovr >= thresh or ovr1 > 0.95 or ovr2 > 0.95`. */
+ * (:118-120); a box is suppressed when `ovr >= thresh or ovr1 > 0.95 or ovr2 > 0.95`. */
 int64_t orc_nms_new(const float *dets, int64_t n, const int64_t *order,
                     double thresh, int64_t *keep)
 {
@@ -139,7 +139,7 @@ static int64_t nms_greedy(const float *dets, int64_t n, const int64_t *order,
             float ovr = inter / den;
             if ((double)ovr >= thresh)
                 sup[j] = 1;
-            else if (contain) {                               /* nms.pyx:116-121 */
+            else if (contain) {                               /* nms.pyx:118-120 */
                 float ovr1 = inter / iarea;
                 float ovr2 = inter / areas[j];
                 if ((double)ovr1 > 0.95 || (double)ovr2 > 0.95)

@@ -512,7 +512,7 @@ __device__ __forceinline__ void nms_mask_block(const MaskArgs &A, int rb, int se
             // a division per candidate)
             const bool yes = inter > den * t_hi, no = inter < den * t_lo;
             if (contain) {
-                // utils/nms.pyx:115-121: ovr is a C float widened for the compare with the Python float `thresh`;
+                // utils/nms.pyx:118-120: ovr is a C float widened for the compare with the Python float `thresh`;
                 // ovr1 / ovr2 are untyped, i.e. the f32 quotients as Python floats, compared with 0.95 in f64
                 if (((den > 0.0f) & yes) || (double)(inter / den) >= thresh || (double)(inter / iarea) > 0.95 ||
                     (double)(inter / cbox_w[4][j]) > 0.95)
