@@ -51,6 +51,8 @@ def main():
                     "exact walk; > 1 is compared with it by the largest difference relative to max |bottom_diff|)")
     ap.add_argument("--i32", action="store_true", help="time wssdl_roi_pool_backward_ws (i32 arg-max, prepare + walk in "
                     "one call) per plan instead of the 1-byte pair; checked against the tile-owner kernel's result")
+    ap.add_argument("--dup", type=int, default=1, help="repeat the set's images DUP times as further images (N x DUP images, "
+                    "R x DUP RoIs): time(DUP = 2) - time(DUP = 1) is the bulk rate without the launch's ramp and tail")
     ap.add_argument("--denormals", action="store_true",
                     help="scale top_diff so that sums pass through the f32 denormal range (checks that every plan, "
                          "the ds_add_f32 ones included, still equals plan 11 bit for bit)")
@@ -62,6 +64,10 @@ def main():
         rois_np = np.concatenate([np.concatenate([np.full((int((rois_np[:, 0] == k).sum()), 1), i, np.float32),
                                                   rois_np[rois_np[:, 0] == k][:, 1:]], axis=1)
                                   for i, k in enumerate(keep)]).astype(np.float32)
+    if args.dup > 1:
+        import numpy as np
+        n0 = int(rois_np[:, 0].max()) + 1
+        rois_np = np.concatenate([rois_np + np.array([[k * n0, 0, 0, 0, 0]], np.float32) for k in range(args.dup)]).astype(np.float32)
     H, W = (int(v) for v in args.map.split(","))
     N, C = int(rois_np[:, 0].max()) + 1, args.channels
     dev = torch.device("cuda")
