@@ -229,10 +229,10 @@ def cpu_baseline(wl, fixed_rois=None, seed=3):
         cpu_hot_path_ms_per_step=t_step * 1e3)
 
 
-def fixed_roi_set(wl, net, blobs):
+def fixed_roi_set(wl, net, blobs, weak_step=False):
     """The RoI set of the roofline leg: the committed file for the default workload, otherwise
     n_sup * 128 sampled + n_ws * post_nms_topN proposals built from the network like
-    tools/make_roofline_rois.py does."""
+    tools/make_roofline_rois.py does.  `weak_step`: the alternating mode's weak step (all images weak)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import roofline_leg
@@ -246,13 +246,13 @@ def fixed_roi_set(wl, net, blobs):
         was = net.training
         net.train(train)
         L = net(blobs["data"], blobs["im_info"], blobs["gt_boxes"], blobs["num_gt_boxes"], is_training=train,
-                is_ws=(wl["mode"] == "alter" and wl["n_sup"] == 0), test_net=not train)
+                is_ws=bool(weak_step) or (wl["mode"] == "alter" and wl["n_sup"] == 0), test_net=not train)
         net.train(was)
     post = int((cfg.TRAIN if train else cfg.TEST).RPN_POST_NMS_TOP_N)
     rp, cnt, dec, sidx, scnt = [t.cpu().numpy() for t in proposal_layer_padded(
         L["rpn_cls_score"], L["rpn_bbox_pred"], blobs["im_info"], train, debug=True, from_logits=True)]
     rows = []
-    n_valid = L["roi-data"][1].shape[0] if (train and isinstance(L["roi-data"], tuple)) else 0
+    n_valid = L["roi-data"][1].shape[0] if (train and isinstance(L["roi-data"], tuple) and not weak_step) else 0
     sampled = L["roi-data"][0][:n_valid].cpu().numpy() if n_valid else np.zeros((0, 5), np.float32)
     n_img = blobs["data"].shape[0]
     for i in range(n_img):
@@ -470,8 +470,10 @@ def main():
     # runs it so that ranks stay in step; rank 0 reports)
     tl = _lib.timeline.summary()          # hot-path launches of the timed region (this rank)
     feat_key = "conv5_3" if wl["net"].startswith("VGG") else "group2/relu"
-    leg_blobs = blobs_s if mode == "alter" else blobs
-    rois_fixed, roi_tag = fixed_roi_set(wl, net, leg_blobs)
+    # (alternating mode: the leg measures the WEAK step's launch -- all of its images' proposals through RoI pooling,
+    # the heavier of the iteration's two -- not the supervised step's 128 rows)
+    leg_blobs = blobs_ws if mode == "alter" else blobs
+    rois_fixed, roi_tag = fixed_roi_set(wl, net, leg_blobs, weak_step=(mode == "alter"))
     if args.save_fixed_rois and ctx.rank == 0:
         np.save(args.save_fixed_rois, rois_fixed)
     sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -588,14 +588,16 @@ int walk_plan_count() { return WALK_PLANS; }
 // chain one wave walks alone (small tiles: more, shorter chains).  A train-sized launch is
 // bandwidth-bound and wants 6x6; a launch with few waves (few images or channel groups) is bound by
 // its longest chain: 2 images x 256 channels x 4000 RoIs take 0.44 ms with 6x6 tiles, 0.24 with 4x4,
-// 0.12 with 2x2 (tools/bwd_plan_sweep.py).  Rule: walk down the list below -- tile area descending,
-// at equal tiles 128-channel waves before 64-channel ones (twice the waves, each chain as long but
-// half as wide) -- and take the first plan that gives 2048 waves (one per wave slot of the chip at 8
+// 0.12 with 2x2 (tools/bwd_plan_sweep.py).  Rule: walk down the list below -- tile area descending
+// -- and take the first plan that gives 2048 waves (one per wave slot of the chip at 8
 // per CU).  Measured at the shapes of the other bench workloads (round 3): 3 images x 512 channels x
 // 6000 RoIs 0.27 -> 0.22 ms (4x4 / 64 channels instead of 2x4 / 128), 2 x 256 x 4000 0.12 -> 0.11,
 // 1 x 1024 x 300 0.042 -> 0.040.
 static int walk_plan_auto(int N, int H, int W, int C) {
-    static const int order[] = {11, 5, 23, 18, 22, 19, 21};
+    // (round 4: 4x4 / 128 channels -- plan 5 -- left the list: wherever it was the first plan with 2048 waves, 4x4 /
+    // 64 channels was faster: two weak images x 1024 channels 0.344 -> 0.298 ms on the alternating workload's own set
+    // and 0.313 -> 0.289 on two weak images of the default set, 3 images x 512 channels 0.47 -> 0.34)
+    static const int order[] = {11, 23, 18, 22, 19, 21};
     for (int id : order) {
         const WalkPlan &p = kWalkPlans[id];
         if ((long long)N * cdiv(H, p.th) * cdiv(W, p.tw) * cdiv(C, 64 * p.cpl) >= 2048) return id;
