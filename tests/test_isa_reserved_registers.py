@@ -2,7 +2,11 @@
 (v80-v95, wssdl_bus_amd/csrc/nms.hip) that only their inline-asm statements may name; both kernels carry
 amdgpu_num_vgpr(80) so that the register allocator stays below them.  That attribute is a request, not a
 guarantee: this test disassembles the two kernels out of the BUILT library and checks that every instruction
-that mentions v80-v95 is one of those asm statements (a load into a register pair, or a move out of one)."""
+that mentions v80-v95 is one of those asm statements (a load into a register pair, the zeroing of the registers
+before the first turn, or the OR that takes a landed batch out of them).
+
+(The request is only honoured in a range: with the registers moved to v48-v63 / v64-v79 and amdgpu_num_vgpr(48) /
+(64) the allocator of ROCm 7.2 ignored it and used them -- which is how this test earned its keep in round 4.)"""
 import os
 import re
 import shutil
@@ -73,7 +77,7 @@ def _check(lib_path):
         shutil.rmtree(tmp, ignore_errors=True)
     assert set(listings) == set(KERNELS), sorted(listings)
     for k, lines in listings.items():
-        loads = moves = 0
+        loads = zeroed = ors = 0
         for line in lines:
             if not RESERVED.search(line):
                 continue
@@ -81,8 +85,11 @@ def _check(lib_path):
             op, args = words[0], words[1:]
             if op == "global_load_dwordx2" and RESERVED.fullmatch(args[0]) and not any(RESERVED.search(a) for a in args[1:]):
                 loads += 1                      # a batch load: the reserved pair is the destination only
-            elif op.startswith("v_mov_b32") and RESERVED.fullmatch(args[1]) and not RESERVED.search(args[0]):
-                moves += 1                      # the consume step copies a landed word out
+            elif op.startswith("v_mov_b32") and RESERVED.fullmatch(args[0]) and args[1] == "0":
+                zeroed += 1                     # before the first turn: never-issued batches read as zero words
+            elif op.startswith(("v_or3_b32", "v_or_b32")) and not RESERVED.search(args[0]) and \
+                    any(RESERVED.fullmatch(a) for a in args[1:]):
+                ors += 1                        # the consume step: the landed words are sources only
             else:
                 raise AssertionError("%s: reserved register used outside the helpers' asm: %s" % (k, line.strip()))
-        assert loads == 8 and moves == 16, (k, loads, moves)
+        assert loads == 8 and zeroed == 16 and ors == 8, (k, loads, zeroed, ors)

@@ -793,6 +793,16 @@ __device__ __forceinline__ void sweep_wait_segment(const int *segdone, int expec
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
+// what a helper slot with no word to fetch loads (the pipelined sweep): eight zero bytes
+__device__ const unsigned long long wssdl_sweep_zero_word[2] = {0ull, 0ull};
+
+#ifdef WSSDL_SWEEP_PROFILE
+// tools/nms_sweep_profile.py builds the library with this macro: per wave of an image's sweep, the shader-clock
+// cycles between barriers (work) and inside them (wait), summed over the walk.  [image][wave][4]: work, wait,
+// iterations, realtime ticks (100 MHz) of the whole walk.  Never defined in the product build.
+__device__ unsigned long long wssdl_sweep_prof[64][SWEEP_BLOCK / 64][32];   // [8 + k]: the wave's work cycles in chunks 16k .. 16k + 15
+#endif
+
 __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, int img, int *kept_rows /* LDS [max_keep + 64] */,
                                                           SweepShared &sh) {
     const unsigned long long *__restrict__ mask = A.mask, *__restrict__ diag_t = A.diag_t, *__restrict__ summ = A.summ;
@@ -809,6 +819,7 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
     const unsigned long long *m = mask + (size_t)img * n_max * ncb;
     const unsigned long long *dt = diag_t + (size_t)img * n_max;
     const unsigned long long *cs = summ + (size_t)img * ncb * ncb;        // [column block][row block]
+    const unsigned long long *zero_word = wssdl_sweep_zero_word;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 8) sh.ring[tid] = 0ull;
     if (tid < 2) { sh.pub[tid].kept = 0ull; sh.pub[tid].base = 0; sh.pub[tid].count = 0; }
@@ -935,26 +946,24 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
     // in inline asm with an ordinary operand.  So the batches live in sixteen FIXED registers, v80-v95, that
     // only the asm statements below name (both kernels carry amdgpu_num_vgpr(80), which keeps the register
     // allocator below them -- a request, which tests/test_isa_reserved_registers.py checks in the built library;
-    // 96 VGPRs in all -- see the fused kernel for why not the top of a 128 budget): always HELPER_SLOTS loads per turn (unused slots load word 0 and are masked at the
-    // consume step), consumed behind s_waitcnt vmcnt(HELPER_SLOTS).  Helper waves issue no other vector memory
-    // operation.
+    // 96 VGPRs in all -- see the fused kernel for why not the top of a 128 budget; round 4 tried them at v48-v63 and
+    // v64-v79 for a smaller kernel: the allocator ignored amdgpu_num_vgpr(48) / (64) and used those registers, the
+    // test caught it): always HELPER_SLOTS loads per turn (a slot with nothing to fetch loads a zero word),
+    // consumed behind s_waitcnt vmcnt(HELPER_SLOTS).  Helper waves issue no other vector memory operation.
     constexpr int HELPER_SLOTS = 4;
     constexpr int HELPER_LANES = (SWEEP_BLOCK / 64 - SWEEP_FIRST_HELPER) * 64;
     static_assert(HELPER_SLOTS * HELPER_LANES >= SWEEP_LH * SWEEP_GROUP, "every list position has a slot");
-    struct Batch { unsigned long long w[HELPER_SLOTS]; };
+    // take: the OR of the batch's four words, straight out of the fixed registers (a slot without a word to fetch
+    // loaded a zero, see helper_turn -- no masks to keep, no moves: 4 instructions)
 #define WSSDL_TAKE(R0, R1, R2, R3, R4, R5, R6, R7)                                                                      \
     [&]() {                                                                                                             \
-        unsigned l0, h0, l1, h1, l2, h2, l3, h3;                                                                        \
-        asm volatile("s_waitcnt vmcnt(4)\n\tv_mov_b32 %0, " R0 "\n\tv_mov_b32 %1, " R1 "\n\tv_mov_b32 %2, " R2             \
-                     "\n\tv_mov_b32 %3, " R3 "\n\tv_mov_b32 %4, " R4 "\n\tv_mov_b32 %5, " R5 "\n\tv_mov_b32 %6, " R6       \
-                     "\n\tv_mov_b32 %7, " R7                                                                            \
-                     : "=v"(l0), "=v"(h0), "=v"(l1), "=v"(h1), "=v"(l2), "=v"(h2), "=v"(l3), "=v"(h3)                  \
+        unsigned lo, hi;                                                                                                \
+        asm volatile("s_waitcnt vmcnt(4)\n\tv_or3_b32 %0, " R0 ", " R2 ", " R4 "\n\tv_or3_b32 %1, " R1 ", " R3 ", " R5       \
+                     "\n\tv_or_b32 %0, %0, " R6 "\n\tv_or_b32 %1, %1, " R7                                              \
+                     : "=&v"(lo), "=&v"(hi)                                                                             \
                      :                                                                                                  \
                      : "memory");                                                                                       \
-        Batch b;                                                                                                        \
-        b.w[0] = ((unsigned long long)h0 << 32) | l0;  b.w[1] = ((unsigned long long)h1 << 32) | l1;                    \
-        b.w[2] = ((unsigned long long)h2 << 32) | l2;  b.w[3] = ((unsigned long long)h3 << 32) | l3;                    \
-        return b;                                                                                                       \
+        return ((unsigned long long)hi << 32) | lo;                                                                     \
     }
 #define WSSDL_ISSUE(P0, P1, P2, P3, C0, C1, C2, C3, C4, C5, C6, C7)                                                     \
     [&](int j, const unsigned long long *src) {                                                                         \
@@ -971,39 +980,74 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
                                "v93", "v94", "v95");
 #undef WSSDL_TAKE
 #undef WSSDL_ISSUE
+    // (the first two turns take batches that were never issued: the registers start as zero words)
+    if (helper)
+        asm volatile("v_mov_b32 v80, 0\n\tv_mov_b32 v81, 0\n\tv_mov_b32 v82, 0\n\tv_mov_b32 v83, 0\n\tv_mov_b32 v84, 0\n\t"
+                     "v_mov_b32 v85, 0\n\tv_mov_b32 v86, 0\n\tv_mov_b32 v87, 0\n\tv_mov_b32 v88, 0\n\tv_mov_b32 v89, 0\n\t"
+                     "v_mov_b32 v90, 0\n\tv_mov_b32 v91, 0\n\tv_mov_b32 v92, 0\n\tv_mov_b32 v93, 0\n\tv_mov_b32 v94, 0\n\t"
+                     "v_mov_b32 v95, 0" ::: "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89",
+                     "v90", "v91", "v92", "v93", "v94", "v95");
     const int hall = hw * 64 + lane;
-    unsigned live_a = 0u, live_b = 0u;
-    auto helper_turn = [&](auto &take, auto &issue, unsigned &live, int c) {
-        // consume word c+1: this batch was issued at iteration c-2; the one issued at c-1 may stay in flight
-        const Batch got = take();
-        unsigned long long acc = 0ull;
+    int hpos[HELPER_SLOTS];                  // this lane's list positions, held inside the LDS list
 #pragma unroll
-        for (int j = 0; j < HELPER_SLOTS; ++j) acc |= ((live >> j) & 1u) ? got.w[j] : 0ull;
-        acc = wave_or_u64(acc);
-        if (lane == 0 && acc != 0ull) atomicOr(&sh.ring[(c + 1) & 7], acc);
+    for (int j = 0; j < HELPER_SLOTS; ++j) hpos[j] = min(hall + j * HELPER_LANES, max_keep);
+    // The helpers' turn is the longest of most iterations (tools/nms_sweep_profile.py: the last helper waves arrive
+    // last at the barrier in 50-90 % of them) and what it costs is issue slots: one CU issues for all sixteen
+    // waves, and a turn took the same ~1100-1400 cycles with nothing to gather as with a full list.  So it is
+    // written for instruction count (round 4, ~170 -> ~90): a slot with nothing to fetch loads a word that is zero
+    // (no per-slot masks: the batch is ORed straight out of its registers), the wave's contribution goes to the
+    // ring with one LDS atomic per lane that HAS one (a few lanes per wave; the 64-bit DPP reduction was 30
+    // instructions for every wave, every turn), the list entries and the summary words are read in two rounds of
+    // LDS loads instead of a dependent pair per slot, the summary as 32-bit halves.  Early-stop walks 0.165 ->
+    // 0.157 ms (fused) and 0.243 -> 0.233 (two launches) for the 8-image layer; the bench's full walks, which wait
+    // for the mask's last segments, did not move (profiles/r04_sweep_roles.log).
+#ifdef WSSDL_SWEEP_PROFILE
+    unsigned long long prof_mid = 0ull;      // helpers: cycles in take() (the wait for the batch); stagers: in the wait for their rows
+#endif
+    auto helper_turn = [&](auto &take, auto &issue, int c) {
+        // consume word c+1: this batch was issued at iteration c-2; the one issued at c-1 may stay in flight
+        // (the instruction itself: atomicOr() on one address becomes a loop over the active lanes)
+#ifdef WSSDL_SWEEP_PROFILE
+        const unsigned long long prof_m0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        const unsigned long long acc = take();
+#ifdef WSSDL_SWEEP_PROFILE
+        prof_mid += __builtin_amdgcn_s_memtime() - prof_m0;       // (incl. ~2 x 60 cycles of the stamps themselves)
+#endif
+        if (acc != 0ull)
+            asm volatile("ds_or_b64 %0, %1" : : "v"((unsigned)(size_t)&sh.ring[(c + 1) & 7]), "v"(acc) : "memory");
         // issue word c+3 of every box in the kept list (chunks <= c-2) for which the column's summary has a
         // bit (the others are zero, and were not even stored); 32-bit word offsets (n_max * pitch < 2^31
         // checked by the launcher).  (A lane per CHUNK, walking the bits of kept & summary, needs no list -- but
         // a chunk can hold more such boxes than a lane has registers, and the overflow loads sat inside the
         // iteration: 0.49 against 0.37 ms in the step.)
         const int lim = (c >= 1 && c + 3 < nchunks) ? min(sh.pub[(c - 1) & 1].base, max_keep) : 0;
-        const unsigned long long *colsum_now = sh.colsum[(c + 3) & 3];
-        live = 0u;
+        const unsigned *colsum_now = reinterpret_cast<const unsigned *>(sh.colsum[(c + 3) & 3]);
+        unsigned row[HELPER_SLOTS], cw[HELPER_SLOTS];
+#pragma unroll
+        for (int j = 0; j < HELPER_SLOTS; ++j) row[j] = (unsigned)kept_rows[hpos[j]];
+#pragma unroll
+        for (int j = 0; j < HELPER_SLOTS; ++j) row[j] = (hall + j * HELPER_LANES < lim) ? row[j] : 0u;
+#pragma unroll
+        for (int j = 0; j < HELPER_SLOTS; ++j) cw[j] = colsum_now[row[j] >> 5];
+        const unsigned long long *src[HELPER_SLOTS];
 #pragma unroll
         for (int j = 0; j < HELPER_SLOTS; ++j) {
-            const int i = hall + j * HELPER_LANES;
-            unsigned off = 0u;
-            if (i < lim) {
-                const unsigned row = (unsigned)kept_rows[i];
-                if ((colsum_now[row >> 6] >> (row & 63u)) & 1ull) {
-                    off = __umul24(row, (unsigned)ncb) + (unsigned)(c + 3);
-                    live |= 1u << j;
-                }
-            }
-            issue(j, m + off);
+            const unsigned hit = (unsigned)(hall + j * HELPER_LANES < lim) & (cw[j] >> (row[j] & 31u)) & 1u;
+            src[j] = hit ? m + (__umul24(row[j], (unsigned)ncb) + (unsigned)(c + 3)) : zero_word;
         }
+#pragma unroll
+        for (int j = 0; j < HELPER_SLOTS; ++j) issue(j, src[j]);
     };
     int count = 0, last = -1;
+#ifdef WSSDL_SWEEP_PROFILE
+    __shared__ unsigned long long prof_lds[SWEEP_BLOCK / 64][24];
+    if (tid < (SWEEP_BLOCK / 64) * 24) prof_lds[tid / 24][tid % 24] = 0ull;
+    __syncthreads();
+    unsigned long long prof_work = 0ull, prof_wait = 0ull, prof_last = 0ull, prof_max = 0ull, prof_maxc = 0ull, prof_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long prof_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int c = 0; c < nchunks; ++c) {
         if (wave == 0) {
             unsigned long long rem = 0ull;
@@ -1036,26 +1080,61 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
         } else if (role == 4) {
             // spare
         } else if (helper) {
-            if (c & 1) helper_turn(take_b, issue_b, live_b, c);
-            else helper_turn(take_a, issue_a, live_a, c);
+#ifndef WSSDL_SWEEP_NULL_HELPERS      // (timing experiment of the profile build: what the iteration costs without them; wrong keeps)
+            if (c & 1) helper_turn(take_b, issue_b, c);
+            else helper_turn(take_a, issue_a, c);
+#endif
         } else if ((c & 1) == group) {
             if (scribe) {
-                flush();                               // outputs fetched two iterations ago
+#ifdef WSSDL_SWEEP_PROFILE
+                const unsigned long long prof_m0 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                prof_mid += __builtin_amdgcn_s_memtime() - prof_m0;
+#endif
+                // the column first: its s_waitcnt vmcnt(0) (for the loads of two iterations ago) otherwise also waits
+                // for the global stores flush() has just issued -- vmcnt counts stores -- and the scribe of the
+                // iteration was the last wave at the barrier in 90 % of the chunks of the bench's steps, ~19-26 %
+                // after the swap (tools/nms_sweep_profile.py, profiles/r04_sweep_roles.log)
                 store_column(c + 4);                   // fetched two iterations ago
+                flush();                               // outputs fetched two iterations ago
                 if (c > 0) expand(c - 1);
                 fetch_column(c + 6);
             } else if (stager) {
+#ifdef WSSDL_SWEEP_PROFILE
+                const unsigned long long prof_m0 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                prof_mid += __builtin_amdgcn_s_memtime() - prof_m0;
+#endif
 #pragma unroll
                 for (int j = 0; j <= SWEEP_AHEAD; ++j) sh.rowbuf[(c + 1) & 1][j][lane] = rows[j];
                 load_rows(c + 3);
             }
         }
+#ifdef WSSDL_SWEEP_PROFILE
+        const unsigned long long prof_t1 = __builtin_amdgcn_s_memtime();
         lds_only_barrier();
+        const unsigned long long prof_t2 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        prof_last += (prof_t2 - prof_t1 < 200ull) ? 1ull : 0ull;             // this wave was (nearly) the last to arrive
+        if (lane == 0 && c < 24 * 16) prof_lds[wave][c >> 4] += prof_t1 - prof_prev;      // this wave's work, by 16-chunk bucket
+        if (prof_t1 - prof_prev > prof_max) { prof_max = prof_t1 - prof_prev;  prof_maxc = (unsigned long long)c; }
+        prof_work += prof_t1 - prof_prev;  prof_wait += prof_t2 - prof_t1;  prof_prev = prof_t2;
+#else
+        lds_only_barrier();
+#endif
         if (wave != 0) count = sh.pub[c & 1].count;
         last = c;
         if (count >= max_keep) break;
     }
     if (helper) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (batches still in flight)
+#ifdef WSSDL_SWEEP_PROFILE
+    if (lane == 0 && img < 64) {
+        unsigned long long *o = wssdl_sweep_prof[img][wave];
+        o[0] = prof_work;  o[1] = prof_wait;  o[2] = (unsigned long long)(last + 1);
+        o[3] = __builtin_amdgcn_s_memrealtime() - prof_rt0;  o[4] = prof_mid;  o[5] = prof_last;  o[6] = prof_max;  o[7] = prof_maxc;
+        for (int k = 0; k < 24; ++k) o[8 + k] = prof_lds[wave][k];
+    }
+#endif
     if (scribe && last >= 0) {
         // chunk `last` was resolved but not expanded yet: it belongs to the group of last + 1
         flush();
@@ -1381,3 +1460,14 @@ extern "C" int wssdl_nms_new(const float *dets, int n, double thresh, int max_ke
                              wssdl_stream_t stream) {
     return nms_entry(dets, n, thresh, max_keep, keep, num_keep, workspace, workspace_bytes, stream, 1);
 }
+
+#ifdef WSSDL_SWEEP_PROFILE
+// profile build only (tools/nms_sweep_profile.py): copy the sweep's per-wave cycle counts to the host and zero them
+extern "C" __attribute__((visibility("default"))) int wssdl_debug_sweep_profile_read(unsigned long long *host, size_t bytes) {
+    if (bytes > sizeof(wssdl::wssdl_sweep_prof)) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (hipDeviceSynchronize() != hipSuccess) return WSSDL_ERR_LAUNCH;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(wssdl::wssdl_sweep_prof), bytes) != hipSuccess) return WSSDL_ERR_LAUNCH;
+    static unsigned long long zeros[sizeof(wssdl::wssdl_sweep_prof) / 8];
+    return hipMemcpyToSymbol(HIP_SYMBOL(wssdl::wssdl_sweep_prof), zeros, sizeof(zeros)) == hipSuccess ? WSSDL_OK : WSSDL_ERR_LAUNCH;
+}
+#endif
