@@ -176,8 +176,13 @@ def _worker_two_ranks(rank, world, port, q):
         expect = _flat(torch, [exp_state[k] for k, _ in net.named_parameters()]).clone()
         # the same expectation once more: what the non-deterministic convolution gradients alone
         # move (the yardstick for the comparison below)
-        exp_again, _ = expected_step(net, state0, plain.joint_backward, blobs, [50, 51], plain.lr)
-        out["joint_noise"] = float((expect - _flat(torch, [exp_again[k] for k, _ in net.named_parameters()])).abs().max())
+        # (three repeats, the largest difference: one repeat is a single sample of that noise and has come out 10 x
+        # below the next one)
+        noise = 0.0
+        for _ in range(3):
+            exp_again, _ = expected_step(net, state0, plain.joint_backward, blobs, [50, 51], plain.lr)
+            noise = max(noise, float((expect - _flat(torch, [exp_again[k] for k, _ in net.named_parameters()])).abs().max()))
+        out["joint_noise"] = noise
         _load(net, state0)
         solver = SolverWrapper(net, dist_ctx=ctx)
         np.random.seed(50 + rank)
@@ -210,9 +215,12 @@ def _worker_two_ranks(rank, world, port, q):
         # parameters without a weak gradient must come out of the weak step untouched
         out["weak_nograd_static"] = all(bool(torch.equal(s1[n], s2[n])) for n, h in zip(names, had) if not h)
         expect2 = _flat(torch, [s2[k] for k in names]).clone()
-        s1b, _ = expected_step(net2, s0, plain2.supervised_backward, blobs_s, [60, 61], plain2.lr)
-        s2b, _ = expected_step(net2, s1b, plain2.weak_backward, blobs_w, [70, 71], plain2.lr)
-        out["alter_noise"] = float((expect2 - _flat(torch, [s2b[k] for k in names])).abs().max())
+        noise2 = 0.0
+        for _ in range(3):
+            s1b, _ = expected_step(net2, s0, plain2.supervised_backward, blobs_s, [60, 61], plain2.lr)
+            s2b, _ = expected_step(net2, s1b, plain2.weak_backward, blobs_w, [70, 71], plain2.lr)
+            noise2 = max(noise2, float((expect2 - _flat(torch, [s2b[k] for k in names])).abs().max()))
+        out["alter_noise"] = noise2
         _load(net2, s0)
         solver2 = SolverWrapper(net2, dist_ctx=ctx)
         orig_apply = solver2._apply
@@ -265,7 +273,7 @@ def test_two_ranks_on_one_gpu_real_steps_match_mean_gradient_update():
         # the serial expectation by no more than a few times what a REPEAT of the serial
         # computation differs from itself (MIOpen's weight gradients are not deterministic),
         # and in any case by less than 2 % of the largest possible Adam step (lr)
-        # (one repeat is a single sample of that noise, hence the generous factor)
+        # (the yardstick is the largest of three repeats)
         assert o["joint_err"] <= max(10 * o["joint_noise"], 2e-6), o
         assert o["alter_err"] <= max(10 * o["alter_noise"], 2e-6), o
         assert o["joint_err"] <= 1e-5 and o["alter_err"] <= 1e-5, o
