@@ -117,7 +117,9 @@ def main():
         return
 
     ref = op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=run(11))
-    timeit(lambda: op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=run(11)), 10)     # clocks up
+    # clocks up: with 10 launches the first plan of the list measured ~8 % slow (plan 11 0.58-0.60 ms in first place, 0.516-0.526
+    # later in the same run), which is how plan 13 once seemed faster than plan 11
+    timeit(lambda: op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=run(11)), 100)
     scale = float(ref.abs().max())
     for p in (int(x) for x in args.plans.split(",")):
         plan = run(p)
