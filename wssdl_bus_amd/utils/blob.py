@@ -238,8 +238,33 @@ def im_list_to_blob(ims, scale=1.0, divide=False):
     return blob
 
 
+def imread(path):
+    """The grey plane of an image file as a [h,w] uint8 array -- what ``skimage.io.imread`` hands the reference for its
+    single-channel B-mode images (roi_data_layer/minibatch_bus.py:269,294,304).  Decoding a file format is byte
+    parsing with no arithmetic in it and stays on the HOST (PIL here; scikit-image is not installed); everything from
+    the decoded plane on runs on the device.  Colour / 16-bit files are refused rather than converted silently."""
+    from PIL import Image
+    with Image.open(path) as im:
+        if im.mode not in ("L", "P", "1"):
+            raise ValueError("%s: mode %s -- the reference's pipeline stacks ONE grey plane three times "
+                             "(minibatch_bus.py:270); convert the file first" % (path, im.mode))
+        plane = np.asarray(im.convert("L"), dtype=np.uint8)
+    if plane.ndim != 2:
+        raise ValueError("%s: not a single plane" % path)
+    return np.ascontiguousarray(plane)
+
+
+def roidb_planes(roidb):
+    """[{'image': path, 'flipped': bool}, ...] (the reference's roidb entries) -> (planes, flips)."""
+    return [imread(e["image"]) for e in roidb], [bool(e.get("flipped", False)) for e in roidb]
+
+
 def _get_image_blob(planes, flipped, net_name, scale_inds, is_training, is_ws, rng=None, resize=None):
-    """roi_data_layer/minibatch_bus.py:259-283: one list of images, all supervised or all weak."""
+    """roi_data_layer/minibatch_bus.py:259-283: one list of images, all supervised or all weak.  `planes` = decoded
+    grey planes with `flipped` = their flags, or the reference's own first argument -- a roidb list of
+    {'image': path, 'flipped': bool} entries -- with flipped=None."""
+    if flipped is None:
+        planes, flipped = roidb_planes(planes)
     ims, scales = [], []
     for i, (g, f) in enumerate(zip(planes, flipped)):
         im, s = prep_im_for_blob(g, net_name, PIXEL_MEANS, PIXEL_STDS, cfg.TRAIN.SCALES[int(scale_inds[i])],
@@ -253,7 +278,12 @@ def _get_image_blob_joint(planes_s, flipped_s, planes_ws, flipped_ws, net_name, 
                           rng=None, resize=None):
     """roi_data_layer/minibatch_bus.py:285-318: the combined mini-batch -- the supervised images first
     (is_ws=False), then the weak ones (is_ws=True: cropped), `scale_inds` indexed in that order, one RNG
-    stream through all of them; zero-padded blob [n_s + n_ws, max_h, max_w, 3] and the im_scales."""
+    stream through all of them; zero-padded blob [n_s + n_ws, max_h, max_w, 3] and the im_scales.  With
+    flipped_s = flipped_ws = None the first and third arguments are the reference's roidb_s / roidb_ws lists."""
+    if flipped_s is None:
+        planes_s, flipped_s = roidb_planes(planes_s)
+    if flipped_ws is None:
+        planes_ws, flipped_ws = roidb_planes(planes_ws)
     ims, scales = [], []
     k = 0
     for planes, flips, ws in ((planes_s, flipped_s, False), (planes_ws, flipped_ws, True)):
