@@ -1,0 +1,9 @@
+mkdir -p gpurun_out/r4_prof; timeout -k 10 400 python bench.py --workload resnet50_alter --steps 6 --warmup 3 --no-cpu-baseline --save-fixed-rois gpurun_out/r4_prof/alter_rois_now.npy > gpurun_out/r4_prof/alter_bench_now.log 2>&1; python - <<EOF
+import json,numpy as np
+d=json.loads([l for l in open("gpurun_out/r4_prof/alter_bench_now.log") if l.startswith("{\"metric")][-1])
+fs=d["roofline"]["fixed_set"]; print("bench leg:", {k:round(v["avg_ms"],4) for k,v in fs.items()})
+for f in ("gpurun_out/r4_prof/alter_rois_now.npy","profiles/roofline_rois_resnet50_alter_weak_r4000.npy"):
+    r=np.load(f); w=(r[:,3]-r[:,1]+1)/16; h=(r[:,4]-r[:,2]+1)/16
+    print(f, r.shape, "mean w,h in cells %.1f %.1f"%(w.mean(),h.mean()), "images", np.bincount(r[:,0].astype(int)))
+EOF
+timeout -k 10 300 python tools/probes/alter_leg_split.py gpurun_out/r4_prof/alter_rois_now.npy 2>&1 | cut -c1-200 | head -6

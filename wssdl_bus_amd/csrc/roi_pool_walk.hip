@@ -625,11 +625,17 @@ static int walk_plan_choice(int N, int H, int W, int C) {
 // Measured (tools/bwd_fixed_sweep.py, profiles/r04_split_walk_sweeps.log): VGG-16's own 1 + 2 set (R = 4128, C = 512,
 // RoIs of ~24 x 24 cells) exact 0.31-0.34 ms (any plan) -> 0.246 with 8 segments on 8x8 / 64-channel tiles (plan 7);
 // one 2000-RoI image x 1024 channels 0.186 -> 0.155; two such images x 1024 channels (the alternating mode's weak
-// step) are NOT chain-bound any more (exact 0.289 ms = 0.44 of peak on moved bytes, split 0.285-0.30): the rule asks
-// for fewer than 2048 (image, channel) pairs.  Beyond the chain the launch is bound by the bytes neighbouring tiles
+// step) are NOT chain-bound any more (exact 0.289 ms = 0.44 of peak on moved bytes, split 0.285-0.30 on that set): they
+// get 4 segments for the bytes the larger tiles save (see below); more than 2048 (image, channel) pairs: the exact walk.  Beyond the chain the launch is bound by the bytes neighbouring tiles
 // re-read (windows of 4.4 x 4.5 cells against 8 x 8 tiles: 2 x), which no segment count changes.
 int walk_split_segments(int R, int N, int H, int W, int C) {
-    if (N < 1 || N > 4 || (C & 3) || (long long)R < 1000LL * N || (long long)N * C >= 2048) return 1;
+    if (N < 1 || N > 4 || (C & 3) || (long long)R < 1000LL * N || (long long)N * C > 2048) return 1;
+    // exactly 2048 pairs (two weak images x 1024 channels, the alternating mode's weak step): with the small RoIs of one
+    // saved set the exact walk on 4x4 tiles tied (0.306-0.315 ms against 0.289-0.31 inside the roofline leg), with the
+    // larger ones other runs of the same untrained network propose (21 x 17 cells instead of 13 x 12) it loses to the
+    // split form's 8x8 tiles: 0.40 against 0.328 (4 segments) / 0.339 (8) -- tools/probes/alter_leg_split.py
+    // (measured for two images; four images x 512 channels keep the exact walk)
+    if ((long long)N * C == 2048) return N <= 2 ? 4 : 1;
     return 8;
 }
 // the plan the split form wants (chains no longer matter: larger tiles, fewer re-read bytes)
