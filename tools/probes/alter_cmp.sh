@@ -1,3 +1,4 @@
+# the workload's own leg (bench.py --save-fixed-rois) against tools/probes/alter_leg_split.py on the set that run generated: are the leg's numbers the RoI set or the leg?
 mkdir -p gpurun_out/r4_prof; timeout -k 10 400 python bench.py --workload resnet50_alter --steps 6 --warmup 3 --no-cpu-baseline --save-fixed-rois gpurun_out/r4_prof/alter_rois_now.npy > gpurun_out/r4_prof/alter_bench_now.log 2>&1; python - <<EOF
 import json,numpy as np
 d=json.loads([l for l in open("gpurun_out/r4_prof/alter_bench_now.log") if l.startswith("{\"metric")][-1])
