@@ -118,6 +118,11 @@ def roi_pool_forward(bottom, rois, pooled_h, pooled_w, spatial_scale, mode="cuda
     rois = np.ascontiguousarray(rois, dtype=np.float32).reshape(-1, 5)
     N, H, W, C = bottom.shape
     R = rois.shape[0]
+    # roi_pooling_op.cc:150-152 / roi_pooling_op_gpu.cu.cc:41-43 index the batch unchecked: an index outside [0, N) reads
+    # out of bounds there (and here).  Not a defined input of the reference; the product's answer for it (an empty RoI) is
+    # its own, tested in tests/test_gpu_edges.py.
+    if R and ((rois[:, 0] < 0).any() or (rois[:, 0].astype(np.int64) >= N).any()):
+        raise ValueError("roi_pool_forward oracle: batch index outside [0, %d) -- undefined in the reference op" % N)
     top = np.empty((R, pooled_h, pooled_w, C), dtype=np.float32)
     arg = np.empty((R, pooled_h, pooled_w, C), dtype=np.int32)
     L = lib()
