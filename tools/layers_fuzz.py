@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
-from oracle import np_oracle as O  # noqa: E402
+from oracle import np_oracle as O, ref_kernels  # noqa: E402
 from wssdl_bus_amd.fast_rcnn.config import cfg  # noqa: E402
 from wssdl_bus_amd.rpn_msr.anchor_target_layer_tf_bus import anchor_target_layer  # noqa: E402
 from wssdl_bus_amd.rpn_msr.proposal_target_layer_tf_bus import proposal_target_layer  # noqa: E402
@@ -69,6 +69,9 @@ for k in range(args.cases):
     q = np.ascontiguousarray(gt[:n, :4].astype(np.float64))
     ok_iou = np.array_equal(np.asarray(bbox_overlaps(boxes, q)), O.bbox_overlaps(boxes, q)) and \
         np.array_equal(np.asarray(bbox_overlaps_ui(boxes, q)), O.bbox_overlaps_ui(boxes, q))
+    if ref_kernels.available():          # the reference's own compiled bbox.pyx / bbox_ui.pyx (oracle/_ref)
+        ok_iou = ok_iou and np.array_equal(np.asarray(bbox_overlaps(boxes, q)), ref_kernels.bbox_overlaps(boxes, q)) and \
+            np.array_equal(np.asarray(bbox_overlaps_ui(boxes, q)), ref_kernels.bbox_overlaps_ui(boxes, q))
     # proposal targets (alternating mode, train / weak / test) of N images: proposals around the ground truth and elsewhere
     Ni = int(rs.randint(1, 4))
     gts = np.zeros((Ni, MAX_GT, 5), np.float32)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random NMS cases, product (wssdl_nms / wssdl_nms_new through hip_nms) against the C oracle's keep lists: sizes 1 ... 13000
+"""Random NMS cases, product (wssdl_nms / wssdl_nms_new through hip_nms) against the C oracle's keep lists (and the reference's own Cython build, oracle/_ref, when present): sizes 1 ... 13000
 (not multiples of 64 on purpose), tight clusters, duplicates, degenerate boxes, thresholds 0.05 ... 0.95, max_keep cuts.
 Scores are distinct (the order of equal scores is the product's own rule, tested elsewhere).
     python3 tools/nms_fuzz.py [--cases 400] [--seed 0]"""
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-from oracle import c_oracle  # noqa: E402
+from oracle import c_oracle, ref_kernels  # noqa: E402
 from wssdl_bus_amd.nms.hip_nms import hip_nms  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -19,7 +19,7 @@ ap.add_argument("--cases", type=int, default=400)
 ap.add_argument("--seed", type=int, default=0)
 args = ap.parse_args()
 rs = np.random.RandomState(args.seed)
-bad = 0
+bad = n_ref = 0
 for k in range(args.cases):
     n = int(rs.choice([1, 2, 63, 64, 65, 127, 129, 300, 1000, 2047, 2049, 4097, 6000, 9001, 12000, 13000])) if k % 3 else int(rs.randint(1, 13001))
     kind = k % 5
@@ -38,6 +38,14 @@ for k in range(args.cases):
     thresh = float(rs.choice([0.05, 0.3, 0.5, 0.7, 0.95]))
     rule = "nms_new" if k % 4 == 0 else "nms"
     want = (c_oracle.nms_new if rule == "nms_new" else c_oracle.cpu_nms)(d, thresh)
+    # ... and, where oracle/_ref is built, the reference's own compiled Cython says the same (cpu_nms.pyx / utils/nms.pyx)
+    ref_fn = (ref_kernels.nms_new if rule == "nms_new" else ref_kernels.cpu_nms)
+    if ref_fn is not None:
+        ref_keep = [int(v) for v in ref_fn(d, thresh)]
+        if ref_keep != want:
+            bad += 1
+            print("ORACLE != REFERENCE BUILD case %d: n %d thresh %.2f rule %s" % (k, n, thresh, rule))
+        n_ref += 1
     mk = None if k % 2 else int(rs.choice([1, 64, 300, 2000]))
     got = hip_nms(d, thresh, max_keep=mk, rule=rule)
     if mk is not None:
@@ -47,5 +55,5 @@ for k in range(args.cases):
         print("MISMATCH case %d: n %d kind %d thresh %.2f rule %s max_keep %s: got %d kept, want %d" % (k, n, kind, thresh, rule, mk, len(got), len(want)))
     if (k + 1) % 100 == 0:
         print("case %d ok so far (%d mismatches)" % (k + 1, bad), flush=True)
-print("cases %d mismatches %d" % (args.cases, bad))
+print("cases %d mismatches %d (%d of them also against the reference's own Cython build)" % (args.cases, bad, n_ref))
 sys.exit(1 if bad else 0)
