@@ -87,3 +87,15 @@ def test_bare_bench_gpus_n_starts_the_launcher_before_torch(tmp_path):
     assert p.returncode != 0
     assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert "needs a GPU" in err and "torch.distributed" in err.replace("torchrun", "torch.distributed"), err[-1500:]
+
+
+def test_every_tool_script_parses():
+    """tools/*.py and tools/probes/*.py are run on the GPU box only; a syntax error in one of them should show up here."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py")) + glob.glob(os.path.join(root, "tools", "probes", "*.py")))
+    assert len(files) >= 20
+    for f in files:
+        with open(f) as fh:
+            ast.parse(fh.read(), filename=f)
