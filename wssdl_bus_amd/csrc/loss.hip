@@ -79,8 +79,8 @@ __device__ __forceinline__ long long rpn_target_off(const MtlArgs &x, long long 
 }
 
 __device__ __forceinline__ float log_sum_exp2(float a, float b) {
-    const float m = fmaxf(a, b);
-    return m + logf(expf(a - m) + expf(b - m));
+    // (log1p of the smaller term: see lse_minus_max in common.hip.h)
+    return fmaxf(a, b) + log1pf(expf(-fabsf(a - b)));
 }
 
 // partials: [nb_cls] CE sums, [nb_cls] counts, [nb_box] box sums, then 3 values of the R-CNN block
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(MTL_BLOCK) void mtl_forward_kernel(MtlArgs x, doubl
             const int l = x.rpn_labels[lo];
             if (l < 0) continue;
             const float bg = x.rpn_cls_score[so], fg = x.rpn_cls_score[so + x.A];
-            s += (double)(log_sum_exp2(bg, fg) - (l ? fg : bg));
+            // (max - own score) + log1p(...): adding the maximum first and subtracting it again would round the small term away
+            s += (double)((fmaxf(bg, fg) - (l ? fg : bg)) + log1pf(expf(-fabsf(bg - fg))));
             c += 1.0;
         }
         const double ss = block_sum(s, scratch), cc = block_sum(c, scratch);
@@ -127,11 +128,9 @@ __global__ __launch_bounds__(MTL_BLOCK) void mtl_forward_kernel(MtlArgs x, doubl
             const int l = x.labels[r];
             if (l >= 0 && l < x.K) {       // (a label outside [0, K) is ignored like padding, not read through)
                 const float *sc = x.cls_score + (size_t)r * x.K;
-                float m = sc[0];
-                for (int k = 1; k < x.K; ++k) m = fmaxf(m, sc[k]);
-                float z = 0.0f;
-                for (int k = 0; k < x.K; ++k) z += expf(sc[k] - m);
-                ce += (double)(m + logf(z) - sc[l]);
+                float m;
+                const float lz = lse_minus_max(sc, x.K, &m);
+                ce += (double)((m - sc[l]) + lz);
                 cnt += 1.0;
             }
             const size_t o = (size_t)r * 4 * x.K;
@@ -187,8 +186,10 @@ __global__ __launch_bounds__(MTL_BLOCK) void mtl_backward_kernel(MtlArgs x, cons
             if (l >= 0) {
                 const float bg = x.rpn_cls_score[so], fg = x.rpn_cls_score[so + x.A];
                 const float lse = log_sum_exp2(bg, fg);
-                gb = (expf(bg - lse) - (l == 0 ? 1.0f : 0.0f)) * scale;
-                gf = (expf(fg - lse) - (l == 1 ? 1.0f : 0.0f)) * scale;
+                // (two classes: the label's component is minus the other class's probability)
+                const float pb = expf(bg - lse), pf = expf(fg - lse);
+                gb = (l == 0 ? -pf : pb) * scale;
+                gf = (l == 1 ? -pb : pf) * scale;
             }
             g_rpn_cls[so] = gb;
             g_rpn_cls[so + x.A] = gf;
@@ -223,12 +224,17 @@ __global__ __launch_bounds__(MTL_BLOCK) void mtl_backward_kernel(MtlArgs x, cons
             const int l = (r < x.n_rows) ? x.labels[r] : -1;
             if (l >= 0 && l < x.K) {
                 const float *sc = x.cls_score + (size_t)r * x.K;
-                float m = sc[0];
-                for (int k = 1; k < x.K; ++k) m = fmaxf(m, sc[k]);
-                float z = 0.0f;
-                for (int k = 0; k < x.K; ++k) z += expf(sc[k] - m);
-                const float lse = m + logf(z);
-                for (int k = 0; k < x.K; ++k) gc[k] = (expf(sc[k] - lse) - (k == l ? 1.0f : 0.0f)) * sc_ce;
+                float m;
+                const float lz = lse_minus_max(sc, x.K, &m);
+                const float lse = m + lz;
+                // (the label's component as -(sum of the other probabilities): accurate when p_l -> 1)
+                float others = 0.0f;
+                for (int k = 0; k < x.K; ++k) {
+                    const float pk = expf(sc[k] - lse);
+                    gc[k] = pk * sc_ce;
+                    others += (k == l) ? 0.0f : pk;
+                }
+                gc[l] = -others * sc_ce;
             } else {
                 for (int k = 0; k < x.K; ++k) gc[k] = 0.0f;
             }

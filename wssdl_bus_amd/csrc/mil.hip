@@ -85,11 +85,9 @@ __global__ __launch_bounds__(64) void mil_bag_term_kernel(const float *__restric
     float v = 0.0f;
     if (r >= 0 && l >= 0 && l < K) {
         const float *s = logits + (size_t)r * K;
-        float m = s[0];
-        for (int k = 1; k < K; ++k) m = fmaxf(m, s[k]);
-        float z = 0.0f;
-        for (int k = 0; k < K; ++k) z += expf(s[k] - m);
-        v = cw.w[l] * (m + logf(z) - s[l]);
+        float m;
+        const float lz = lse_minus_max(s, K, &m);
+        v = cw.w[l] * ((m - s[l]) + lz);
     }
     bag_loss[b] = v;
 }
@@ -110,13 +108,18 @@ __global__ __launch_bounds__(256) void mil_loss_backward_kernel(
         return;
     }
     const float *s = logits + (size_t)r * K;
-    float m = s[0];
-    for (int k = 1; k < K; ++k) m = fmaxf(m, s[k]);
-    float z = 0.0f;
-    for (int k = 0; k < K; ++k) z += expf(s[k] - m);
-    const float lse = m + logf(z);
+    float m;
+    const float lz = lse_minus_max(s, K, &m);
+    const float lse = m + lz;
     const float c = grad_loss[0] * scale * cw.w[l] / (float)n_bags;
-    for (int k = 0; k < K; ++k) g[k] = c * (expf(s[k] - lse) - (k == l ? 1.0f : 0.0f));
+    // the label's component is p_l - 1 = -(sum of the other probabilities): the sum keeps its accuracy when p_l -> 1
+    float others = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const float pk = expf(s[k] - lse);
+        g[k] = c * pk;
+        others += (k == l) ? 0.0f : pk;
+    }
+    g[l] = -c * others;
 }
 
 }  // namespace wssdl
