@@ -15,7 +15,8 @@ import numpy as np  # noqa: E402
 from oracle import np_oracle as O, ref_kernels  # noqa: E402
 from wssdl_bus_amd.fast_rcnn.config import cfg  # noqa: E402
 from wssdl_bus_amd.rpn_msr.anchor_target_layer_tf_bus import anchor_target_layer  # noqa: E402
-from wssdl_bus_amd.rpn_msr.proposal_target_layer_tf_bus import proposal_target_layer  # noqa: E402
+from wssdl_bus_amd.rpn_msr.proposal_target_layer_tf_bus import proposal_target_layer, proposal_target_layer_joint  # noqa: E402
+from wssdl_bus_amd.rpn_msr.anchor_target_layer_tf_bus import anchor_target_layer_joint  # noqa: E402
 from wssdl_bus_amd.utils.cython_bbox import bbox_overlaps  # noqa: E402
 from wssdl_bus_amd.utils.cython_bbox_ui import bbox_overlaps_ui  # noqa: E402
 
@@ -97,6 +98,30 @@ for k in range(args.cases):
         for j in range(5):
             a, e = np.asarray(g_[j]), w_[j]
             ok_pt = ok_pt and a.shape == e.shape and (ulp(a, e).max() <= 4 if j == 2 and a.size else np.array_equal(a, e))
+    # combined mode: the first n_s images supervised, the others weak (rois appended only / all-ignore anchor labels)
+    n_s = int(rs.randint(1, Ni + 1))
+    old_ims = (cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.WS_IMS_PER_BATCH)
+    cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.WS_IMS_PER_BATCH = n_s, Ni - n_s
+    oc = dict(IMS_PER_BATCH=n_s, WS_IMS_PER_BATCH=Ni - n_s)
+    try:
+        for tr in (True, False):
+            w_ = O.proposal_target_layer_joint(rois, gts, ngs, 3, tr, rng=np.random.RandomState(seed), cfg=oc)
+            g_ = proposal_target_layer_joint(rois, gts, ngs, 3, tr, rng=np.random.RandomState(seed))
+            for j in range(5):
+                a, e = np.asarray(g_[j]), w_[j]
+                ok_pt = ok_pt and a.shape == e.shape and (ulp(a, e).max() <= 4 if j == 2 and a.size else np.array_equal(a, e))
+        iis = np.repeat(ii, Ni, axis=0)
+        scoreN = np.zeros((Ni, H, W, 18), np.float32)
+        for tr in (True, False):
+            sc_in = scoreN if tr else scoreN[:n_s]
+            w_ = O.anchor_target_layer_joint(sc_in, gts[:len(sc_in)], ngs[:len(sc_in)], iis[:len(sc_in)], None, tr, (16,), (8, 16, 32), ds,
+                                             rng=np.random.RandomState(seed), cfg=oc)
+            g_ = anchor_target_layer_joint(sc_in, gts[:len(sc_in)], ngs[:len(sc_in)], iis[:len(sc_in)], None, tr, [16], [8, 16, 32], ds,
+                                           rng=np.random.RandomState(seed))
+            ok = ok and np.array_equal(np.asarray(g_[0]), w_[0]) and ulp(g_[1], w_[1]).max() <= 1 and \
+                np.array_equal(np.asarray(g_[2]), w_[2]) and np.array_equal(np.asarray(g_[3]), w_[3])
+    finally:
+        cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.WS_IMS_PER_BATCH = old_ims
     if not (ok and ok_iou and ok_pt):
         bad += 1
         print("MISMATCH case %d map %dx%d image %dx%d gt %d %s: anchor targets %s, IoU %s, proposal targets %s" % (k, H, W, im_h, im_w, n, ds, ok, ok_iou, ok_pt), flush=True)
