@@ -51,16 +51,21 @@ for k in range(args.cases):
     fused = [x.grad.clone() for x in (rpn_cls, rpn_box, cls, box)]
     for x in (rpn_cls, rpn_box, cls, box):
         x.grad = None
+    # the chain of torch ops the op replaces, in f64 under autograd: the yardstick for the gradients (the same chain in f32
+    # computes the label's component as p - 1, which cancels when p -> 1)
+    d = [x.detach().double().requires_grad_(True) for x in (rpn_cls, rpn_box, cls, box)]
     n, h, w, c = rpn_cls.shape
-    reshaped = rpn_cls.permute(0, 3, 1, 2).reshape(n, 2, A * h, w).permute(0, 2, 3, 1)
-    ref = torch.stack([TB.rpn_cls_loss(reshaped, rpn_data[0]), TB.rpn_box_loss(rpn_box, rpn_data, n_sup),
-                       TB.rcnn_cls_loss(cls, roi_data[1]), TB.rcnn_box_loss(box, roi_data)])
-    (ref * wts).sum().backward()
+    reshaped = d[0].permute(0, 3, 1, 2).reshape(n, 2, A * h, w).permute(0, 2, 3, 1)
+    rd64 = tuple(t.double() if t.is_floating_point() else t for t in rpn_data)
+    ro64 = tuple(t.double() if t.is_floating_point() else t for t in roi_data)
+    ref = torch.stack([TB.rpn_cls_loss(reshaped, rd64[0]), TB.rpn_box_loss(d[1], rd64, n_sup),
+                       TB.rcnn_cls_loss(d[2], ro64[1]), TB.rcnn_box_loss(d[3], ro64)])
+    (ref * wts.double()).sum().backward()
     ok_g = True
-    for f, x in zip(fused, (rpn_cls, rpn_box, cls, box)):
+    for f, x in zip(fused, d):
         g = x.grad
         scale = float(g.abs().max().clamp_min(1e-30))
-        ok_g = ok_g and float((f - g).abs().max()) <= 2e-5 * scale + 1e-12
+        ok_g = ok_g and float((f.double() - g).abs().max()) <= 2e-5 * scale + 1e-12
     if not (ok_v and ok_g):
         bad += 1
         print("MISMATCH case %d N %d map %dx%d A %d rows %d of %d weak_from %s pad %d: values %s (%s vs %s) gradients %s" % (
