@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random NMS cases, product (wssdl_nms / wssdl_nms_new through hip_nms) against the C oracle's keep lists (and the reference's own Cython build, oracle/_ref, when present): sizes 1 ... 13000
+"""Random NMS cases, product (wssdl_nms / wssdl_nms_new through hip_nms) against the C oracle's keep lists (and the reference's own Cython build, oracle/_ref, when present): sizes 1 ... 26000 (beyond 20480 boxes: the general sweep instead of the pipelined one)
 (not multiples of 64 on purpose), tight clusters, duplicates, degenerate boxes, thresholds 0.05 ... 0.95, max_keep cuts.
 Scores are distinct (the order of equal scores is the product's own rule, tested elsewhere).
     python3 tools/nms_fuzz.py [--cases 400] [--seed 0]"""
@@ -21,7 +21,7 @@ args = ap.parse_args()
 rs = np.random.RandomState(args.seed)
 bad = n_ref = 0
 for k in range(args.cases):
-    n = int(rs.choice([1, 2, 63, 64, 65, 127, 129, 300, 1000, 2047, 2049, 4097, 6000, 9001, 12000, 13000])) if k % 3 else int(rs.randint(1, 13001))
+    n = int(rs.choice([1, 2, 63, 64, 65, 127, 129, 300, 1000, 2047, 2049, 4097, 6000, 9001, 12000, 13000, 20480, 20481, 26000])) if k % 3 else int(rs.randint(1, 13001))
     kind = k % 5
     spread = [1000.0, 300.0, 100.0, 30.0, 600.0][kind]
     c = rs.uniform(0, spread, size=(n, 2)) * [1.0, 0.6]
