@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--check", action="store_true",
                     help="before timing: the pair's outputs on this RoI set against the C oracle, bit for bit "
                          "(one supervised and one weak image; tests/test_gpu_roi_compact.py)")
+    ap.add_argument("--rois", default="", metavar="PATH.npy", help="another RoI set (float32 [R,5]) instead of the fixed one")
+    ap.add_argument("--map", default="38,63,1024", help="H,W,C of the feature map the set belongs to")
     args = ap.parse_args()
     import torch
     assert torch.cuda.is_available()
@@ -136,12 +138,13 @@ def main():
         from test_gpu_roi_compact import roofline_set_parity
         checked, plans = roofline_set_parity(torch)
         print(json.dumps(dict(check="top, argmax, bottom_diff == C oracle", rois_per_image=checked, plans=plans)))
-    rois, tag = load_rois()
+    rois, tag = load_rois(args.rois) if args.rois else load_rois()
     if args.roi_bwd_plan >= 0:
         from wssdl_bus_amd import _lib
         _lib.set_tuning("roi_bwd_plan", args.roi_bwd_plan)
     N = int(rois[:, 0].max()) + 1
-    ops, meta = run(rois, N, 38, 63, 1024, args.iters, args.warmup)
+    H, W, C = (int(v) for v in args.map.split(","))
+    ops, meta = run(rois, N, H, W, C, args.iters, args.warmup)
     print(json.dumps(dict(roi_set=tag, meta=meta, ops=ops)))
 
 
