@@ -352,10 +352,10 @@ WSSDL_API int wssdl_roi_pool_backward_compact(const float *top_diff, const uint8
  * result on every run, every element within 1e-6 of ..._backward_compact relative to its own sum of |terms|
  * (measured ~2e-8) and the tensor within 1e-5 of its scale (north_star's tolerance for RoI pooling), not
  * bit-identical to it.  segments = 1 is the exact walk.
- * wssdl_roi_pool_backward_split_segments suggests a count by launch shape (8; 4 for two images with exactly 2048
- * (image, channel) pairs, where the gain is the larger tiles' fewer re-read bytes; or 1 = keep the exact walk: more
- * than 4 images, fewer than 1000 RoIs per image, or more (image, channel) pairs than that -- enough waves that the
- * chains no longer bind); wssdl_roi_pool_backward_split_plan = the plan to prepare the lists with for the split form
+ * wssdl_roi_pool_backward_split_segments suggests a count by launch shape (8; 4 for two images with 2048 and for
+ * three images with up to 3072 (image, channel) pairs, where the gain is the larger tiles' fewer re-read bytes; or
+ * 1 = keep the exact walk: more than 4 images, fewer than 1000 RoIs per image, or more (image, channel) pairs than
+ * that -- enough waves that the chains no longer bind); wssdl_roi_pool_backward_split_plan = the plan to prepare the lists with for the split form
  * (set "roi_bwd_plan" to it around ..._backward_prepare: large tiles, since the chains no longer matter); same
  * workspace as ..._backward_compact. */
 WSSDL_API int wssdl_roi_pool_backward_split_segments(int R, int N, int H, int W, int C);

@@ -282,7 +282,9 @@ def test_split_walk_is_deterministic_and_within_1e6_of_the_oracle(torch_cuda):
     assert L.wssdl_roi_pool_backward_split_segments(4128, 3, 37, 62, 512) == 8        # VGG-16, 1 + 2 images
     assert L.wssdl_roi_pool_backward_split_segments(2000, 1, 38, 63, 1024) == 8       # one weak image
     assert L.wssdl_roi_pool_backward_split_segments(4000, 2, 38, 63, 1024) == 4       # alternating weak step: 8x8 tiles' fewer bytes
-    assert L.wssdl_roi_pool_backward_split_segments(8000, 4, 38, 63, 1024) == 1       # more than 2048 (image, channel) pairs
+    assert L.wssdl_roi_pool_backward_split_segments(4128, 3, 38, 63, 1024) == 4       # 1 + 2 images on a ResNet
+    assert L.wssdl_roi_pool_backward_split_segments(8000, 4, 38, 63, 1024) == 1       # four images x 1024 channels: exact walk
+    assert L.wssdl_roi_pool_backward_split_segments(4000, 4, 38, 63, 512) == 1
     assert L.wssdl_roi_pool_backward_split_segments(8512, 8, 38, 63, 1024) == 1       # the default workload: exact walk
     assert L.wssdl_roi_pool_backward_split_segments(256, 2, 38, 63, 256) == 1
     assert L.wssdl_roi_pool_backward_split_scratch_bytes(3, 37, 62, 512, 4) == 3 * 3 * 37 * 62 * 512 * 4

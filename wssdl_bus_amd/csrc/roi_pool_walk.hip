@@ -629,13 +629,18 @@ static int walk_plan_choice(int N, int H, int W, int C) {
 // get 4 segments for the bytes the larger tiles save (see below); more than 2048 (image, channel) pairs: the exact walk.  Beyond the chain the launch is bound by the bytes neighbouring tiles
 // re-read (windows of 4.4 x 4.5 cells against 8 x 8 tiles: 2 x), which no segment count changes.
 int walk_split_segments(int R, int N, int H, int W, int C) {
-    if (N < 1 || N > 4 || (C & 3) || (long long)R < 1000LL * N || (long long)N * C > 2048) return 1;
+    if (N < 1 || N > 4 || (C & 3) || (long long)R < 1000LL * N || (long long)N * C > 3072) return 1;
     // exactly 2048 pairs (two weak images x 1024 channels, the alternating mode's weak step): with the small RoIs of one
     // saved set the exact walk on 4x4 tiles tied (0.306-0.315 ms against 0.289-0.31 inside the roofline leg), with the
     // larger ones other runs of the same untrained network propose (21 x 17 cells instead of 13 x 12) it loses to the
     // split form's 8x8 tiles: 0.40 against 0.328 (4 segments) / 0.339 (8) -- tools/probes/alter_leg_split.py
     // (measured for two images; four images x 512 channels keep the exact walk)
-    if ((long long)N * C == 2048) return N <= 2 ? 4 : 1;
+    // 2049 .. 3072 pairs = three images x 1024 channels (the reference's default 1 + 2 batch on a ResNet): 4 segments tie with
+    // the exact walk on the default set's small RoIs (0.312 against 0.315 ms) and win on 24 x 24-cell ones (0.425 against
+    // 0.4825; 8 segments 0.418 there but 0.336 on the small ones); four images x 1024 channels: the exact walk wins (0.50-0.61
+    // against 0.54-0.60) -- profiles/r04_alter_leg_split.log
+    const long long pairs = (long long)N * C;
+    if (pairs >= 2048) return (N <= 2 || (N == 3 && pairs > 2048)) ? 4 : 1;
     return 8;
 }
 // the plan the split form wants (chains no longer matter: larger tiles, fewer re-read bytes)
