@@ -1,6 +1,6 @@
-# long runs of the randomized parity tools (seed 2026), one after the other; logs under gpurun_out/fuzz/
+# long runs of the randomized parity tools (SEED, default 2026), one after the other; logs under gpurun_out/fuzz/
 out=gpurun_out/fuzz; mkdir -p $out
-run() { name=$1; shift; timeout -k 10 1000 python3 tools/$name.py "$@" --seed 2026 > $out/$name.log 2>&1; echo "$name: $(tail -1 $out/$name.log)"; }
+run() { name=$1; shift; timeout -k 10 1000 python3 tools/$name.py "$@" --seed ${SEED:-2026} > $out/$name.log 2>&1; echo "$name: $(tail -1 $out/$name.log)"; }
 run nms_fuzz --cases 2500
 run roi_pool_fuzz --cases 300
 run layers_fuzz --cases 400
