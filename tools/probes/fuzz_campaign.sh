@@ -9,4 +9,5 @@ run image_fuzz --cases 250
 run loss_fuzz --cases 200
 run mil_fuzz --cases 400
 run post_detect_fuzz --cases 200
+run sampler_fuzz --cases 150
 timeout -k 10 600 python3 tools/nms_fused_stress.py --rounds 1500 --busy > $out/nms_fused_stress.log 2>&1; echo "nms_fused_stress: $(tail -1 $out/nms_fused_stress.log)"

@@ -113,10 +113,17 @@ try:
             mo, am = ov.max(axis=1), ov.argmax(axis=1)
             n_fg = min(fg_rpi, int(np.sum(mo >= cfg.TRAIN.FG_THRESH)))
             n_bg = min(rpi - n_fg, int(np.sum((mo < cfg.TRAIN.BG_THRESH_HI) & (mo >= cfg.TRAIN.BG_THRESH_LO))))
+            # the device path keeps the shape fixed: every image owns rois_per_image rows, the ones beyond its quotas are padding
+            # (-1, 0, 0, 0, 0), label -1, zero targets and weights (the reference returns fewer rows for such an image)
+            row = i * rpi
             blk = out_rois[row:row + n_fg + n_bg]
+            pad = slice(row + n_fg + n_bg, row + rpi)
             if blk.shape[0] != n_fg + n_bg or not np.all(blk[:, 0] == i):
-                why.append("roi block of image %d: %d rows, quotas %d + %d" % (i, blk.shape[0], n_fg, n_bg))
+                why.append("roi block of image %d: quotas %d + %d" % (i, n_fg, n_bg))
                 break
+            if not np.all(out_rois[pad, 0] == -1) or out_rois[pad, 1:].any() or not np.all(labels[pad, 0] == -1) or \
+                    tg[pad].any() or inw[pad].any() or outw[pad].any():
+                why.append("padding rows of image %d" % i)
             have = collections.Counter(tuple(r) for r in cand.tolist())
             drawn = collections.Counter(tuple(r) for r in blk.tolist())
             if any(drawn[t] > have.get(t, 0) for t in drawn):
@@ -146,9 +153,8 @@ try:
                     break
             if tg[row + n_fg:row + n_fg + n_bg].any():
                 why.append("bg rows carry targets (image %d)" % i)
-            row += n_fg + n_bg
-        if not why and row != out_rois.shape[0]:
-            why.append("row count %d against %d" % (out_rois.shape[0], row))
+        if not why and out_rois.shape[0] != Ni * rpi:
+            why.append("row count %d against %d" % (out_rois.shape[0], Ni * rpi))
         if why:
             bad += 1
             print("MISMATCH case %d map %dx%d gt %d images %d: %s" % (k, H, W, n, Ni, "; ".join(why[:3])), flush=True)
