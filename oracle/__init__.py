@@ -1,6 +1,7 @@
 """CPU oracle for the wssdl_bus detection hot path -- TEST INFRASTRUCTURE ONLY.
 
-Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+Only tests/ (incl. the checking scripts under tools/ that tests/test_gpu_fuzz.py and ``tools/roofline_leg.py --check``
+run: they compare, they are never measured or shipped), ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
 may import this package, and only as the checker.  The product package
 ``wssdl_bus_amd`` never imports it.
 
