@@ -493,6 +493,7 @@ def main():
         # dominant kernel = the single-kernel launch of the leg with the largest average duration
         # (roi_pool_backward = the walk kernel alone; its list-building prepare step, like the
         # proposal / target layers, is a chain of small latency-bound kernels: per_kernel only)
+        # (bin-owner form of the backward: "roi_pool_backward" = its walk + the halo merge, two kernels, one op)
         single = [k for k in ("roi_pool_forward", "roi_pool_backward") if k in leg]
         dom = max(single, key=lambda k: leg[k]["avg_ms"])
         d = leg[dom]
@@ -531,7 +532,7 @@ def main():
             fixed_set={k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                        for k, v in leg.items()},
             per_kernel={k: dict(avg_ms=round(v["avg_ms"], 4), calls=v["calls"],
-                                kernels=1 if k in ("roi_pool_forward", "roi_pool_backward") else "chain",
+                                kernels=(1 if k in ("roi_pool_forward", "roi_pool_backward") else "chain"),
                                 GBps=round(sum(alg_bytes(k, m) for m in v["metas"]) / v["calls"]
                                            / (v["avg_ms"] * 1e-3) / 1e9, 1))
                         for k, v in tl.items()})

@@ -366,6 +366,25 @@ WSSDL_API int wssdl_roi_pool_backward_compact_split(const float *top_diff, const
                             int pooled_w, float spatial_scale, int rounding, float *bottom_diff,
                             void *workspace, size_t workspace_bytes, int plan, int segments,
                             void *scratch, size_t scratch_bytes, wssdl_stream_t stream);
+/* Bin-owner form of the list-driven backward (round 5): DETERMINISTIC BUT NOT BIT-ORDERED, like the split form.
+ * The exact walk lists a bin in every tile its window touches, so the launch reads top_diff / the codes ~1.5 x.  Here a
+ * wave accumulates into a region that reaches past its tile (a halo of 1-3 cells) and a bin is listed once, by the tile
+ * of its window's first cell (windows larger than the region continue in the next tile); the halos go to `scratch` and a
+ * second kernel adds them to their owners in a fixed order (own, left, upper, upper-left).  Same result on every run;
+ * the f32 sum per element is associated differently from roi_pooling_op_gpu.cu.cc:132-186, within the split form's
+ * bounds.  Call ..._owner_prepare (instead of ..._backward_prepare; same workspace size) with the owner plan, then
+ * ..._compact_owner with the same plan.  ..._owner_plan suggests a plan by launch shape, -1 = keep the exact walk. */
+WSSDL_API int wssdl_roi_pool_backward_owner_plan_count(void);
+WSSDL_API int wssdl_roi_pool_backward_owner_plan(int R, int N, int H, int W, int C);
+WSSDL_API size_t wssdl_roi_pool_backward_owner_scratch_bytes(int N, int H, int W, int C, int owner_plan);
+WSSDL_API int wssdl_roi_pool_backward_owner_prepare(const float *rois, int R, int N, int H, int W, int C,
+                            int pooled_h, int pooled_w, float spatial_scale, int rounding,
+                            void *workspace, size_t workspace_bytes, int owner_plan, wssdl_stream_t stream);
+WSSDL_API int wssdl_roi_pool_backward_compact_owner(const float *top_diff, const uint8_t *argmax8,
+                            const float *rois, int R, int N, int H, int W, int C, int pooled_h,
+                            int pooled_w, float spatial_scale, int rounding, float *bottom_diff,
+                            void *workspace, size_t workspace_bytes, int owner_plan,
+                            void *scratch, size_t scratch_bytes, wssdl_stream_t stream);
 WSSDL_API int wssdl_roi_argmax_expand(const uint8_t *argmax8, const float *rois, int R, int H, int W,
                             int C, int pooled_h, int pooled_w, float spatial_scale, int rounding,
                             int32_t *argmax, wssdl_stream_t stream);

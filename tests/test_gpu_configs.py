@@ -31,10 +31,10 @@ def cfg_guard():
     """Restores the cfg switches the tests below flip."""
     from wssdl_bus_amd.fast_rcnn.config import cfg
     old = (cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.WS_IMS_PER_BATCH, cfg.SAMPLING_RNG, cfg.ROI_POOL_ROUNDING,
-           cfg.FUSED_RPN_SOFTMAX, cfg.ROI_POOL_BWD_SPLIT)
+           cfg.FUSED_RPN_SOFTMAX, cfg.ROI_POOL_BWD_SPLIT, cfg.ROI_POOL_BWD_OWNER, cfg.ROI_POOL_BWD_EXACT)
     yield cfg
     (cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.WS_IMS_PER_BATCH, cfg.SAMPLING_RNG, cfg.ROI_POOL_ROUNDING,
-     cfg.FUSED_RPN_SOFTMAX, cfg.ROI_POOL_BWD_SPLIT) = old
+     cfg.FUSED_RPN_SOFTMAX, cfg.ROI_POOL_BWD_SPLIT, cfg.ROI_POOL_BWD_OWNER, cfg.ROI_POOL_BWD_EXACT) = old
 
 
 def _np(t):
@@ -189,9 +189,9 @@ def test_config4_resnet50_weak_step(torch_cuda, cfg_guard):
     from wssdl_bus_amd.networks.factory_bus import get_network
     cfg.SAMPLING_RNG = "device"
     # the bit-for-bit comparison is the exact walk's contract; this launch shape (2 images x 1024 channels, >= 1000 RoIs
-    # each) would otherwise take the split form, which is checked against the same oracle at its own tolerance below
-    assert cfg.ROI_POOL_BWD_SPLIT == "auto"
-    cfg.ROI_POOL_BWD_SPLIT = 0
+    # each) would otherwise take the bin-owner form, which is checked against the same oracle at its own tolerance below
+    assert cfg.ROI_POOL_BWD_SPLIT == "auto" and cfg.ROI_POOL_BWD_OWNER == "auto" and not cfg.ROI_POOL_BWD_EXACT
+    cfg.ROI_POOL_BWD_EXACT = True
     torch.manual_seed(4)
     net = get_network("Resnet_train_alter", 50).cuda().to(memory_format=torch.channels_last)
     net.train()
@@ -217,19 +217,24 @@ def test_config4_resnet50_weak_step(torch_cuda, cfg_guard):
     dense = torch.randn(top.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(44))
     want = c_oracle.roi_pool_backward(_np(dense), ea, _np(rois), tuple(feat.shape), 7, 7, 1.0 / 16)
     assert np.array_equal(_np(grad_fn(dense)), want)
-    # the default setting on the same inputs: the split walk (4 segments), deterministic, within north_star's 1e-5 of the
-    # gradient's scale of the oracle's ordered sum
+    # the default setting on the same inputs: the bin-owner walk (owner plan 0; the split form with 4 segments when the
+    # owner form is switched off), both deterministic and within north_star's 1e-5 of the gradient's scale of the
+    # oracle's ordered sum
     from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
-    cfg.ROI_POOL_BWD_SPLIT = "auto"
-    assert op.split_segments(tuple(feat.shape), R) == 4
-    f2 = feat.detach().contiguous().requires_grad_(True)
-    top2, _ = op.RoiPoolFunction.apply(f2, rois, 7, 7, 1.0 / 16, None)
-    assert torch.equal(top2, top)
-    g_a, = torch.autograd.grad(top2, f2, dense, retain_graph=True)
-    g_b, = torch.autograd.grad(top2, f2, dense)
-    assert torch.equal(g_a, g_b)
-    assert np.abs(_np(g_a) - want).max() <= 1e-5 * np.abs(want).max()
-    cfg.ROI_POOL_BWD_SPLIT = 0
+    cfg.ROI_POOL_BWD_EXACT = False
+    assert op.owner_plan(tuple(feat.shape), R) == 0 and op.split_segments(tuple(feat.shape), R) == 4
+    for owner_key, want_variant in (("auto", "bin-owner"), (-1, "split walk, 4")):
+        cfg.ROI_POOL_BWD_OWNER = owner_key
+        assert op.prepare_backward(tuple(feat.shape), rois, 7, 7, 1.0 / 16).variant.startswith(want_variant)
+        f2 = feat.detach().contiguous().requires_grad_(True)
+        top2, _ = op.RoiPoolFunction.apply(f2, rois, 7, 7, 1.0 / 16, None)
+        assert torch.equal(top2, top)
+        g_a, = torch.autograd.grad(top2, f2, dense, retain_graph=True)
+        g_b, = torch.autograd.grad(top2, f2, dense)
+        assert torch.equal(g_a, g_b)
+        assert np.abs(_np(g_a) - want).max() <= 1e-5 * np.abs(want).max()
+    cfg.ROI_POOL_BWD_OWNER = "auto"
+    cfg.ROI_POOL_BWD_EXACT = True
     # the oracle's MIL loss on the step's own logits
     want_mil = O.multi_task_loss_alter_weak({"roi-data": (_np(rois),), "im_info": _np(blobs["im_info"]),
                                              "cls_score": _np(L["cls_score"])}, 2, solver.global_step)

@@ -338,6 +338,113 @@ def test_split_walk_is_deterministic_and_within_1e6_of_the_oracle(torch_cuda):
             cfg.ROI_POOL_BWD_SPLIT = "auto"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 38, 63, 256), (3, 38, 63, 1024), (1, 63, 100, 1024), (1, 37, 62, 512),
+                                   (2, 38, 63, 96), (5, 20, 30, 64), (1, 20, 30, 2048), (2, 12, 17, 4096),
+                                   (1, 25, 40, 768)])
+@pytest.mark.parametrize("mode", ["cuda", "cpu"])
+def test_owner_walk_vs_oracle(torch_cuda, shape, mode):
+    """wssdl_roi_pool_backward_compact_owner (round 5): every bin listed by ONE tile (the tile of its window's first
+    cell; a window larger than the tile's region continues in the next tile), halos merged in a fixed order.  On the
+    shapes of test_compact_pair_vs_oracle, every owner plan:
+      * integer-valued top_diff (every partial sum exact in f32): bit-equal to the oracle -- each (bin, cell) pair
+        is applied exactly once, with the reference's in_roi / candidate tests (roi_pooling_op_gpu.cu.cc:141-186);
+      * real-valued top_diff: the same bits on every run, every element within 1e-6 of the oracle relative to its
+        own sum of |terms|, the tensor within north_star's 1e-5 of its scale."""
+    torch = torch_cuda
+    from wssdl_bus_amd import _lib
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    N, H, W, C = shape
+    rs = np.random.RandomState(H * 1000 + C + 7)
+    f = np.maximum(rs.normal(size=shape), 0).astype(np.float32)
+    R = 300 if C >= 512 else 500
+    rois = _rois_for(rs, R, N, H, W)
+    # many small RoIs as well (windows of 1-3 cells: the owned case) next to _rois_for's large ones (chains)
+    small = rois[: R // 2].copy()
+    small[:, 3:] = small[:, 1:3] + rs.uniform(8, 260, (len(small), 2))
+    rois = np.ascontiguousarray(np.concatenate([rois, small.astype(np.float32)])[rs.permutation(R + len(small))])
+    R = len(rois)
+    et, ea = c_oracle.roi_pool_forward(f, rois, 7, 7, 1.0 / 16, mode, threads=16)
+    ft, rt = torch.from_numpy(f).cuda(), torch.from_numpy(rois).cuda()
+    top, arg8 = op.roi_pool_compact(ft, rt, 7, 7, 1.0 / 16, rounding=mode)
+    assert np.array_equal(top.cpu().numpy(), et)
+    ints = rs.randint(-8, 9, size=et.shape).astype(np.float32)
+    real = rs.normal(size=et.shape).astype(np.float32)
+    want_i = c_oracle.roi_pool_backward(ints, ea, rois, f.shape, 7, 7, 1.0 / 16)
+    want_r = c_oracle.roi_pool_backward(real, ea, rois, f.shape, 7, 7, 1.0 / 16)
+    mag = c_oracle.roi_pool_backward(np.abs(real), ea, rois, f.shape, 7, 7, 1.0 / 16)
+    scale = float(np.abs(want_r).max())
+    it, rl = torch.from_numpy(ints).cuda(), torch.from_numpy(real).cuda()
+    n_plans = _lib.lib().wssdl_roi_pool_backward_owner_plan_count()
+    assert n_plans >= 4
+    for owner in range(n_plans):
+        plan = op.roi_pool_grad_prepare_owner(shape, rt, 7, 7, 1.0 / 16, owner, rounding=mode)
+        got = op.roi_pool_grad_compact(shape, rt, arg8, it, 7, 7, 1.0 / 16, rounding=mode, plan=plan).cpu().numpy()
+        assert np.array_equal(got, want_i), (shape, mode, owner, int((got != want_i).sum()))
+        a = op.roi_pool_grad_compact(shape, rt, arg8, rl, 7, 7, 1.0 / 16, rounding=mode, plan=plan)
+        b = op.roi_pool_grad_compact(shape, rt, arg8, rl, 7, 7, 1.0 / 16, rounding=mode, plan=plan)
+        assert torch.equal(a, b), (shape, mode, owner)
+        a = a.cpu().numpy()
+        assert np.all(np.abs(a - want_r) <= 1e-6 * mag + 1e-30), (shape, mode, owner)
+        assert np.abs(a - want_r).max() <= 1e-5 * scale, (shape, mode, owner)
+        assert not op.flags_raised()
+
+
+def test_owner_rule_and_autograd(torch_cuda):
+    """Which launches the library sends to the bin-owner form (wssdl_roi_pool_backward_owner_plan; measured in
+    tools/owner_ab.sh) and the autograd pair under cfg.ROI_POOL_BWD_OWNER / _EXACT."""
+    torch = torch_cuda
+    from wssdl_bus_amd import _lib
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    L = _lib.lib()
+    assert L.wssdl_roi_pool_backward_owner_plan(8512, 8, 38, 63, 1024) == 0      # the default workload
+    assert L.wssdl_roi_pool_backward_owner_plan(4000, 2, 38, 63, 1024) == 0      # alternating weak step
+    assert L.wssdl_roi_pool_backward_owner_plan(4128, 3, 38, 63, 1024) == 0      # the reference's default 1 + 2 batch
+    assert L.wssdl_roi_pool_backward_owner_plan(4128, 3, 37, 62, 512) == 1       # VGG-16: 4x4 tiles
+    assert L.wssdl_roi_pool_backward_owner_plan(2000, 1, 38, 63, 1024) == 1
+    assert L.wssdl_roi_pool_backward_owner_plan(4000, 2, 38, 63, 256) == -1      # ResNet-18: the split form
+    assert L.wssdl_roi_pool_backward_owner_plan(1024, 8, 38, 63, 1024) == -1     # supervised-only step: the exact walk
+    assert L.wssdl_roi_pool_backward_owner_plan(300, 1, 63, 100, 1024) == -1
+    assert L.wssdl_roi_pool_backward_owner_plan(8512, 8, 38, 63, 96) == -1       # C % 128 != 0
+    nscr = L.wssdl_roi_pool_backward_owner_scratch_bytes(8, 38, 63, 1024, 0)
+    assert nscr == 8 * 10 * 13 * 6 * 7 * 1024 * 4                                 # tiles of 4 x 5 cells, regions of 6 x 7
+    rs = np.random.RandomState(33)
+    N, H, W, C = 2, 38, 63, 512
+    R = 2400
+    f_np = np.maximum(rs.normal(size=(N, H, W, C)), 0).astype(np.float32)
+    ctr = rs.normal([500, 300], [200, 120], size=(R, 2))
+    wh = np.exp(rs.normal(np.log(200), 0.5, size=(R, 2)))
+    rois_np = np.concatenate([(np.arange(R) % N)[:, None], np.clip(ctr - wh / 2, 0, None),
+                              np.minimum(ctr + wh / 2, [991, 591])], axis=1).astype(np.float32)
+    rois_np = rois_np[np.argsort(rois_np[:, 0], kind="stable")]
+    want_t, want_a = c_oracle.roi_pool_forward(f_np, rois_np, 7, 7, 1.0 / 16, "cuda", threads=16)
+    w_np = rs.normal(size=want_t.shape).astype(np.float32)
+    want_g = c_oracle.roi_pool_backward(w_np, want_a, rois_np, f_np.shape, 7, 7, 1.0 / 16)
+    mag = c_oracle.roi_pool_backward(np.abs(w_np), want_a, rois_np, f_np.shape, 7, 7, 1.0 / 16)
+    scale = float(np.abs(want_g).max())
+    ft, rt, wt = torch.from_numpy(f_np).cuda(), torch.from_numpy(rois_np).cuda(), torch.from_numpy(w_np).cuda()
+    assert cfg.ROI_POOL_BWD_OWNER == "auto" and not cfg.ROI_POOL_BWD_EXACT and op.owner_plan((N, H, W, C), R) == 1
+    saved = (cfg.ROI_POOL_BWD_OWNER, cfg.ROI_POOL_BWD_EXACT)
+    try:
+        for owner, exact, bits in (("auto", False, False), (0, False, False), ("auto", True, True), (-1, False, False)):
+            cfg.ROI_POOL_BWD_OWNER, cfg.ROI_POOL_BWD_EXACT = owner, exact
+            grads = []
+            for _ in range(2):
+                f = ft.clone().requires_grad_(True)
+                t, _ = op.RoiPoolFunction.apply(f, rt, 7, 7, 1.0 / 16, None)
+                assert np.array_equal(t.detach().cpu().numpy(), want_t)
+                (t * wt).sum().backward()
+                grads.append(f.grad)
+            assert torch.equal(grads[0], grads[1])
+            g = grads[0].cpu().numpy()
+            assert np.all(np.abs(g - want_g) <= 1e-6 * mag + 1e-30) and np.abs(g - want_g).max() <= 1e-5 * scale
+            assert np.array_equal(g, want_g) or not bits
+    finally:
+        cfg.ROI_POOL_BWD_OWNER, cfg.ROI_POOL_BWD_EXACT = saved
+    assert not op.flags_raised()
+
+
 def test_compact_full_size_properties(torch_cuda):
     """BASELINE config 3 size (R = 4*128 + 4*2000 = 8512, C = 1024, 8 images 38x63): the compact pair
     equals the i32 pair bit for bit (which test_gpu_parity.py checks against the oracle by

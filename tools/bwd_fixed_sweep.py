@@ -51,6 +51,10 @@ def main():
                     "exact walk; > 1 is compared with it by the largest difference relative to max |bottom_diff|)")
     ap.add_argument("--i32", action="store_true", help="time wssdl_roi_pool_backward_ws (i32 arg-max, prepare + walk in "
                     "one call) per plan instead of the 1-byte pair; checked against the tile-owner kernel's result")
+    ap.add_argument("--owner", default="", help="owner plans (bin-owner form, wssdl_roi_pool_backward_compact_owner) to time "
+                    "after the exact plans, e.g. 0,1,4: checked against plan 11 by the largest difference relative to "
+                    "max |bottom_diff| and for repeatability")
+    ap.add_argument("--one-owner", default="", help="like --one for an owner plan (the form to put under rocprofv3 --pmc)")
     ap.add_argument("--dup", type=int, default=1, help="repeat the set's images DUP times as further images (N x DUP images, "
                     "R x DUP RoIs): time(DUP = 2) - time(DUP = 1) is the bulk rate without the launch's ramp and tail")
     ap.add_argument("--denormals", action="store_true",
@@ -108,6 +112,13 @@ def main():
             assert same, p
         _lib.set_tuning("roi_bwd_plan", -1)
         return
+    if args.one_owner:
+        plan = op.roi_pool_grad_prepare_owner(shape, rois, 7, 7, 1.0 / 16, int(args.one_owner))
+        for _ in range(5):
+            op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan)
+        torch.cuda.synchronize()
+        print(json.dumps(dict(one_owner=args.one_owner, R=R, C=C)))
+        return
     if args.one:
         plan = run(int(args.one))
         for _ in range(5):
@@ -138,6 +149,19 @@ def main():
                                   equal_to_plan11=same, max_diff_over_max_abs=rel, repeatable=repeatable,
                                   moved_TBps=round(mb / ms / 1e9, 3), frac_moved=round(mb / ms / 1e9 / 8.0, 3))), flush=True)
             assert repeatable and (same if seg == 1 else rel <= 1e-5), (p, seg)
+    for o in (int(x) for x in args.owner.split(",") if x != ""):
+        plan = op.roi_pool_grad_prepare_owner(shape, rois, 7, 7, 1.0 / 16, o)
+        ms_prep = timeit(lambda: op.roi_pool_grad_prepare_owner(shape, rois, 7, 7, 1.0 / 16, o), 10)
+        got = op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan)
+        rel = float((got - ref).abs().max()) / scale
+        again = op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan)
+        repeatable = bool(torch.equal(got, again))
+        del got, again
+        ms = timeit(lambda: op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan), args.iters)
+        print(json.dumps(dict(owner=o, walk_plus_merge_ms=round(ms, 4), prepare_ms=round(ms_prep, 4),
+                              max_diff_over_max_abs=rel, repeatable=repeatable,
+                              moved_TBps=round(mb / ms / 1e9, 3), frac_moved=round(mb / ms / 1e9 / 8.0, 3))), flush=True)
+        assert repeatable and rel <= 1e-5, o
     assert not op.flags_raised()
 
 

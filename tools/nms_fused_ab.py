@@ -30,11 +30,11 @@ prob, pred = synth_rpn(N, 38, 63, 9, 3)
 pred = pred * args.pred_scale
 ref = None
 for rep in range(2):
-    for fused in (0, 1):
-        with _lib.tuned(nms_fused=fused):
+    for fused, sparse in ((0, 0), (1, 0), (1, 8), (1, 16), (1, 24), (1, 64)):
+        with _lib.tuned(nms_fused=fused, nms_sparse=sparse):
             out = proposal_layer_padded(prob, pred, info, True)
             if ref is None:
                 ref = [t.clone() for t in out]
             assert all(torch.equal(a, b) for a, b in zip(out, ref))
             ms = timeit(lambda: proposal_layer_padded(prob, pred, info, True), args.iters, warmup=5)
-        print(json.dumps(dict(nms_fused=fused, proposal_layer_ms=round(ms, 4), images=N, pred_scale=args.pred_scale, nms_thresh=args.nms_thresh, kept=[int(v) for v in out[1].tolist()])))
+        print(json.dumps(dict(nms_fused=fused, nms_sparse=sparse, proposal_layer_ms=round(ms, 4), images=N, pred_scale=args.pred_scale, nms_thresh=args.nms_thresh, kept=[int(v) for v in out[1].tolist()])))

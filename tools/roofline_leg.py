@@ -85,14 +85,14 @@ def run(rois_np, N, H, W, C, iters=20, warmup=3, seed=3):
         else:
             top, arg = op.roi_pool(feat, rois, 7, 7, 1.0 / 16)
         diff = torch.randn(top.shape, device=dev, generator=g)
-        segs = op.split_segments(shape, R) if compact else 1
-        plan = op.roi_pool_grad_prepare(shape, rois, 7, 7, 1.0 / 16, segments=segs) if compact else None
+        plan = op.prepare_backward(shape, rois, 7, 7, 1.0 / 16) if compact else None
+        segs = plan.segments if compact else 1
 
         def one():
             if compact:
                 op.roi_pool_compact(feat, rois, 7, 7, 1.0 / 16)
-                p = op.roi_pool_grad_prepare(shape, rois, 7, 7, 1.0 / 16, segments=segs)
-                return op.roi_pool_grad_compact(shape, rois, arg, diff, 7, 7, 1.0 / 16, plan=p, segments=segs)
+                p = op.prepare_backward(shape, rois, 7, 7, 1.0 / 16)
+                return op.roi_pool_grad_compact(shape, rois, arg, diff, 7, 7, 1.0 / 16, plan=p, segments=p.segments)
             op.roi_pool(feat, rois, 7, 7, 1.0 / 16)
             return op.roi_pool_grad(feat, rois, arg, diff, 7, 7, 1.0 / 16)
         for _ in range(warmup):
@@ -114,8 +114,8 @@ def run(rois_np, N, H, W, C, iters=20, warmup=3, seed=3):
             out[name]["min_moved_bytes"] = moved_bytes(name, N, H, W, C, R)
     meta = dict(N=N, H=H, W=W, C=C, R=R, argmax_bytes=1 if compact else 4,
                 backward_plan=(plan.plan if plan is not None else None),
-                backward_variant=("exact walk: the reference's summation order, bit for bit" if segs <= 1 else
-                                  "split walk, %d segments: deterministic, not bit-ordered (<= 1e-6 of the exact walk)" % segs),
+                backward_owner_plan=(plan.owner if plan is not None else None),
+                backward_variant=(plan.variant if plan is not None else "i32 pair"),
                 backward_segments=segs, kernel_source_id=kernel_source_id())
     return out, meta
 

@@ -37,10 +37,58 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _digest(paths, extra=""):
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for q in paths:
+        with open(q, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def _compile_one(args):
+    src, obj, flags, verbose = args
+    cmd = [hipcc()] + flags + ["-c", src, "-o", obj + ".tmp"]
+    if verbose:
+        print("[wssdl_bus_amd] " + " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(obj + ".tmp", obj)
+    return obj
+
+
+def compile_objects(sources, headers, flags, verbose=True, jobs=None):
+    """One object per source under csrc/_obj/ (git- and gpurun-ignored), named by a digest of the source, the
+    headers and the flags: only what changed is recompiled, and the files compile in parallel."""
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in flags if f != "-shared"]
+    hdrs = [os.path.join(CSRC, h) for h in headers]
+    todo, objs = [], []
+    for s in sources:
+        src = os.path.join(CSRC, s)
+        tag = _digest([src] + hdrs, " ".join(cflags))
+        obj = os.path.join(objdir, "%s.%s.o" % (os.path.basename(s), tag))
+        objs.append(obj)
+        if not os.path.exists(obj):
+            for old in os.listdir(objdir):
+                if old.startswith(os.path.basename(s) + "."):
+                    os.remove(os.path.join(objdir, old))
+            todo.append((src, obj, cflags, verbose))
+    jobs = jobs or int(os.environ.get("WSSDL_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
+        list(ex.map(_compile_one, todo))
+    return objs
+
+
 def build(force=False, verbose=True):
     if not force and not is_stale():
         return OUT
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp"]
+    if force:
+        import shutil
+        shutil.rmtree(os.path.join(CSRC, "_obj"), ignore_errors=True)
+    objs = compile_objects(SOURCES, HEADERS, FLAGS, verbose)
+    cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-fvisibility=hidden"] + objs + ["-o", OUT + ".tmp"]
     if verbose:
         print("[wssdl_bus_amd] " + " ".join(cmd))
     subprocess.check_call(cmd)

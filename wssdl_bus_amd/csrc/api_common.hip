@@ -17,11 +17,13 @@ static int *tuning_field(const char *key) {
     if (!key) return nullptr;
     Tuning &t = g_tuning;
     if (!strcmp(key, "roi_bwd_plan")) return &t.roi_bwd_plan;
+    if (!strcmp(key, "roi_bwd_owner")) return &t.roi_bwd_owner;
     if (!strcmp(key, "roi_fwd_variant")) return &t.roi_fwd_variant;
     if (!strcmp(key, "roi_bwdc_variant")) return &t.roi_bwdc_variant;
     if (!strcmp(key, "roi_bwd_cg")) return &t.roi_bwd_cg;
     if (!strcmp(key, "nms_one_pass")) return &t.nms_one_pass;
     if (!strcmp(key, "nms_fused")) return &t.nms_fused;
+    if (!strcmp(key, "nms_sparse")) return &t.nms_sparse;
     if (!strcmp(key, "nms_fused_fault")) return &t.nms_fused_fault;
     if (!strcmp(key, "topk_sort")) return &t.topk_sort;
     return nullptr;

@@ -44,6 +44,7 @@ inline int load_base_anchors(const double *host, int A, BaseAnchors *out) {
 // environment.  Defaults = automatic choices.
 struct Tuning {
     int roi_bwd_plan = -1;      // plan id of the list-driven RoI-pool backward (-1: by launch size)
+    int roi_bwd_owner = -1;     // owner plan id of the bin-owner backward that wssdl_roi_pool_backward_owner_plan suggests (-1: its rule)
     int roi_fwd_variant = 0;    // shape of the compact RoI-pool forward (0: automatic)
     int roi_bwdc_variant = 0;   // shape of the tile-owner fallback backward
     int roi_bwd_cg = 0;         // channels per workgroup of the fallback backwards (0: automatic)
@@ -51,6 +52,8 @@ struct Tuning {
     int topk_sort = 1;          // order of the proposal candidates: 1 sorted runs + cross ranks (order_sort.hip),
                                 //    0 the select + sample sort of nms.hip
     int nms_fused = 1;          // 0: mask and sweep of a one-pass NMS as two launches instead of the fused one
+    int nms_sparse = 16;        // fused launch: far column segments of a row block the sweep has resolved are computed for its kept rows
+                                //    only when it kept at most this many of its 64 boxes (0: never)
     int nms_fused_fault = 0;    // fault injection (tests): > 0 = the fused launch withholds image 0's segment counts
                                 //    and its sweep gives up after this many microseconds -> roi count -1
 };

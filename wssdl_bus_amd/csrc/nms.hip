@@ -350,6 +350,10 @@ struct MaskArgs {
     // 0: the rule of cpu_nms.pyx / utils/nms.pyx `nms` (ovr >= thresh); 1: utils/nms.pyx:118-121 `nms_new`
     // (ovr >= thresh or inter / area_i > 0.95 or inter / area_j > 0.95)
     int rule;
+    // fused launch: keptpub[(img * ncb + chunk) * 2 + h] = half h of the chunk's kept bitmask | (chunk + 1) << 32, written
+    // by the image's sweep once the chunk is resolved (zeroed by the launcher); NULL otherwise
+    const unsigned long long *keptpub;
+    int sparse_max;       // most kept boxes of a row block for which the kept-rows form is taken
 };
 
 // COHERENT: the words are read by a sweep that runs beside this kernel, possibly on another XCD (whose
@@ -360,6 +364,105 @@ template <bool COHERENT>
 __device__ __forceinline__ void nms_store_word(unsigned long long *p, unsigned long long v) {
     if (COHERENT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
+}
+
+// Round 5: rows of KEPT boxes only.  Greedy NMS consults the rows of kept boxes and nothing else, and in the fused
+// launch the sweep is usually PAST a row block by the time the mask role reaches the block's far column segments
+// (at chunk c the sweep needs columns <= c + 7; segment s of row block rb with 16 s > rb + 4 is computed when the sweep
+// is near chunk 16 s - 8).  The sweep's spare wave publishes every resolved chunk's kept bitmask (`keptpub`); a mask
+// block that finds its row block resolved runs this TRANSPOSED form: column boxes in lanes, a scalar loop over the
+// kept rows (their boxes in this wave's LDS slice, read as broadcasts), the word of (row, column block) = one ballot.
+// ~8 instructions per (kept row, column block) against ~17 per (row, column block) of the dense form, and 10-30 %
+// of the rows are kept.  Same pair arithmetic (cpu_nms.pyx:43-66: every step is symmetric in the two boxes), so the
+// words of kept rows are bit for bit those of the dense form; rows that were not kept get no words and no summary
+// bits -- nothing reads them (the helpers walk the kept list, the dense band next to the diagonal stays dense).
+template <bool COHERENT>
+__device__ __forceinline__ void nms_mask_block_sparse(const MaskArgs &A, int rb, int seg, int img, int wave, int lane, int n,
+                                                      unsigned long long kept, float ix1, float iy1, float ix2, float iy2,
+                                                      float (*rbox_w)[64] /* [5][64] */, nms_float4v *rgeo_w /* [64] */) {
+    const float *__restrict__ b = A.boxes + (size_t)img * A.box_stride_img;
+    const int n_max = A.n_max, ncb = A.ncb;
+    const double thresh = A.thresh;
+    unsigned long long *__restrict__ mask = A.mask, *__restrict__ summ = A.summ;
+    const float t_lo = (float)(thresh * (1.0 - 1e-4)), t_hi = (float)(thresh * (1.0 + 1e-4));
+    const double fq = thresh / (1.0 + thresh);
+    const bool contain = A.rule == 1;
+    const bool prefilter = !contain && thresh >= 0.25 && thresh < 1.0;
+    const float kq = (float)((0.5 - fq) * (1.0 + 1e-3));
+    auto geometry = [&](float x1, float y1, float x2, float y2, bool live) -> nms_float4v {      // as in nms_mask_block
+        float w = x2 - x1;  w = w + 1.0f;
+        float h = y2 - y1;  h = h + 1.0f;
+        const bool sane = w > 0.0f && h > 0.0f;
+        nms_float4v g;
+        g.x = live ? x1 + 0.5f * w : __builtin_nanf("");
+        g.y = y1 + 0.5f * h;
+        g.z = sane ? w * kq + 1e-3f : INFINITY;
+        g.w = sane ? h * kq + 1e-3f : INFINITY;
+        return g;
+    };
+    // the row boxes stay in the lanes' registers (lane = row); a kept row's values reach the scalar registers with
+    // v_readlane (no LDS round trip inside the row loop)
+    const float iarea = box_area_ref(ix1, iy1, ix2, iy2);
+    const nms_float4v ig = geometry(ix1, iy1, ix2, iy2, true);
+    (void)rbox_w;  (void)rgeo_w;
+    auto bcast = [](float v, int r) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r)); };
+    const int cb_first = max(rb, A.cb_min);
+    const int cb_end = min((n + 63) / 64, (seg + 1) * MASK_SEG);
+    for (int cb = max(cb_first, seg * MASK_SEG) + wave; cb < cb_end; cb += MASK_WAVES) {
+        const int col = cb * 64 + lane;
+        const bool col_ok = col < n;
+        float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
+        if (col_ok) {
+            const nms_float4v v = *reinterpret_cast<const nms_float4v *>(b + (size_t)col * 4);
+            x1 = v.x; y1 = v.y; x2 = v.z; y2 = v.w;
+        }
+        const float carea = box_area_ref(x1, y1, x2, y2);
+        const nms_float4v cg = geometry(x1, y1, x2, y2, col_ok);
+        unsigned long long nz = 0ull, todo = kept;
+        while (todo != 0ull) {
+            const int r = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            unsigned long long cand;
+            if (prefilter) {
+                const float dx = cg.x - bcast(ig.x, r), dy = cg.y - bcast(ig.y, r);
+                const float sx = cg.z + bcast(ig.z, r), sy = cg.w + bcast(ig.w, r);
+                cand = __builtin_amdgcn_fcmpf(__builtin_fabsf(dx), sx, 5 /* ole */) &
+                       __builtin_amdgcn_fcmpf(__builtin_fabsf(dy), sy, 5 /* ole */);
+            } else {
+                cand = __ballot(col_ok);
+            }
+            if (cand == 0ull) continue;
+            const float rx1 = bcast(ix1, r), ry1 = bcast(iy1, r), rx2 = bcast(ix2, r), ry2 = bcast(iy2, r), rarea = bcast(iarea, r);
+            bool hit = false;
+            if ((cand >> lane) & 1ull) {
+                const float xx1 = fmax_ref(rx1, x1);
+                const float yy1 = fmax_ref(ry1, y1);
+                const float xx2 = fmin_ref(rx2, x2);
+                const float yy2 = fmin_ref(ry2, y2);
+                float w = xx2 - xx1;  w = fmax0_ref(w + 1.0f);
+                float h = yy2 - yy1;  h = fmax0_ref(h + 1.0f);
+                const float inter = w * h;
+                float den = rarea + carea;
+                den = den - inter;
+                const bool yes = inter > den * t_hi, no = inter < den * t_lo;
+                if (contain) {
+                    hit = ((den > 0.0f) & yes) || (double)(inter / den) >= thresh || (double)(inter / rarea) > 0.95 ||
+                          (double)(inter / carea) > 0.95;
+                } else if ((den > 0.0f) & (yes | no)) {
+                    hit = yes;
+                } else {
+                    hit = (double)(inter / den) >= thresh;
+                }
+                hit = hit && col_ok;
+            }
+            const unsigned long long word = __ballot(hit);
+            if (word != 0ull) {
+                if (lane == 0) nms_store_word<COHERENT>(&mask[((size_t)img * n_max + rb * 64 + r) * ncb + cb], word);
+                nz |= 1ull << r;
+            }
+        }
+        if (summ && lane == 0) nms_store_word<COHERENT>(&summ[((size_t)img * ncb + cb) * ncb + rb], nz);
+    }
 }
 
 template <bool COHERENT>
@@ -388,7 +491,22 @@ __device__ __forceinline__ void nms_mask_block(const MaskArgs &A, int rb, int se
         const nms_float4v v = *reinterpret_cast<const nms_float4v *>(b + (size_t)i * 4);
         ix1 = v.x; iy1 = v.y; ix2 = v.z; iy2 = v.w;
     }
+    // (likewise the kept bitmask of this row block, if the sweep has published it: two tagged halves)
+    unsigned long long kp0 = 0ull, kp1 = 0ull;
+    const bool far = COHERENT && A.keptpub && dense_ahead >= 0 && seg * MASK_SEG > rb + dense_ahead && max(rb, cb_min) <= seg * MASK_SEG;
+    if (far) {
+        kp0 = __hip_atomic_load(A.keptpub + ((size_t)img * ncb + rb) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        kp1 = __hip_atomic_load(A.keptpub + ((size_t)img * ncb + rb) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (fin) return;
+    if (far && (unsigned)(kp0 >> 32) == (unsigned)(rb + 1) && (unsigned)(kp1 >> 32) == (unsigned)(rb + 1)) {
+        const unsigned long long kept = (kp0 & 0xffffffffull) | (kp1 << 32);
+        // (a row loop per kept box pays off while few are kept; a chunk that kept most of its boxes takes the dense form)
+        if (__popcll(kept) <= A.sparse_max) {
+            nms_mask_block_sparse<COHERENT>(A, rb, seg, img, wave, lane, n, kept, ix1, iy1, ix2, iy2, cbox_w, cgeo_w);
+            return;
+        }
+    }
     const float iarea = box_area_ref(ix1, iy1, ix2, iy2);
     const float t_lo = (float)(thresh * (1.0 - 1e-4)), t_hi = (float)(thresh * (1.0 + 1e-4));
     // Prefilter.  ovr >= t  =>  inter >= f (area_i + area_j), f = t / (1 + t); with
@@ -568,7 +686,7 @@ int launch_nms_mask(const float *boxes, int box_stride_img, const int *n_dev, in
     // (the second pass of a two-pass run adds the column blocks >= cb_min to the summary of the first)
     const int ncb_eff = cdiv(min(n_max, n_limit), 64);      // row / column blocks this pass can touch
     const MaskArgs A = {boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, n_limit, cb_min, done,
-                        nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) ? NMS_DENSE_AHEAD : -1, nullptr, 0, rule};
+                        nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) ? NMS_DENSE_AHEAD : -1, nullptr, 0, rule, nullptr, 0};
     hipLaunchKernelGGL(nms_mask_kernel, dim3(ncb_eff, cdiv(ncb_eff, MASK_SEG), n_images), dim3(64 * MASK_WAVES), 0, st, A);
     return check_launch();
 }
@@ -776,6 +894,9 @@ struct SweepArgs {
     // fused run: how long a stager waits for a column segment without progress before it gives up, in ticks of
     // the 100 MHz real-time counter (0.5 s unless the fault-injection knob shortens it)
     unsigned long long wait_ticks;
+    // fused run: where the spare wave publishes the kept bitmask of every resolved chunk for the mask role
+    // (MaskArgs::keptpub); NULL: nobody reads it
+    unsigned long long *keptpub;
 };
 
 // Wait (one wave, before it reads words of column segment `index`) until the mask blocks running beside
@@ -1078,7 +1199,15 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
             }
             count += __popcll(kept);                   // the resolver keeps its own running count
         } else if (role == 4) {
-            // spare
+            // the spare wave (fused launch): chunk c - 1 was resolved an iteration ago -- tell the mask role which of
+            // its boxes survived, so that the far column segments of that row block are computed for those rows only
+            // (nms_mask_block_sparse).  Two tagged 8-byte halves, each atomic on its own: no ordering, no wait.
+            if (A.keptpub && c >= 1 && lane == 0) {
+                const unsigned long long k = sh.pub[(c - 1) & 1].kept, tag = (unsigned long long)c << 32;
+                unsigned long long *kp = A.keptpub + ((size_t)img * ncb + (c - 1)) * 2;
+                __hip_atomic_store(kp, (k & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(kp + 1, (k >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else if (helper) {
 #ifndef WSSDL_SWEEP_NULL_HELPERS      // (timing experiment of the profile build: what the iteration costs without them; wrong keeps)
             if (c & 1) helper_turn(take_b, issue_b, c);
@@ -1239,7 +1368,7 @@ int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *d
     size_t lds = ((size_t)max_keep + 64) * sizeof(int);
     if (nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ)) {
         const SweepArgs S = {mask, diag_t, summ, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
-                             boxes, box_stride_img, rois_padded, n_limit, done_in, done_out, nullptr, 0, 0ull};
+                             boxes, box_stride_img, rois_padded, n_limit, done_in, done_out, nullptr, 0, 0ull, nullptr};
         hipLaunchKernelGGL(nms_sweep_pipelined_kernel, dim3(n_images), dim3(SWEEP_BLOCK), lds, st, S);
         return check_launch();
     }
@@ -1277,7 +1406,8 @@ int nms_probe_size(int n_max, int max_keep) {
 // [n_images * pitch] ints
 size_t nms_summary_alloc_words(int n_images, int n_max) {
     const size_t pitch = (size_t)nms_mask_pitch(n_max);
-    return (size_t)n_images * pitch * pitch + ((size_t)n_images * pitch + 1) / 2;
+    // + [n_images * pitch ints of control words, rounded to 16 bytes] + [n_images][pitch][2] words of published kept bitmasks
+    return (size_t)n_images * pitch * pitch + (((size_t)n_images * pitch + 3) / 4) * 2 + (size_t)n_images * pitch * 2;
 }
 
 // CUs of the current device (asked once per device; 0 when the runtime cannot tell: no fused launch then)
@@ -1300,15 +1430,20 @@ static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n
     const int nseg = cdiv(nrb, MASK_SEG);
     const int fault = tuning().nms_fused_fault;
     int *segdone = reinterpret_cast<int *>(summ + (size_t)n_images * ncb * ncb);
-    // the control words = 0 (the summaries need no initialisation: every entry that is read is written)
-    if (hipMemsetAsync(segdone, 0, sizeof(int) * (size_t)n_images * ncb, st) != hipSuccess) return WSSDL_ERR_LAUNCH;
+    const size_t ctl_words = (((size_t)n_images * ncb + 3) / 4) * 2;
+    unsigned long long *keptpub = summ + (size_t)n_images * ncb * ncb + ctl_words;
+    // the control words and the published kept bitmasks = 0 (the summaries need no initialisation: every entry that
+    // is read is written)
+    if (hipMemsetAsync(segdone, 0, sizeof(unsigned long long) * (ctl_words + (size_t)n_images * ncb * 2), st) != hipSuccess)
+        return WSSDL_ERR_LAUNCH;
+    const bool sparse = tuning().nms_sparse > 0;
     const MaskArgs M = {boxes, box_stride_img, n_dev, n_max, thresh, mask, ncb, diag_t, summ, 0x7fffffff, 0, nullptr,
-                        NMS_DENSE_AHEAD, segdone + ncb - 2, ncb, 0};
+                        NMS_DENSE_AHEAD, segdone + ncb - 2, ncb, 0, sparse ? keptpub : nullptr, tuning().nms_sparse};
     const SweepArgs S = {mask, diag_t, summ, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
                          boxes, box_stride_img, rois_padded, 0x7fffffff, nullptr, nullptr, segdone, nrb,
                          // 0.5 s; wssdl_set_tuning("nms_fused_fault", microseconds) shortens the wait AND withholds
                          // image 0's segment counts: the test of the time-out path
-                         fault > 0 ? (unsigned long long)fault * 100ull : 50000000ull};
+                         fault > 0 ? (unsigned long long)fault * 100ull : 50000000ull, sparse ? keptpub : nullptr};
     const size_t lds_mask = (size_t)(SWEEP_BLOCK / 64) * (5 * 64 * sizeof(float) + 64 * sizeof(nms_float4v));
     SegTable table;
     if (nseg > MASK_MAX_SEGS) return WSSDL_ERR_INVALID_ARGUMENT;

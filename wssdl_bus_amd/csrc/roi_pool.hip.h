@@ -111,5 +111,14 @@ int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, 
                 int nseg = 1, float *partial = nullptr, bool i32 = false /* arg8 points at the i32 arg-max */);
 bool walk_i32_supported(int R, int N, int H, int W, int C, int PH, int PW);
 int walk_split_segments(int R, int N, int H, int W, int C);
+// bin-owner form (round 5): every bin listed by one tile, halos merged afterwards
+int owner_plan_count();
+int owner_plan_auto(int R, int N, int H, int W, int C);
+bool owner_supported(int R, int N, int H, int W, int C, int PH, int PW);
+size_t owner_scratch_bytes(int N, int H, int W, int C, int plan);
+int owner_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, int PW, float scale, int rounding,
+                  void *workspace, size_t workspace_bytes, int plan, hipStream_t st);
+int launch_owner(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH, int PW,
+                 float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, float *halo, hipStream_t st);
 
 }  // namespace wssdl

@@ -200,6 +200,94 @@ __global__ __launch_bounds__(256) void walk_axes_kernel(
     }
 }
 
+// ---- bin-owner form (round 5) ---------------------------------------------------------------------
+// The exact walk lists a bin in EVERY tile its window touches (1.58 x the bins for 6x6 tiles on the default
+// workload: the bytes the launch re-reads).  Here a wave accumulates into a REGION of RN lines that starts at its
+// tile's origin and reaches RN - SN lines into the next tile (tiles repeat every SN lines, SN < RN), and a bin
+// is listed by the FIRST tile whose region can hold it: the tile of its window's first line.  A window that
+// does not fit continues in the tile of its first uncovered line, and so on (a chain; rare: windows are 2-3
+// cells), so every line of a window belongs to exactly one (tile, mask) listing per axis and every
+// (bin, cell) pair is applied once.  What lands outside the tile's own SN x SN cells goes to a halo buffer that
+// walk_merge_kernel adds to the owners in a fixed order: deterministic, NOT the reference's association
+// (roi_pooling_op_gpu.cu.cc:132-186 sums roi^, ph^, pw^ per cell) -- a separate entry point, like the split form.
+__device__ __forceinline__ int win_end_w(int p, float bin, int rs, int limit, int rounding) {
+    const float v = (float)(p + 1) * bin;
+    const int e = (rounding == WSSDL_ROI_ROUND_CPU) ? (int)v : (int)ceilf(v);        // roi_pooling_op.cc:169-170 / _gpu.cu.cc:53-58
+    return min(max(e + rs, 0), limit);
+}
+
+template <int RN, int SN>
+__device__ __forceinline__ AxisEntry axis_entry_own(int T, int limit, int rs, int re, float bin, int P, int rounding) {
+    static_assert(SN >= 1 && SN <= RN && RN <= 8 && RN - SN <= SN, "halo no larger than the tile; 8-bit masks");
+    AxisEntry e;
+    const int t0 = T * SN;
+    int p0, pn;
+    const int t1 = min(t0 + RN, limit) - 1;
+    unsigned long long m;
+    touch_axis<RN, 8>(t0, t1, rs, re, bin, P, p0, pn, m);
+    e.mask = e.info = 0ull;
+    if (pn <= 0 || re < rs) return e;
+    int first = -1, last = -1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        unsigned bits = 0u;
+        if (k < pn) {
+            const int s = win_start_w(p0 + k, bin, rs, limit, rounding), z = win_end_w(p0 + k, bin, rs, limit, rounding);
+            // the chain of listings of this window: u = first line not covered yet
+            int u = s;
+            for (int it = 0; it < 64 && u < z; ++it) {
+                const int t = u / SN;
+                if (t == T) {
+                    const int lo = u - t0, hi = min(z, t0 + RN) - t0;        // lines [lo, hi) of the region
+                    bits = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                    break;
+                }
+                if (t > T) break;
+                u = t * SN + RN;
+            }
+            bits &= (unsigned)(m >> (8 * k)) & 0xffu;
+        }
+        if (bits) { if (first < 0) first = k;  last = k; }
+        m = (m & ~(0xffull << (8 * k))) | ((unsigned long long)bits << (8 * k));
+    }
+    if (first < 0) return e;
+    p0 += first;
+    pn = last - first + 1;
+    e.mask = m >> (8 * first);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int a = min(max(win_start_w(p0 + k, bin, rs, limit, rounding) - t0, -16), 15);
+        e.info |= (unsigned long long)((unsigned)a & 31u) << (5 * k);
+    }
+    e.info |= ((unsigned long long)(unsigned)p0 << 40) | ((unsigned long long)(unsigned)pn << 48);
+    return e;
+}
+
+template <int RH, int RW, int SH, int SW>
+__global__ __launch_bounds__(256) void walk_axes_own_kernel(
+    const float *__restrict__ rois, int R, int N, int H, int W, int PH, int PW, float scale, int rounding,
+    int tiles_h, int tiles_w, unsigned long long *__restrict__ rowtab, unsigned long long *__restrict__ coltab) {
+    const int per = tiles_h + tiles_w;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)R * per) return;
+    const int r = (int)(i / per), a = (int)(i - (long long)r * per);
+    const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, PH, PW);
+    const bool bad = g.batch < 0 || g.batch >= N;
+    AxisEntry e;
+    if (a < tiles_h) {
+        e = axis_entry_own<RH, SH>(a, H, g.sh, g.eh, g.bin_h, PH, rounding);
+        if (bad) e.mask = e.info = 0ull;
+        rowtab[((size_t)r * tiles_h + a) * 2] = e.mask;
+        rowtab[((size_t)r * tiles_h + a) * 2 + 1] = e.info;
+    } else {
+        const int tx = a - tiles_h;
+        e = axis_entry_own<RW, SW>(tx, W, g.sw, g.ew, g.bin_w, PW, rounding);
+        if (bad) e.mask = e.info = 0ull;
+        coltab[((size_t)r * tiles_w + tx) * 2] = e.mask;
+        coltab[((size_t)r * tiles_w + tx) * 2 + 1] = e.info;
+    }
+}
+
 __device__ __forceinline__ int axis_pn(unsigned long long info) { return (int)(info >> 48) & 15; }
 __device__ __forceinline__ int axis_p0(unsigned long long info) { return (int)(info >> 40) & 255; }
 
@@ -369,7 +457,7 @@ __device__ __forceinline__ SlotRec spread_rec(unsigned v, bool valid, unsigned t
     return r;
 }
 
-template <int CPL, bool I32>
+template <int CPL, bool I32, int AUX = 0 /* cache policy bits of the data loads (gfx950: 1 = sc0, 2 = nt, 16 = sc1) */>
 __device__ __forceinline__ void issue_rec(SlotData<CPL> &d, const SlotRec &r, __amdgpu_buffer_rsrc_t ra,
                                           __amdgpu_buffer_rsrc_t rt, int voff8, int voff) {
 #pragma unroll
@@ -377,21 +465,21 @@ __device__ __forceinline__ void issue_rec(SlotData<CPL> &d, const SlotRec &r, __
         if (I32) {
             if (CPL == 2) {
                 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-                const uint2v a = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(ra, voff, (int)(r.lo[s] << 2), 0));
+                const uint2v a = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(ra, voff, (int)(r.lo[s] << 2), AUX));
                 d.a[s][0] = a.x;  d.a[s][1] = a.y;
-                const float2v t = __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(rt, voff, (int)(r.lo[s] << 2), 0));
+                const float2v t = __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(rt, voff, (int)(r.lo[s] << 2), AUX));
                 d.td[s][0] = t.x;  d.td[s][CPL - 1] = t.y;
             } else {
-                d.a[s][0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ra, voff, (int)(r.lo[s] << 2), 0);
-                d.td[s][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, voff, (int)(r.lo[s] << 2), 0));
+                d.a[s][0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ra, voff, (int)(r.lo[s] << 2), AUX);
+                d.td[s][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, voff, (int)(r.lo[s] << 2), AUX));
             }
         } else if (CPL == 2) {
-            d.a[s][0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(ra, voff8, (int)r.lo[s], 0);
-            const float2v t = __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(rt, voff, (int)(r.lo[s] << 2), 0));
+            d.a[s][0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(ra, voff8, (int)r.lo[s], AUX);
+            const float2v t = __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(rt, voff, (int)(r.lo[s] << 2), AUX));
             d.td[s][0] = t.x;  d.td[s][CPL - 1] = t.y;
         } else {
-            d.a[s][0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(ra, voff8, (int)r.lo[s], 0);
-            d.td[s][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, voff, (int)(r.lo[s] << 2), 0));
+            d.a[s][0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(ra, voff8, (int)r.lo[s], AUX);
+            d.td[s][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, voff, (int)(r.lo[s] << 2), AUX));
         }
     }
 }
@@ -442,13 +530,15 @@ __device__ __forceinline__ void process_rec(const SlotData<CPL> &d, const SlotRe
     }
 }
 
-template <int TH, int TW, int DEPTH, int MINW, int CPL, bool I32>
+template <int TH, int TW, int DEPTH, int MINW, int CPL, bool I32, bool OWN = false, int AUX = 0>
 __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
     const float *__restrict__ top_diff, const unsigned char *__restrict__ arg8 /* I32: the i32 arg-max */,
     const unsigned *__restrict__ slots, const int *__restrict__ tile_off, const int *__restrict__ tile_slots,
     const int *__restrict__ order, int items, int tiles_w, int tiles, int G, int H, int W, int C,
     unsigned total_elems, float *__restrict__ bottom_diff, int nseg, float *__restrict__ partial,
-    unsigned long long seg_stride, WalkI32 q) {
+    unsigned long long seg_stride, WalkI32 q, int own_sh, int own_sw) {
+    // OWN (bin-owner form): TH x TW is the wave's REGION; tiles repeat every own_sh x own_sw cells; `partial` is the
+    // halo buffer [items][TH * TW][C] (region cells outside the tile's own cells; walk_merge_kernel adds them up)
     static_assert(TH <= 8 && TW <= 8 && DEPTH >= 2 && DEPTH <= 4, "8-bit masks; 2..4 records in flight");
     __shared__ float acc[(TH * TW + 1) * CPL * 64];
     // blockIdx -> (position k in the launch order, channel group g).  Workgroups are dealt
@@ -475,7 +565,7 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
     const int item = order[k];
     const int n = item / tiles, tile = item - n * tiles;
     const int ty = tile / tiles_w, tx = tile - ty * tiles_w;
-    const int h0 = ty * TH, w0 = tx * TW;
+    const int h0 = ty * (OWN ? own_sh : TH), w0 = tx * (OWN ? own_sw : TW);
     const int lane = threadIdx.x;
     const int c0 = g * (64 * CPL) + CPL * lane;
     const bool lane_ok = c0 < C;
@@ -506,7 +596,7 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
 #pragma unroll
     for (int j = 0; j < DEPTH - 1; ++j) {
         r[j] = spread_rec(fetch_rec(rp, j, nrec, lane), j < nrec, total_elems);
-        issue_rec<CPL, I32>(d[j], r[j], ra, rt, voff8, voff);
+        issue_rec<CPL, I32, (AUX & 31)>(d[j], r[j], ra, rt, voff8, voff);
     }
     unsigned pending = fetch_rec(rp, DEPTH - 1, nrec, lane);
     for (int i = 0; i < nrec; i += DEPTH) {
@@ -515,29 +605,76 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
             const int x = (j + DEPTH - 1) % DEPTH;
             const unsigned next = fetch_rec(rp, i + j + DEPTH, nrec, lane);
             r[x] = spread_rec(pending, i + j + DEPTH - 1 < nrec, total_elems);
-            issue_rec<CPL, I32>(d[x], r[x], ra, rt, voff8, voff);
+            issue_rec<CPL, I32, (AUX & 31)>(d[x], r[x], ra, rt, voff8, voff);
             process_rec<TH, TW, CPL, I32>(d[j], r[j], acc, lane, lane_ok, q, h0, w0, W);
             pending = next;
         }
     }
 
     if (lane_ok) {
-        float *img = (seg == 0 ? bottom_diff : partial + (size_t)(seg - 1) * seg_stride) +
+        float *img = ((OWN || seg == 0) ? bottom_diff : partial + (size_t)(seg - 1) * seg_stride) +
                      (size_t)n * H * W * C;
+        float *halo = OWN ? partial + (size_t)item * (TH * TW) * C : nullptr;
 #pragma unroll
         for (int i = 0; i < TH * TW; ++i) {
             const int h = h0 + i / TW, w = w0 + i % TW;
             if (h < H && w < W) {
+                float *dst = img + ((size_t)h * W + w) * C + c0;
+                if (OWN && (i / TW >= own_sh || i % TW >= own_sw)) dst = halo + (size_t)i * C + c0;
                 if (CPL == 2) {
                     float2v o;
                     o.x = acc[(i * CPL) * 64 + lane];
                     o.y = acc[(i * CPL + CPL - 1) * 64 + lane];
-                    *reinterpret_cast<float2v *>(img + ((size_t)h * W + w) * C + c0) = o;
+                    if (AUX & 64) __builtin_nontemporal_store(o, reinterpret_cast<float2v *>(dst));
+                    else *reinterpret_cast<float2v *>(dst) = o;
                 } else {
-                    img[((size_t)h * W + w) * C + c0] = acc[i * 64 + lane];
+                    if (AUX & 64) __builtin_nontemporal_store(acc[i * 64 + lane], dst);
+                    else *dst = acc[i * 64 + lane];
                 }
             }
         }
+    }
+}
+
+// bin-owner form: bottom_diff (the tiles' own cells, written by the walk) += the halos of the left, upper and
+// upper-left neighbours, in that order.  One thread = 4 channels of one cell that can receive a halo (the first
+// RH - SH rows and RW - SW columns of a tile); the other cells are final after the walk.
+__global__ __launch_bounds__(256) void walk_merge_kernel(float *__restrict__ bottom_diff, const float *__restrict__ halo,
+                                                          int H, int W, int C4, int tiles_h, int tiles_w, int RH, int RW,
+                                                          int SH, int SW) {
+    const int HH = RH - SH, HW = RW - SW;
+    const int ncell = SH * SW - (SH - HH) * (SW - HW);          // receiving cells per tile
+    const int item = blockIdx.x;
+    const int tiles = tiles_h * tiles_w;
+    const int n = item / tiles, tile = item - n * tiles;
+    const int ty = tile / tiles_w, tx = tile - ty * tiles_w;
+    const size_t reg = (size_t)RH * RW * C4;                     // float4 per item of the halo buffer
+    const float4v *hb = reinterpret_cast<const float4v *>(halo);
+    float4v *out = reinterpret_cast<float4v *>(bottom_diff) + (size_t)n * H * W * C4;
+    // blockIdx.y = receiving cell: the first HH rows whole, then the first HW columns of the other rows
+    const int cell = blockIdx.y;
+    if (cell >= ncell) return;
+    int lh, lw;
+    if (cell < HH * SW) { lh = cell / SW;  lw = cell - lh * SW; }
+    else { const int j = cell - HH * SW;  lh = HH + j / HW;  lw = j - (j / HW) * HW; }
+    const int h = ty * SH + lh, w = tx * SW + lw;
+    if (h >= H || w >= W) return;
+    const bool left = lw < HW && tx > 0, up = lh < HH && ty > 0;
+    for (int c = threadIdx.x; c < C4; c += 256) {
+        float4v v = out[((size_t)h * W + w) * C4 + c];
+        if (left) {
+            const float4v a = hb[(size_t)(item - 1) * reg + (size_t)(lh * RW + lw + SW) * C4 + c];
+            v.x = v.x + a.x;  v.y = v.y + a.y;  v.z = v.z + a.z;  v.w = v.w + a.w;
+        }
+        if (up) {
+            const float4v a = hb[(size_t)(item - tiles_w) * reg + (size_t)((lh + SH) * RW + lw) * C4 + c];
+            v.x = v.x + a.x;  v.y = v.y + a.y;  v.z = v.z + a.z;  v.w = v.w + a.w;
+        }
+        if (left && up) {
+            const float4v a = hb[(size_t)(item - tiles_w - 1) * reg + (size_t)((lh + SH) * RW + lw + SW) * C4 + c];
+            v.x = v.x + a.x;  v.y = v.y + a.y;  v.z = v.z + a.z;  v.w = v.w + a.w;
+        }
+        out[((size_t)h * W + w) * C4 + c] = v;
     }
 }
 
@@ -770,12 +907,12 @@ static int launch_walk_t(const float *top_diff, const unsigned char *arg8, int R
         hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<TH, TW, DEPTH, MINW, CPL, true>), dim3((unsigned)blocks, (unsigned)nseg),
                            dim3(64), 0, st, top_diff, arg8, reinterpret_cast<const unsigned *>(ws.slots), ws.tile_off,
                            ws.tile_slots, ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff, nseg, partial,
-                           seg_stride, q);
+                           seg_stride, q, TH, TW);
     }
     if (!i32)
     hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<TH, TW, DEPTH, MINW, CPL, false>), dim3((unsigned)blocks, (unsigned)nseg), dim3(64),
                        0, st, top_diff, arg8, reinterpret_cast<const unsigned *>(ws.slots), ws.tile_off, ws.tile_slots,
-                       ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff, nseg, partial, seg_stride, q);
+                       ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff, nseg, partial, seg_stride, q, TH, TW);
     if (nseg > 1) {
         const long long n4 = (long long)(seg_stride / 4);          // C is even and walk_split_supported asks C % 4 == 0
         hipLaunchKernelGGL(walk_combine_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, bottom_diff, partial, n4,
@@ -793,6 +930,137 @@ int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, 
         case ID: return launch_walk_t<ID, TH, TW, D, MW, CPL>(top_diff, arg8, R, N, H, W, C, PH, PW, bottom_diff, workspace, \
                                                          workspace_bytes, st, nseg, partial, i32);
         WSSDL_WALK_PLANS(WSSDL_X)
+#undef WSSDL_X
+        default: return WSSDL_ERR_INVALID_ARGUMENT;
+    }
+}
+
+
+// ---- bin-owner form: plans, prepare, launch ----------------------------------------------------
+//   X(id, region h, region w, tile h, tile w, records in flight, waves per SIMD asked for, channels per lane, cache policy: bits 0-4 of the data loads (gfx950: 1 = sc0, 2 = nt, 16 = sc1), 64 = non-temporal stores)
+#define WSSDL_OWNER_PLANS(X) \
+    X(0, 6, 7, 4, 5, 2, 1, 2, 66)  /* the default: 128-channel waves, 21.5 KiB of LDS (7 waves per CU), halo 2 x 2 */ \
+    X(1, 6, 6, 4, 4, 2, 2, 2, 66)  /* at the exact walk's LDS (18.5 KiB) */ \
+    X(2, 8, 8, 6, 6, 3, 2, 1, 66)  /* 64-channel waves, 16.25 KiB: the fewest bytes (1.20 x moved) */ \
+    X(3, 7, 8, 5, 6, 2, 2, 1, 66)  \
+    X(4, 6, 6, 4, 4, 2, 2, 2, 0)   /* plan 1 with plain loads and stores (the A/B of the cache policy) */ \
+    X(5, 7, 7, 5, 5, 2, 1, 2, 66)  /* 25 KiB: 6 waves per CU */ \
+    X(6, 5, 5, 4, 4, 2, 2, 2, 66)  /* halo 1: 13.3 KiB, 12 waves per CU */ \
+    X(7, 6, 7, 5, 5, 2, 1, 2, 66)  /* halo 1 x 2 */
+
+struct OwnerPlan {
+    int rh, rw, sh, sw, depth, minw, cpl;
+};
+static const OwnerPlan kOwnerPlans[] = {
+#define WSSDL_X(ID, RH, RW, SH, SW, D, MW, CPL, AUX) {RH, RW, SH, SW, D, MW, CPL},
+    WSSDL_OWNER_PLANS(WSSDL_X)
+#undef WSSDL_X
+};
+constexpr int OWNER_PLANS = sizeof(kOwnerPlans) / sizeof(kOwnerPlans[0]);
+
+int owner_plan_count() { return OWNER_PLANS; }
+
+// Which launches take the owner form (-1: keep the exact walk / the split form).  Measured on subsets and copies of the
+// default workload's fixed RoI set (tools/owner_ab.sh, profiles/r05_owner_ab.log; exact = the faster of plans 11 / 13 / 23,
+// split = its best segment count):
+//   8 images x 1024 channels (the default launch)  exact 0.52   owner 0.47 (plan 0)      16 images: 1.01 -> 0.96
+//   8 x 512                                         exact 0.34   owner 0.24               8 x 2048: 1.00 -> 0.95
+//   4 weak + 1 / 4 weak / 4 sup + 2 weak x 1024     0.51 / 0.51 / 0.34 -> 0.43 / 0.42 / 0.27
+//   2 weak x 1024 (alternating mode's weak step)    split 0.29   owner 0.22
+//   1 + 2 images x 1024 (reference's default batch) split 0.31   owner 0.23
+//   1 + 2 x 512 (VGG-16) / 1 weak x 1024            split 0.18 / 0.16   owner 0.17 / 0.16 (plan 1: 4x4 tiles)
+//   2 weak x 256 (ResNet-18)                        split 0.10   owner 0.16   -> not taken
+//   2 supervised images (R = 256)                   exact 0.03   owner 0.04   -> not taken
+int owner_plan_auto(int R, int N, int H, int W, int C) {
+    const int v = tuning().roi_bwd_owner;
+    if (v >= 0 && v < OWNER_PLANS) return v;
+    if (v < -1) return -1;                                       // -2: never (tools, A/B runs)
+    const long long pairs = (long long)N * C;
+    if (R < 1536 || N < 1 || (C & 127) || pairs < 1024) return -1;
+    return pairs >= 2048 ? 0 : 1;
+}
+
+bool owner_supported(int R, int N, int H, int W, int C, int PH, int PW) {
+    return walk_supported(R, N, H, W, C, PH, PW) && (C & 3) == 0;
+}
+
+size_t owner_scratch_bytes(int N, int H, int W, int C, int plan) {
+    if (plan < 0 || plan >= OWNER_PLANS || N < 1 || H < 1 || W < 1 || C < 1) return 0;
+    const OwnerPlan &p = kOwnerPlans[plan];
+    return (size_t)N * cdiv(H, p.sh) * cdiv(W, p.sw) * p.rh * p.rw * (size_t)C * sizeof(float);
+}
+
+template <int RH, int RW, int SH, int SW>
+static int prepare_own_t(const float *rois, int R, int N, int H, int W, int C, int PH, int PW, float scale,
+                         int rounding, void *workspace, size_t workspace_bytes, hipStream_t st) {
+    const int tiles_h = cdiv(H, SH), tiles_w = cdiv(W, SW), tiles = tiles_h * tiles_w;
+    const int items = N * tiles;
+    const long long cap = walk_record_bound(R, N, H, W, PH, PW, SH, SW);      // a chain lists a bin no more often than the exact form
+    WalkWs ws;
+    if (carve_walk(workspace, R, N, tiles_h, tiles_w, cap, &ws) > workspace_bytes) return WSSDL_ERR_WORKSPACE;
+    const unsigned total_elems = (unsigned)((long long)R * PH * PW * C);
+    hipError_t e = hipMemsetAsync(ws.img_span, 0, (char *)ws.tile_slots - (char *)ws.img_span, st);
+    if (e != hipSuccess) { set_last_error(e);  return WSSDL_ERR_LAUNCH; }
+    if (R > 0) {
+        hipLaunchKernelGGL(walk_span_kernel, dim3(cdiv(R, 256)), dim3(256), 0, st, rois, R, N, ws.img_span);
+        hipLaunchKernelGGL((walk_axes_own_kernel<RH, RW, SH, SW>), dim3(cdiv((long long)R * (tiles_h + tiles_w), 256)),
+                           dim3(256), 0, st, rois, R, N, H, W, PH, PW, scale, rounding, tiles_h, tiles_w, ws.rowtab, ws.coltab);
+    }
+    hipLaunchKernelGGL(walk_count_kernel, dim3(items), dim3(FILL_BLOCK), 0, st, rois, R, tiles_h, tiles_w,
+                       ws.img_span, ws.rowtab, ws.coltab, ws.tile_slots);
+    hipLaunchKernelGGL(walk_order_kernel, dim3(1), dim3(1024), 0, st, ws.tile_slots, items, ws.tile_off, ws.order,
+                       ws.total);
+    hipLaunchKernelGGL(walk_fill_kernel, dim3(items), dim3(FILL_BLOCK), 0, st, rois, C, PW, PH * PW, R, tiles_h,
+                       tiles_w, ws.img_span, ws.rowtab, ws.coltab, ws.tile_off, ws.tile_slots, ws.slots, cap,
+                       total_elems, ws.total);
+    return check_launch();
+}
+
+int owner_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, int PW, float scale, int rounding,
+                  void *workspace, size_t workspace_bytes, int plan, hipStream_t st) {
+    switch (plan) {
+#define WSSDL_X(ID, RH, RW, SH, SW, D, MW, CPL, AUX) \
+        case ID: return prepare_own_t<RH, RW, SH, SW>(rois, R, N, H, W, C, PH, PW, scale, rounding, workspace, workspace_bytes, st);
+        WSSDL_OWNER_PLANS(WSSDL_X)
+#undef WSSDL_X
+        default: return WSSDL_ERR_INVALID_ARGUMENT;
+    }
+}
+
+template <int RH, int RW, int SH, int SW, int DEPTH, int MINW, int CPL, int AUX>
+static int launch_owner_t(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH,
+                          int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, float *halo, hipStream_t st) {
+    const int tiles_h = cdiv(H, SH), tiles_w = cdiv(W, SW), tiles = tiles_h * tiles_w;
+    const int items = N * tiles;
+    WalkWs ws;
+    if (carve_walk(workspace, R, N, tiles_h, tiles_w, walk_record_bound(R, N, H, W, PH, PW, SH, SW), &ws) > workspace_bytes)
+        return WSSDL_ERR_WORKSPACE;
+    const unsigned total_elems = (unsigned)((long long)R * PH * PW * C);
+    const int G = cdiv(C, 64 * CPL);
+    long long blocks;
+    if ((G & 7) == 0) blocks = (long long)items * G;
+    else if (G < 8 && (8 % G) == 0) blocks = 8LL * cdiv(items, 8 / G);
+    else blocks = (long long)items * G;
+    if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
+    WalkI32 q = {0, 0u, 0u};
+    hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<RH, RW, DEPTH, MINW, CPL, false, true, AUX>), dim3((unsigned)blocks, 1u), dim3(64),
+                       0, st, top_diff, arg8, reinterpret_cast<const unsigned *>(ws.slots), ws.tile_off, ws.tile_slots,
+                       ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff, 1, halo, 0ull, q, SH, SW);
+    constexpr int HH = RH - SH, HW = RW - SW;
+    constexpr int ncell = SH * SW - (SH - HH) * (SW - HW);
+    if (ncell > 0)
+        hipLaunchKernelGGL(walk_merge_kernel, dim3((unsigned)items, (unsigned)ncell), dim3(256), 0, st, bottom_diff, halo, H, W,
+                           C / 4, tiles_h, tiles_w, RH, RW, SH, SW);
+    return check_launch();
+}
+
+int launch_owner(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH, int PW,
+                 float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, float *halo, hipStream_t st) {
+    switch (plan) {
+#define WSSDL_X(ID, RH, RW, SH, SW, D, MW, CPL, AUX) \
+        case ID: return launch_owner_t<RH, RW, SH, SW, D, MW, CPL, AUX>(top_diff, arg8, R, N, H, W, C, PH, PW, bottom_diff, workspace, \
+                                                                workspace_bytes, halo, st);
+        WSSDL_OWNER_PLANS(WSSDL_X)
 #undef WSSDL_X
         default: return WSSDL_ERR_INVALID_ARGUMENT;
     }

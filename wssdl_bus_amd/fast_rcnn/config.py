@@ -110,6 +110,17 @@ __C.ROI_POOL_FLAG_CHECK = "deferred"
 # associates each element's f32 sum differently from the reference (within ~1e-7 of it; north_star's tolerance
 # for RoI pooling is 1e-5); the parity tests of the gradient run the exact walk.
 __C.ROI_POOL_BWD_SPLIT = 'auto'
+# RoI-pool backward of the training path on train-sized launches (>= 2048 RoIs, >= 1024 (image, channel) pairs): the
+# bin-owner form (round 5: every bin read once by the tile of its window's first cell, halos merged in a fixed order;
+# 10-25 % faster than the exact walk, deterministic, within ~1e-6 of the reference's ordered sum).  'auto' = the
+# library's rule (wssdl_roi_pool_backward_owner_plan), an int = that owner plan, -1 = never.  Takes precedence over
+# the split form.
+__C.ROI_POOL_BWD_OWNER = 'auto'
+# True: the backward is ALWAYS the exact walk -- the reference's f32 summation order (roi, ph, pw), bit for bit
+# (roi_pooling_op_gpu.cu.cc:132-186) -- whatever the two keys above say.  The default training gradient is
+# tolerance-parity (north_star: 1e-5; measured <= 1e-6 of the tensor's scale), not bit-parity; every forward output
+# and every integer result is bit-exact in both settings.
+__C.ROI_POOL_BWD_EXACT = False
 __C.PADDED_ROIS = False
 # a13: the four supervised loss terms and their gradients as one device op (csrc/loss.hip) when the
 # layers are on the GPU; False = the chain of torch ops in fast_rcnn/train_bus.py

@@ -244,8 +244,10 @@ class BackwardPlan(object):
     and the plan id the walk kernel must be launched with (-1: no lists, the backward filters
     the RoIs itself)."""
 
-    def __init__(self, workspace, nbytes, plan):
-        self.workspace, self.nbytes, self.plan = workspace, nbytes, plan
+    def __init__(self, workspace, nbytes, plan, owner=-1):
+        # owner >= 0: the lists were built for that plan of the bin-owner form (roi_pool_grad_prepare_owner)
+        self.workspace, self.nbytes, self.plan, self.owner = workspace, nbytes, plan, owner
+        self.segments, self.variant = 1, "exact walk: the reference's summation order, bit for bit"
 
 
 def roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scale, rounding=None, segments=1):
@@ -274,12 +276,68 @@ def roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scal
     return BackwardPlan(ws, nws, int(plan.value))
 
 
+def owner_plan(shape, R):
+    """The owner plan the bin-owner form of the list-driven backward should use for this launch, or -1 to keep
+    the exact walk: cfg.ROI_POOL_BWD_OWNER = 'auto' (the library's rule by launch shape), an int plan id, or -1 / False
+    for never.  >= 0 is deterministic but NOT bit-identical to the reference's summation order (like the split form)."""
+    v = cfg.get("ROI_POOL_BWD_OWNER", "auto")
+    N, H, W, C = shape
+    if cfg.get("ROI_POOL_BWD_EXACT", False):
+        return -1
+    if v == "auto":
+        return int(_lib.lib().wssdl_roi_pool_backward_owner_plan(int(R), N, H, W, C))
+    if v is False or v is None:
+        return -1
+    return int(v)
+
+
+def roi_pool_grad_prepare_owner(shape, rois, pooled_height, pooled_width, spatial_scale, owner, rounding=None):
+    """Lists of the bin-owner form (every bin listed once, by the tile of its window's first cell)."""
+    N, H, W, C = shape
+    mode = _ROUNDING[cfg.ROI_POOL_ROUNDING if rounding is None else rounding]
+    L = _lib.lib()
+    R = rois.shape[0]
+    with torch.cuda.device(rois.device):
+        nws = L.wssdl_roi_pool_backward_workspace_bytes(R, N, H, W, int(pooled_height), int(pooled_width))
+        ws = torch.empty((nws,), dtype=torch.uint8, device=rois.device)
+        with _lib.timed("roi_pool_backward_prepare", dict(N=N, H=H, W=W, C=C, R=R, owner=int(owner))):
+            _lib.check(L.wssdl_roi_pool_backward_owner_prepare(
+                _lib.ptr(rois), R, N, H, W, C, int(pooled_height), int(pooled_width), float(spatial_scale),
+                mode, _lib.ptr(ws), nws, int(owner), _lib.stream()), "wssdl_roi_pool_backward_owner_prepare")
+            off = L.wssdl_roi_pool_backward_status_offset(R, N, H, W, int(pooled_height), int(pooled_width))
+            _flags(rois.device).flags[1:2].bitwise_or_(ws[off + 4:off + 8].view(torch.int32))
+    return BackwardPlan(ws, nws, -1, owner=int(owner))
+
+
+def prepare_backward(shape, rois, pooled_height, pooled_width, spatial_scale, rounding=None):
+    """The lists of the form the backward of this launch will take (cfg.ROI_POOL_BWD_EXACT / _OWNER / _SPLIT): the
+    bin-owner form where the library suggests it, else the split form where it suggests that, else the exact walk.
+    The returned plan carries `.variant` (a description for logs and bench lines) and `.segments`."""
+    R = rois.shape[0]
+    own = owner_plan(shape, R)
+    if own >= 0:
+        plan = roi_pool_grad_prepare_owner(shape, rois, pooled_height, pooled_width, spatial_scale, own, rounding)
+        plan.segments = 1
+        plan.variant = "bin-owner walk, owner plan %d: deterministic, not bit-ordered (<= 1e-6 of the exact walk)" % own
+        return plan
+    segs = split_segments(shape, R)
+    plan = roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scale, rounding, segments=segs)
+    if plan.plan < 0:
+        segs = 1
+    plan.segments = segs
+    plan.variant = ("exact walk: the reference's summation order, bit for bit" if segs <= 1 else
+                    "split walk, %d segments: deterministic, not bit-ordered (<= 1e-6 of the exact walk)" % segs)
+    return plan
+
+
 def split_segments(shape, R):
     """How many segments the list-driven backward cuts a tile's slot stream into for this launch:
     cfg.ROI_POOL_BWD_SPLIT = 'auto' (the library's rule: few images with >= 1000 RoIs each -> 8), an int, or
     0 / 1 for the exact walk.  > 1 is deterministic but NOT bit-identical to the reference's summation order."""
     v = cfg.get("ROI_POOL_BWD_SPLIT", "auto")
     N, H, W, C = shape
+    if cfg.get("ROI_POOL_BWD_EXACT", False):
+        return 1
     if v == "auto":
         return int(_lib.lib().wssdl_roi_pool_backward_split_segments(int(R), N, H, W, C))
     return max(1, int(v))
@@ -297,6 +355,17 @@ def roi_pool_grad_compact(shape, rois, arg8, grad, pooled_height, pooled_width, 
     R = rois.shape[0]
     if plan is None and use_workspace:
         plan = roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scale, rounding)
+    if plan is not None and plan.owner >= 0:
+        with torch.cuda.device(grad.device):
+            nscr = L.wssdl_roi_pool_backward_owner_scratch_bytes(N, H, W, C, plan.owner)
+            scratch = torch.empty((nscr,), dtype=torch.uint8, device=grad.device)
+            with _lib.timed("roi_pool_backward", dict(N=N, H=H, W=W, C=C, R=R, argmax_bytes=1, owner=plan.owner)):
+                _lib.check(L.wssdl_roi_pool_backward_compact_owner(
+                    _lib.ptr(grad), _lib.ptr(arg8), _lib.ptr(rois), R, N, H, W, C,
+                    int(pooled_height), int(pooled_width), float(spatial_scale), mode, _lib.ptr(out),
+                    _lib.ptr(plan.workspace), plan.nbytes, plan.owner, _lib.ptr(scratch), nscr,
+                    _lib.stream()), "wssdl_roi_pool_backward_compact_owner")
+        return out
     if plan is None or plan.plan < 0:
         plan = BackwardPlan(None, 0, -1)
     segments = int(segments) if plan.plan >= 0 else 1
@@ -361,9 +430,7 @@ class RoiPoolFunction(torch.autograd.Function):
         if ctx.compact:
             if data.requires_grad or bottom_data.requires_grad:
                 # the backward's lists depend on the RoIs only: build them now, behind the forward
-                ctx.plan = roi_pool_grad_prepare(tuple(data.shape), rois, pooled_height, pooled_width,
-                                                 spatial_scale, rounding,
-                                                 segments=split_segments(tuple(data.shape), rois.shape[0]))
+                ctx.plan = prepare_backward(tuple(data.shape), rois, pooled_height, pooled_width, spatial_scale, rounding)
         else:
             top, arg = roi_pool(data, rois, pooled_height, pooled_width, spatial_scale,
                                 rounding=rounding)
@@ -378,7 +445,7 @@ class RoiPoolFunction(torch.autograd.Function):
         shape, ph, pw, scale, rounding = ctx.geom
         if ctx.compact:
             bottom_diff = roi_pool_grad_compact(shape, rois, arg, grad_top.contiguous(), ph, pw, scale,
-                                                rounding, plan=ctx.plan, segments=split_segments(shape, rois.shape[0]))
+                                                rounding, plan=ctx.plan, segments=getattr(ctx.plan, "segments", 1))
         else:
             bottom_diff = roi_pool_grad(torch.empty(shape, device="meta"), rois, arg,
                                         grad_top.contiguous(), ph, pw, scale)
