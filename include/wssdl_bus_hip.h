@@ -219,7 +219,10 @@ WSSDL_API int wssdl_anchor_targets(const int8_t *labels, const int32_t *argmax_g
  *   weights (:187-210, :89).  keep [n_keep] i32 indexes rois; is_fg [n_keep] u8.  A negative keep
  *   entry is a padding slot of a fixed-shape list (wssdl_roi_sample_device pads with -1 when an
  *   image runs short of candidates): its output row is (-1,0,0,0,0), label -1, zero targets and
- *   weights, so that consumers can run on the full shape without reading the counts back. */
+ *   weights, so that consumers can run on the full shape without reading the counts back.
+ *   normalize_host != NULL = cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED (:221-224): 8 host doubles, BBOX_NORMALIZE_MEANS
+ *   then BBOX_NORMALIZE_STDS; targets = (f32 target - mean) / std evaluated in f64 and rounded to f32 once, as NumPy does
+ *   when the f32 targets meet np.array(MEANS) / np.array(STDS). */
 WSSDL_API int wssdl_roi_gt_assign(const float *rois, int R, const float *gt_boxes, int max_gt,
                         const int32_t *num_pos_boxes, int n_images, double *max_overlap,
                         int32_t *assignment, wssdl_stream_t stream);
@@ -242,8 +245,8 @@ WSSDL_API int wssdl_proposal_target_device(
     const float *rois, int R, const float *gt_boxes, int max_gt, const int32_t *num_gt_boxes, int n_images,
     const int32_t *images, int n_sample_images, int append_gt, int rois_per_image, int fg_rois_per_image,
     double fg_thresh, double bg_thresh_hi, double bg_thresh_lo, uint64_t seed, int num_classes,
-    const float *inside_weights_host, float *rois_out, float *labels, float *bbox_targets, float *inside_w,
-    float *outside_w, void *workspace, size_t workspace_bytes, wssdl_stream_t stream);
+    const float *inside_weights_host, const double *normalize_host, float *rois_out, float *labels, float *bbox_targets,
+    float *inside_w, float *outside_w, void *workspace, size_t workspace_bytes, wssdl_stream_t stream);
 WSSDL_API int wssdl_roi_sample_device(const float *cand, const double *max_overlap, int Rc,
                             const int32_t *images, int n_sample_images, int rois_per_image,
                             int fg_rois_per_image, double fg_thresh, double bg_thresh_hi,
@@ -251,8 +254,9 @@ WSSDL_API int wssdl_roi_sample_device(const float *cand, const double *max_overl
                             int32_t *counts, wssdl_stream_t stream);
 WSSDL_API int wssdl_roi_targets(const float *rois, const int32_t *keep, const uint8_t *is_fg, int n_keep,
                       const int32_t *assignment, const float *gt_boxes, int max_gt, int num_classes,
-                      const float *inside_weights_host /* [4] */, float *rois_out, float *labels,
-                      float *bbox_targets, float *inside_w, float *outside_w,
+                      const float *inside_weights_host /* [4] */,
+                      const double *normalize_host /* NULL, or means[4] then stds[4] */, float *rois_out,
+                      float *labels, float *bbox_targets, float *inside_w, float *outside_w,
                       wssdl_stream_t stream);
 
 /* ---------------------------------------------------------------- a11, a12 ---

@@ -329,6 +329,29 @@ def main():
     pt["seed_joint"] = np.array(17)
     save("proposal_target", **pt)
 
+    # ---- a10 with cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED (proposal_target_layer_tf_bus.py:221-224) -------
+    # the reference's own means / stds (config.py:182-183: (0,0,0,0) / (0.1,0.1,0.2,0.2)), same inputs and seeds as above
+    ptn = dict(rois_in=rois, gt_boxes=gtb, num_gt=ng,
+               means=np.asarray(cfg.TRAIN.BBOX_NORMALIZE_MEANS, np.float64), stds=np.asarray(cfg.TRAIN.BBOX_NORMALIZE_STDS, np.float64))
+    assert not cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED
+    cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED = True
+    np.random.seed(13)
+    o = R.proposal_target_layer(rois, gtb, ng, 3, True, False)
+    for k, nm in enumerate(("rois", "labels", "targets", "inside", "outside")):
+        ptn["alt_train/%s" % nm] = o[k]
+    cfg.TRAIN.IMS_PER_BATCH = 1
+    cfg.TRAIN.WS_IMS_PER_BATCH = 1
+    np.random.seed(17)
+    o = R.proposal_target_layer_joint(rois, gtb, ng, 3, True)
+    for k, nm in enumerate(("rois", "labels", "targets", "inside", "outside")):
+        ptn["joint_train/%s" % nm] = o[k]
+    cfg.TRAIN.WS_IMS_PER_BATCH = 2
+    cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED = False
+    ptn["seed_alt"] = np.array(13)
+    ptn["seed_joint"] = np.array(17)
+    assert np.array_equal(ptn["alt_train/rois"], pt["alt_train/rois"]) and not np.array_equal(ptn["alt_train/targets"], pt["alt_train/targets"])
+    save("proposal_target_norm", **ptn)
+
     # ---- box transforms -------------------------------------------------------
     rs = np.random.RandomState(21)
     ex = rs.uniform(0, 500, size=(64, 2))

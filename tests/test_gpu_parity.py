@@ -5,8 +5,13 @@ Bars: bit-exact for integer / index / label work and for f32/f64 arithmetic that
 not go through exp/log; RoI-pool activations and gradients bit-exact (<= 1e-5 is the
 north-star tolerance); decoded boxes and regression targets within a few ulp (the
 reference's own np.exp / np.log are not correctly rounded)."""
+import os
+import sys
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from conftest import load_golden
 from oracle import c_oracle, np_oracle as O
@@ -399,13 +404,23 @@ def test_proposal_layer_golden(torch_cuda, case):
         assert np.array_equal(blob[off:off + c], rois_p[i, :c])
         off += c
     assert off == blob.shape[0]
-    # a9 end to end vs the reference's own output: same rois up to exp rounding;
-    # a flipped NMS decision at the threshold would shift rows, so require >= 99.5 %
+    # a9 end to end vs the reference's OWN output (proposal_layer_tf_bus.py:116-142), pinned (round 5): per image the
+    # exact number of rows that differ from the reference's rois by more than 1e-3 px, the first such row and the row
+    # counts -- tests/golden/a9_pinned.json, measured by tools/a9_mismatch.py.  On all four golden cases that number is
+    # ZERO: no NMS decision sits close enough to the threshold for the exp rounding (f64 exp rounded once on the device,
+    # NumPy's f32 exp in the reference) to flip it.  A change that flips a single decision, drops a row or reorders
+    # two fails here.
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from a9_mismatch import analyse
+    with open(os.path.join(ROOT, "tests", "golden", "a9_pinned.json")) as f:
+        pinned = json.load(f)[case]
     ref = g[case + "/rois"]
-    m = min(len(ref), len(blob))
-    close = np.all(np.abs(ref[:m] - blob[:m]) <= 1e-3, axis=1)
-    assert abs(len(ref) - len(blob)) <= max(2, len(ref) // 200)
-    assert close.mean() >= 0.995
+    assert len(pinned) == N
+    for i in range(N):
+        got = analyse(ref[ref[:, 0] == i], blob[blob[:, 0] == i])
+        assert got == pinned[i], (case, i, got, pinned[i])
+        assert got["rows_differing"] == 0 and got["n_ref"] == got["n_got"]
 
 
 def test_proposal_layer_gpu_tensor_io_and_empty_image(torch_cuda):
@@ -453,4 +468,40 @@ def test_proposal_target_golden(torch_cuda):
                                             rng=np.random.RandomState(int(g["seed_joint"])))
             check(o, tag)
     finally:
+        cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.WS_IMS_PER_BATCH = 1, 2
+    # cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED (proposal_target_layer_tf_bus.py:221-224; round 5): the reference's
+    # outputs with the switch on and its own means / stds (config.py:182-183); the division happens in f64 on the f32
+    # targets and is rounded once, so the bound stays np.log's 4 ulp
+    g = load_golden("proposal_target_norm")
+    assert not cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED
+    saved = (cfg.TRAIN.BBOX_NORMALIZE_MEANS, cfg.TRAIN.BBOX_NORMALIZE_STDS)
+    cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED = True
+    cfg.TRAIN.BBOX_NORMALIZE_MEANS, cfg.TRAIN.BBOX_NORMALIZE_STDS = tuple(g["means"]), tuple(g["stds"])
+    try:
+        check(proposal_target_layer(rois, gt, ng, 3, True, False, rng=np.random.RandomState(int(g["seed_alt"]))), "alt_train")
+        cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.WS_IMS_PER_BATCH = 1, 1
+        check(proposal_target_layer_joint(rois, gt, ng, 3, True, rng=np.random.RandomState(int(g["seed_joint"]))), "joint_train")
+        assert float(np.abs(g["alt_train/targets"]).max()) > 1.0          # the normalised scale, not the raw one
+        # the device-sampled chain (wssdl_proposal_target_device) takes the same switch: its targets are those of the
+        # oracle on the rows it drew
+        cfg.SAMPLING_RNG = "device"
+        import torch
+        o = proposal_target_layer(torch.from_numpy(rois).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(ng).cuda(),
+                                  3, True, False)
+        dr, dl, dt = (t.cpu().numpy() for t in o[:3])
+        from oracle import np_oracle as OO
+        for i in np.where(dl[:, 0] > 0)[0]:
+            img = int(dr[i, 0])
+            pos = gt[img, :ng[img]]
+            pos = pos[pos[:, 4] > 0]
+            ov = OO.bbox_overlaps(dr[i:i + 1, 1:5].astype(np.float64), pos[:, :4].astype(np.float64))[0]
+            k = int(ov.argmax())
+            want = (OO.bbox_transform(dr[i:i + 1, 1:5], pos[k:k + 1, :4]) - g["means"]) / g["stds"]
+            c = int(dl[i, 0])
+            assert ulp_diff_f32(dt[i, 4 * c:4 * c + 4], want.astype(np.float32)[0]).max() <= 4
+        assert int((dl[:, 0] > 0).sum()) > 0
+    finally:
+        cfg.SAMPLING_RNG = "reference"
+        cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED = False
+        cfg.TRAIN.BBOX_NORMALIZE_MEANS, cfg.TRAIN.BBOX_NORMALIZE_STDS = saved
         cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.WS_IMS_PER_BATCH = 1, 2

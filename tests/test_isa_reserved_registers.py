@@ -1,63 +1,41 @@
 """The NMS sweep's helper waves keep two batches of in-flight gather loads in sixteen FIXED registers
-(v80-v95, wssdl_bus_amd/csrc/nms.hip) that only their inline-asm statements may name; both kernels carry
-amdgpu_num_vgpr(80) so that the register allocator stays below them.  That attribute is a request, not a
-guarantee: this test disassembles the two kernels out of the BUILT library and checks that every instruction
-that mentions v80-v95 is one of those asm statements (a load into a register pair, the zeroing of the registers
-before the first turn, or the OR that takes a landed batch out of them).
-
-(The request is only honoured in a range: with the registers moved to v48-v63 / v64-v79 and amdgpu_num_vgpr(48) /
-(64) the allocator of ROCm 7.2 ignored it and used them -- which is how this test earned its keep in round 4.)"""
+(v80-v95, wssdl_bus_amd/csrc/nms.hip) that only their inline-asm statements may name.  The check itself lives in
+wssdl_bus_amd/isa_check.py and is part of build() since round 5 (a library that violates it is never installed; missing
+LLVM tools are an error); these tests run it on the built library and on the one the GPU process has loaded, and show
+that build() really refuses."""
 import os
-import re
-import shutil
-import subprocess
-import tempfile
 
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LLVM = "/opt/rocm/lib/llvm/bin"
-MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
-KERNELS = ("nms_sweep_pipelined_kernel", "nms_mask_sweep_fused_kernel")
-RESERVED = re.compile(r"\bv(8[0-9]|9[0-5])\b|\bv\[(8[0-9]|9[0-5]):(8[0-9]|9[0-5])\]")
-
-
-def _tool(name):
-    path = os.path.join(LLVM, name)
-    if not os.path.exists(path):
-        pytest.skip("%s not available" % path)
-    return path
-
-
-def _kernel_listings(lib_path, tmp):
-    """{kernel name: [instruction lines]} from the gfx950 code objects embedded in the library."""
-    fat = os.path.join(tmp, "fat.bin")
-    subprocess.check_call([_tool("llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib_path])
-    data = open(fat, "rb").read()
-    starts = [m.start() for m in re.finditer(re.escape(MAGIC), data)]
-    out = {}
-    for i, o in enumerate(starts):
-        piece = os.path.join(tmp, "bundle%d.bin" % i)
-        with open(piece, "wb") as f:
-            f.write(data[o:starts[i + 1] if i + 1 < len(starts) else len(data)])
-        co = os.path.join(tmp, "dev%d.co" % i)
-        subprocess.run([_tool("clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + piece,
-                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], capture_output=True)
-        if not os.path.exists(co) or os.path.getsize(co) == 0:
-            continue
-        dis = subprocess.run([_tool("llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True,
-                             text=True).stdout
-        for part in re.split(r"\n(?=[0-9a-f]+ <)", dis):
-            head = part.split("\n", 1)[0]
-            for k in KERNELS:
-                if k in head:
-                    out[k] = part.split("\n")[1:]
-    return out
+from wssdl_bus_amd import isa_check
 
 
 def test_only_the_helpers_asm_names_the_reserved_registers():
     from wssdl_bus_amd import build
-    _check(build.build(verbose=False))
+    assert isa_check.check_library(build.build(verbose=False))
+
+
+def test_build_refuses_without_the_disassembler(monkeypatch, tmp_path):
+    """fail, not skip: without llvm-objdump & co. the check raises, and build() runs it before installing."""
+    from wssdl_bus_amd import build
+    monkeypatch.setattr(isa_check, "LLVM", str(tmp_path))
+    with pytest.raises(isa_check.IsaCheckError, match="not available"):
+        isa_check.check_library(build.OUT)
+    import inspect
+    src = inspect.getsource(build.build)
+    assert src.index("isa_check.check_library") < src.index("os.replace(OUT")
+
+
+def test_a_violation_is_caught(monkeypatch):
+    """the checker rejects a listing that touches v80-v95 outside the three allowed instruction shapes"""
+    good = ["\tglobal_load_dwordx2 v[80:81], v[2:3], off"] * 8 + ["\tv_mov_b32_e32 v80, 0"] * 16 + \
+           ["\tv_or3_b32 v4, v80, v82, v84"] * 8
+    monkeypatch.setattr(isa_check, "kernel_listings", lambda lib, tmp: {k: list(good) for k in isa_check.KERNELS})
+    assert isa_check.check_library("unused")
+    bad = good + ["\tv_add_f32_e32 v85, v1, v2"]
+    monkeypatch.setattr(isa_check, "kernel_listings", lambda lib, tmp: {k: list(bad) for k in isa_check.KERNELS})
+    with pytest.raises(isa_check.IsaCheckError, match="outside the helpers"):
+        isa_check.check_library("unused")
 
 
 @pytest.mark.gpu
@@ -66,30 +44,4 @@ def test_loaded_library_keeps_the_reserved_registers_to_the_helpers():
     driver's round-end run then disassembles the very code object the GPU box executes."""
     from wssdl_bus_amd import _lib
     _lib.lib()
-    _check(_lib.LIB_PATH)
-
-
-def _check(lib_path):
-    tmp = tempfile.mkdtemp(prefix="wssdl_isa_")
-    try:
-        listings = _kernel_listings(lib_path, tmp)
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-    assert set(listings) == set(KERNELS), sorted(listings)
-    for k, lines in listings.items():
-        loads = zeroed = ors = 0
-        for line in lines:
-            if not RESERVED.search(line):
-                continue
-            words = line.replace(",", " ").split()
-            op, args = words[0], words[1:]
-            if op == "global_load_dwordx2" and RESERVED.fullmatch(args[0]) and not any(RESERVED.search(a) for a in args[1:]):
-                loads += 1                      # a batch load: the reserved pair is the destination only
-            elif op.startswith("v_mov_b32") and RESERVED.fullmatch(args[0]) and args[1] == "0":
-                zeroed += 1                     # before the first turn: never-issued batches read as zero words
-            elif op.startswith(("v_or3_b32", "v_or_b32")) and not RESERVED.search(args[0]) and \
-                    any(RESERVED.fullmatch(a) for a in args[1:]):
-                ors += 1                        # the consume step: the landed words are sources only
-            else:
-                raise AssertionError("%s: reserved register used outside the helpers' asm: %s" % (k, line.strip()))
-        assert loads == 8 and zeroed == 16 and ors == 8, (k, loads, zeroed, ors)
+    assert isa_check.check_library(_lib.LIB_PATH)

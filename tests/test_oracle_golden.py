@@ -224,6 +224,29 @@ def test_proposal_target_golden():
     assert g["joint_train/rois"].shape[0] == 128 + int((rois[:, 0] == 1).sum())
 
 
+def test_proposal_target_golden_with_precomputed_normalisation():
+    """cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED = True (proposal_target_layer_tf_bus.py:221-224) with the
+    reference's own means / stds (config.py:182-183): the reference's outputs, bit for bit."""
+    g = load_golden("proposal_target_norm")
+    rois, gt, ng = g["rois_in"], g["gt_boxes"], g["num_gt"]
+    names = ("rois", "labels", "targets", "inside", "outside")
+    over = dict(BBOX_NORMALIZE_TARGETS_PRECOMPUTED=True, BBOX_NORMALIZE_MEANS=tuple(g["means"]),
+                BBOX_NORMALIZE_STDS=tuple(g["stds"]))
+    o = O.proposal_target_layer(rois, gt, ng, 3, True, False, rng=np.random.RandomState(int(g["seed_alt"])), cfg=over)
+    for k, nm in enumerate(names):
+        assert np.array_equal(o[k], g["alt_train/%s" % nm]), nm
+    o = O.proposal_target_layer_joint(rois, gt, ng, 3, True, rng=np.random.RandomState(int(g["seed_joint"])),
+                                      cfg=dict(over, IMS_PER_BATCH=1, WS_IMS_PER_BATCH=1))
+    for k, nm in enumerate(names):
+        assert np.array_equal(o[k], g["joint_train/%s" % nm]), nm
+    # the switch matters: the plain fixtures' targets differ, and by exactly the scaling (means are zero)
+    p = load_golden("proposal_target")
+    assert not np.array_equal(p["alt_train/targets"], g["alt_train/targets"])
+    fg = p["alt_train/targets"] != 0
+    scaled = (p["alt_train/targets"].astype(np.float64).reshape(-1, 3, 4) / g["stds"]).reshape(p["alt_train/targets"].shape)
+    assert np.array_equal(scaled.astype(np.float32)[fg], g["alt_train/targets"][fg])
+
+
 def test_oracle_roundtrip_c_binding_shapes():
     top, arg = c_oracle.roi_pool_forward(np.zeros((1, 4, 4, 2), np.float32),
                                          np.zeros((0, 5), np.float32), 7, 7, 1.0 / 16)

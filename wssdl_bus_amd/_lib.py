@@ -49,9 +49,9 @@ SYMBOLS = {
     "wssdl_roi_candidates": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "wssdl_roi_sample_device": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _d, _d, _d, _u64, _vp, _vp, _vp, _vp]),
     "wssdl_proposal_target_device_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
-    "wssdl_proposal_target_device": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _d, _d, _d, _u64, _i, _vp,
+    "wssdl_proposal_target_device": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _d, _d, _d, _u64, _i, _vp, _vp,
                                           _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "wssdl_roi_targets": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+    "wssdl_roi_targets": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp]),
     "wssdl_roi_pool_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "wssdl_roi_pool_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),

@@ -92,6 +92,14 @@ def build(force=False, verbose=True):
     if verbose:
         print("[wssdl_bus_amd] " + " ".join(cmd))
     subprocess.check_call(cmd)
+    # the NMS sweep's reserved registers (v80-v95): disassemble what was just linked; a library that violates the
+    # rule -- or that cannot be checked -- is not installed (isa_check.py)
+    from . import isa_check
+    try:
+        isa_check.check_library(OUT + ".tmp")
+    except Exception:
+        os.remove(OUT + ".tmp")
+        raise
     os.replace(OUT + ".tmp", OUT)
     return OUT
 

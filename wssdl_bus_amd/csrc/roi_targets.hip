@@ -64,11 +64,19 @@ __global__ __launch_bounds__(256) void roi_gt_assign_kernel(
     assignment[r] = arg;
 }
 
+// cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED (proposal_target_layer_tf_bus.py:221-224):
+// targets = (targets - np.array(MEANS)) / np.array(STDS) -- the f32 targets meet f64 arrays, so the subtraction and the
+// division happen in f64 and the result is rounded to f32 once (the hstack + astype(np.float32) of :225-226)
+struct RoiTargetNorm {
+    int on;
+    double mean[4], std[4];
+};
+
 __global__ __launch_bounds__(256) void roi_targets_kernel(
     const float *__restrict__ rois, const int *__restrict__ keep,
     const unsigned char *__restrict__ is_fg, int n_keep, const int *__restrict__ assignment,
     const float *__restrict__ gt_boxes, int max_gt, int num_classes, float iw0, float iw1,
-    float iw2, float iw3, float *__restrict__ rois_out, float *__restrict__ labels,
+    float iw2, float iw3, RoiTargetNorm norm, float *__restrict__ rois_out, float *__restrict__ labels,
     float *__restrict__ bbox_targets, float *__restrict__ inside_w, float *__restrict__ outside_w) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_keep) return;
@@ -105,10 +113,16 @@ __global__ __launch_bounds__(256) void roi_targets_kernel(
             float gh = g[3] - g[1];  gh = gh + 1.0f;
             float hgw = 0.5f * gw, hgh = 0.5f * gh;
             const float gcx = g[0] + hgw, gcy = g[1] + hgh;
-            const float t0 = (gcx - ecx) / ew;
-            const float t1 = (gcy - ecy) / eh;
-            const float t2 = (float)log((double)(gw / ew));
-            const float t3 = (float)log((double)(gh / eh));
+            float t0 = (gcx - ecx) / ew;
+            float t1 = (gcy - ecy) / eh;
+            float t2 = (float)log((double)(gw / ew));
+            float t3 = (float)log((double)(gh / eh));
+            if (norm.on) {
+                t0 = (float)(((double)t0 - norm.mean[0]) / norm.std[0]);
+                t1 = (float)(((double)t1 - norm.mean[1]) / norm.std[1]);
+                t2 = (float)(((double)t2 - norm.mean[2]) / norm.std[2]);
+                t3 = (float)(((double)t3 - norm.mean[3]) / norm.std[3]);
+            }
             const int s = 4 * cls;
             to[s + 0] = t0; to[s + 1] = t1; to[s + 2] = t2; to[s + 3] = t3;
             io[s + 0] = iw0; io[s + 1] = iw1; io[s + 2] = iw2; io[s + 3] = iw3;
@@ -337,7 +351,7 @@ extern "C" int wssdl_roi_gt_assign(const float *rois, int R, const float *gt_box
 extern "C" int wssdl_roi_targets(const float *rois, const int32_t *keep, const uint8_t *is_fg,
                                  int n_keep, const int32_t *assignment, const float *gt_boxes,
                                  int max_gt, int num_classes, const float *inside_weights_host,
-                                 float *rois_out, float *labels, float *bbox_targets,
+                                 const double *normalize_host, float *rois_out, float *labels, float *bbox_targets,
                                  float *inside_w, float *outside_w, wssdl_stream_t stream) {
     if (n_keep < 0 || max_gt < 1 || num_classes < 1 || !inside_weights_host)
         return WSSDL_ERR_INVALID_ARGUMENT;
@@ -345,10 +359,16 @@ extern "C" int wssdl_roi_targets(const float *rois, const int32_t *keep, const u
     if (!rois || !keep || !is_fg || !assignment || !gt_boxes || !rois_out || !labels ||
         !bbox_targets || !inside_w || !outside_w)
         return WSSDL_ERR_INVALID_ARGUMENT;
+    RoiTargetNorm norm;
+    norm.on = normalize_host ? 1 : 0;
+    for (int j = 0; j < 4; ++j) {
+        norm.mean[j] = normalize_host ? normalize_host[j] : 0.0;
+        norm.std[j] = normalize_host ? normalize_host[4 + j] : 1.0;
+    }
     hipLaunchKernelGGL(roi_targets_kernel, dim3(cdiv(n_keep, 256)), dim3(256), 0, as_stream(stream),
                        rois, keep, is_fg, n_keep, assignment, gt_boxes, max_gt, num_classes,
                        inside_weights_host[0], inside_weights_host[1], inside_weights_host[2],
-                       inside_weights_host[3], rois_out, labels, bbox_targets, inside_w, outside_w);
+                       inside_weights_host[3], norm, rois_out, labels, bbox_targets, inside_w, outside_w);
     return check_launch();
 }
 
@@ -427,8 +447,8 @@ extern "C" int wssdl_proposal_target_device(
     const float *rois, int R, const float *gt_boxes, int max_gt, const int32_t *num_gt_boxes, int n_images,
     const int32_t *images, int n_sample_images, int append_gt, int rois_per_image, int fg_rois_per_image,
     double fg_thresh, double bg_thresh_hi, double bg_thresh_lo, uint64_t seed, int num_classes,
-    const float *inside_weights_host, float *rois_out, float *labels, float *bbox_targets, float *inside_w,
-    float *outside_w, void *workspace, size_t workspace_bytes, wssdl_stream_t stream) {
+    const float *inside_weights_host, const double *normalize_host, float *rois_out, float *labels, float *bbox_targets,
+    float *inside_w, float *outside_w, void *workspace, size_t workspace_bytes, wssdl_stream_t stream) {
     if (R < 0 || n_images < 1 || max_gt < 1 || n_sample_images < 0 || rois_per_image < 1 || num_classes < 1)
         return WSSDL_ERR_INVALID_ARGUMENT;
     if (n_sample_images == 0) return WSSDL_OK;
@@ -451,5 +471,5 @@ extern "C" int wssdl_proposal_target_device(
                                       fg_thresh, bg_thresh_hi, bg_thresh_lo, seed, w.keep, w.is_fg, w.counts, stream)))
         return rc;
     return wssdl_roi_targets(w.cand, w.keep, w.is_fg, n_keep, w.assign, gt_boxes, max_gt, num_classes,
-                             inside_weights_host, rois_out, labels, bbox_targets, inside_w, outside_w, stream);
+                             inside_weights_host, normalize_host, rois_out, labels, bbox_targets, inside_w, outside_w, stream);
 }

@@ -51,7 +51,9 @@ __C.TRAIN.FG_THRESH = 0.5                           # :124
 __C.TRAIN.BG_THRESH_HI = 0.5                        # :128
 __C.TRAIN.BG_THRESH_LO = 0.0                        # :130
 __C.TRAIN.BBOX_INSIDE_WEIGHTS = (1.0, 1.0, 1.0, 1.0)   # :178
-__C.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED = False   # :181
+__C.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED = False   # :181 (read by proposal_target_layer_tf_bus.py:221-224)
+__C.TRAIN.BBOX_NORMALIZE_MEANS = (0.0, 0.0, 0.0, 0.0)  # :182
+__C.TRAIN.BBOX_NORMALIZE_STDS = (0.1, 0.1, 0.2, 0.2)   # :183
 __C.TRAIN.RPN_POSITIVE_OVERLAP = 0.7                # :196
 __C.TRAIN.RPN_NEGATIVE_OVERLAP = 0.3                # :198
 __C.TRAIN.RPN_CLOBBER_POSITIVES = False             # :200

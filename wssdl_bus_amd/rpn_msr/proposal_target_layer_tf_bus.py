@@ -59,6 +59,16 @@ def _empty_outputs(dev, num_classes):
     return [z(5), z(1), z(4 * num_classes), z(4 * num_classes), z(4 * num_classes)]
 
 
+def _normalize_arg():
+    """cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED (proposal_target_layer_tf_bus.py:221-224): the 8 host doubles
+    wssdl_roi_targets takes (means then stds), or None when the switch is off (the reference's default)."""
+    if not cfg.TRAIN.get("BBOX_NORMALIZE_TARGETS_PRECOMPUTED", False):
+        return None
+    v = np.concatenate([np.asarray(cfg.TRAIN.BBOX_NORMALIZE_MEANS, dtype=np.float64).reshape(4),
+                        np.asarray(cfg.TRAIN.BBOX_NORMALIZE_STDS, dtype=np.float64).reshape(4)])
+    return np.ascontiguousarray(v)
+
+
 def _supervised(rois, gt_dev, gt_host, ng_host, images, append_gt, num_classes, rng):
     """Sampled rows for the supervised `images` (in that order), all on the GPU."""
     with _lib.timed("proposal_target_layer", dict(R=int(rois.shape[0]), images=len(images))):
@@ -74,6 +84,7 @@ def _supervised_device(rois, gt_dev, ng_dev, images, append_gt, num_classes):
     rpi = int(cfg.TRAIN.BATCH_SIZE) // 1
     fg_rpi = int(np.round(cfg.TRAIN.FG_FRACTION * rpi))
     iw = np.ascontiguousarray(cfg.TRAIN.BBOX_INSIDE_WEIGHTS, dtype=np.float32)
+    norm = _normalize_arg()
     with torch.cuda.device(dev):
         images_dev = _images_tensor(images, dev)
         R = int(rois.shape[0])
@@ -96,7 +107,8 @@ def _supervised_device(rois, gt_dev, ng_dev, images, append_gt, num_classes):
             _lib.check(L.wssdl_proposal_target_device(
                 _lib.ptr(rois), R, _lib.ptr(gt_dev), max_gt, _lib.ptr(ng_dev), n_img, _lib.ptr(images_dev), S,
                 int(bool(append_gt)), rpi, fg_rpi, float(cfg.TRAIN.FG_THRESH), float(cfg.TRAIN.BG_THRESH_HI),
-                float(cfg.TRAIN.BG_THRESH_LO), seed, int(num_classes), _lib.host_ptr(iw), _lib.ptr(out_rois),
+                float(cfg.TRAIN.BG_THRESH_LO), seed, int(num_classes), _lib.host_ptr(iw),
+                _lib.host_ptr(norm) if norm is not None else None, _lib.ptr(out_rois),
                 _lib.ptr(labels), _lib.ptr(tg), _lib.ptr(inw), _lib.ptr(outw), _lib.ptr(ws), nws, _lib.stream()),
                 "wssdl_proposal_target_device")
     return [out_rois, labels, tg, inw, outw]
@@ -174,6 +186,7 @@ def _supervised_impl(rois, gt_dev, gt_host, ng_host, images, append_gt, num_clas
     fg_np = np.concatenate(fg_all) if fg_all else np.zeros(0, np.uint8)
     n_keep = keep_np.size
     iw = np.ascontiguousarray(cfg.TRAIN.BBOX_INSIDE_WEIGHTS, dtype=np.float32)
+    norm = _normalize_arg()
     with torch.cuda.device(dev):
         keep_dev = torch.from_numpy(keep_np).to(dev)
         fg_dev = torch.from_numpy(fg_np).to(dev)
@@ -185,6 +198,7 @@ def _supervised_impl(rois, gt_dev, gt_host, ng_host, images, append_gt, num_clas
         _lib.check(L.wssdl_roi_targets(
             _lib.ptr(cand), _lib.ptr(keep_dev), _lib.ptr(fg_dev), n_keep, _lib.ptr(assign),
             _lib.ptr(gt_dev), gt_dev.shape[1], int(num_classes), _lib.host_ptr(iw),
+            _lib.host_ptr(norm) if norm is not None else None,
             _lib.ptr(out_rois), _lib.ptr(labels), _lib.ptr(tg), _lib.ptr(inw), _lib.ptr(outw),
             _lib.stream()), "wssdl_roi_targets")
     return [out_rois, labels, tg, inw, outw], batch_host[:R]
