@@ -303,6 +303,206 @@ def test_real_step_losses_match_oracle(torch_cuda, cfg_guard):
     assert want["mil_cross_entropy"] > 0 and want["rpn_loss_box"] > 0
 
 
+# ------------------------------- configs[2]: the step the driver times, layer by layer ---
+
+def test_config3_resnet50_joint_4_plus_4_step_layer_by_layer(torch_cuda, cfg_guard):
+    """BASELINE configs[2] at full scale, exactly as bench.py builds its default workload (`resnet50_joint_b8`:
+    ResNet-50, 4 supervised + 4 weak images of 600 x 1000, device samplers, fused RPN softmax and loss, compact blob):
+    ONE forward + backward of the combined mini-batch, then every hot-path layer of THAT step against the oracle on
+    the step's own inputs (round 5; the smaller test_real_step_losses_match_oracle stays):
+      a5   anchor labels before sub-sampling == oracle, bit for bit; the device sub-sampler's draw by invariants
+           (anchor_target_layer_tf_bus.py:202-217 quotas, subset of the pre-labels, weak images all-ignore :613-626)
+      a6/7 decoded boxes within exp rounding; candidate order a valid descending sort of the oracle's f64 softmax
+      a8/9 kept rows == the oracle's NMS (cpu_nms.pyx:17-68) on the GPU-decoded candidates, exact; == the layer's rois
+      a10  proposal-target rows by invariants (candidates of their image, quotas, overlap bands, labels, targets at
+           4 ulp, weights :228-280,187-226); the weak images' rois appended whole (:162-182)
+      a11  RoI-pool top and arg-max == oracle on ALL of the step's RoIs, bit for bit
+      a12  bottom_diff: the exact walk == oracle bit for bit; the default (bin-owner) form within 1e-5 of the scale
+      a13  the five losses at 1e-5."""
+    torch = torch_cuda
+    cfg = cfg_guard
+    from wssdl_bus_amd import _lib, synthetic
+    from wssdl_bus_amd.fast_rcnn.train_bus import SolverWrapper, mil_loss, supervised_loss
+    from wssdl_bus_amd.mil import core as mil_core
+    from wssdl_bus_amd.networks.factory_bus import get_network
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    from wssdl_bus_amd.rpn_msr.anchor_target_layer_tf_bus import anchor_target_layer_joint
+    from wssdl_bus_amd.rpn_msr.proposal_layer_tf_bus import proposal_layer_padded
+    n_s, n_ws, im_h, im_w = 4, 4, 600, 1000
+    cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.WS_IMS_PER_BATCH = n_s, n_ws
+    cfg.SAMPLING_RNG = "device"
+    cfg.FUSED_RPN_SOFTMAX = True
+    assert cfg.get("FUSED_LOSS", True) and not cfg.PADDED_ROIS and cfg.ROI_POOL_BWD_OWNER == "auto"
+    seed = int(cfg.RNG_SEED)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    net = get_network("Resnet_train", 50).cuda().to(memory_format=torch.channels_last)
+    net.train()
+    solver = SolverWrapper(net)
+    blobs = synthetic.make_batch(n_s, n_ws, im_h, im_w, seed)
+    # joint_backward (train_bus.py:732-764 mirror) with the pooled tensor's gradient retained
+    L = net(blobs["data"], blobs["im_info"], blobs["gt_boxes"], blobs["num_gt_boxes"], is_training=True, is_ws=False)
+    top = L["roi_pool"]
+    top.retain_grad()
+    losses = supervised_loss(L, net.weight_decay_params(), n_s)
+    n_valid = L["roi-data"][1].numel()
+    losses["mil_cross_entropy"] = mil_loss(L["cls_score"][n_valid:], L["roi-data"][0][n_valid:, 0] - n_s,
+                                           blobs["im_info"][n_s:, 3].to(torch.int32), n_ws, solver.global_step,
+                                           [mil_core.get_mal_max_logit, mil_core.get_mal_max_logit])
+    (losses["loss"] + losses["mil_cross_entropy"]).backward(retain_graph=True)
+    op.check_flags()
+    feat = L["group2/relu"]
+    N, H, W, C = feat.shape
+    assert (N, H, W, C) == (8, 38, 63, 1024)
+    gt, ng, info = _np(blobs["gt_boxes"]), _np(blobs["num_gt_boxes"]), _np(blobs["im_info"])
+    A = 9
+
+    # ---- a5: anchor targets ------------------------------------------------------------------------------------
+    score_shape = np.zeros((N, H, W, 2 * A), np.float32)
+    pre_want = O.anchor_target_layer_joint(score_shape, gt, ng, info, None, True, (16,), (8, 16, 32), "SNUBH",
+                                           rng=np.random.RandomState(0),
+                                           cfg=dict(RPN_BATCHSIZE=10 ** 9, IMS_PER_BATCH=n_s, WS_IMS_PER_BATCH=n_ws))[0]
+    old_bs = cfg.TRAIN.RPN_BATCHSIZE
+    cfg.TRAIN.RPN_BATCHSIZE = 10 ** 9                          # nothing to draw: the labels before sub-sampling
+    try:
+        pre_got = anchor_target_layer_joint(L["rpn_cls_score"], blobs["gt_boxes"], blobs["num_gt_boxes"], blobs["im_info"],
+                                            None, True, [16, ], [8, 16, 32], "SNUBH")[0]
+    finally:
+        cfg.TRAIN.RPN_BATCHSIZE = old_bs
+    pre_got = _np(pre_got)
+    assert pre_got.shape == pre_want.shape == (N, 1, A * H, W)
+    assert np.array_equal(pre_got, pre_want)                                    # bit-identical anchor labels
+    lab = _np(L["rpn-data"][0])
+    assert lab.shape == pre_want.shape and np.all(lab[n_s:] == -1)              # weak images: all-ignore
+    for i in range(n_s):
+        a, b = lab[i].reshape(-1), pre_want[i].reshape(-1)
+        assert np.all((a == b) | (a == -1))                                     # sub-sampling only disables
+        n_fg_pre, n_bg_pre = int((b == 1).sum()), int((b == 0).sum())
+        n_fg, n_bg = int((a == 1).sum()), int((a == 0).sum())
+        assert n_fg == min(n_fg_pre, 128) and n_bg == min(n_bg_pre, 256 - n_fg)  # :202-217
+        inw, outw = _np(L["rpn-data"][2])[i], _np(L["rpn-data"][3])[i]
+        fgm = (lab[i].reshape(A, H, W) == 1)
+        used = (lab[i].reshape(A, H, W) >= 0)
+        for j in range(4):
+            assert np.array_equal(inw.reshape(A, 4, H, W)[:, j] == 1, fgm)        # inside weights on fg (:228)
+            assert np.array_equal(outw.reshape(A, 4, H, W)[:, j] > 0, used)       # 1 / #(labels >= 0) on fg and bg (:233-244)
+        assert np.allclose(outw[outw > 0], 1.0 / (n_fg + n_bg), rtol=1e-6)
+
+    # ---- a6 - a9: proposals ------------------------------------------------------------------------------------
+    rp, cnt, dec, sidx, scnt = proposal_layer_padded(L["rpn_cls_score"].detach(), L["rpn_bbox_pred"].detach(),
+                                                     blobs["im_info"], True, debug=True, from_logits=True)
+    rp, cnt, dec, sidx, scnt = (_np(t) for t in (rp, cnt, dec, sidx, scnt))
+    p64 = O.rpn_cls_prob_reshape(_np(L["rpn_cls_score"]))
+    pred = _np(L["rpn_bbox_pred"])
+    anchors = O.shifted_anchors(H, W, 16, O.generate_anchors(scales=[8, 16, 32]))
+    tol = 2.0 ** -21
+    rois_layer = _np(L["rpn_rois"])
+    off = 0
+    for i in range(N):
+        st = O.proposal_stages_one_image(p64[i].astype(np.float32), pred[i], info[i], anchors, A, 12000, 2000, 0.7, 16)
+        assert np.allclose(dec[i], st["decoded"], rtol=2e-6, atol=2e-4)
+        n = int(scnt[i])
+        order = sidx[i, :n]
+        assert n == len(st["order"]) == 12000
+        s64 = p64[i].reshape(-1, 2 * A)[:, A:].reshape(-1)
+        so = s64[order]
+        assert np.all(so[:-1] >= so[1:] - tol * np.maximum(so[:-1], 1e-3))       # a valid descending sort
+        diff = np.setxor1d(order, st["order"])
+        if diff.size:
+            edge = s64[st["order"][-1]]
+            assert np.all(np.abs(s64[diff] - edge) <= tol * max(edge, 1e-3))     # only boundary ties may differ
+        assert diff.size <= 12
+        # greedy NMS only depends on the order: strictly decreasing surrogate scores (an untrained net has ties)
+        dets = np.hstack((dec[i][order], np.arange(n, 0, -1, dtype=np.float32)[:, None])).astype(np.float32)
+        keep = np.asarray(O.nms(dets, 0.7)[:2000], dtype=np.int64)
+        c = int(cnt[i])
+        assert c == len(keep) and c > 0
+        assert np.array_equal(rp[i, :c, 1:], dets[keep, :4])
+        assert np.array_equal(rois_layer[off:off + c, 1:], dets[keep, :4]) and np.all(rois_layer[off:off + c, 0] == i)
+        off += c
+    assert off == rois_layer.shape[0]
+
+    # ---- a10: proposal targets (device sampler: invariants) -------------------------------------------------------
+    rois = _np(L["roi-data"][0])
+    labels, tgt, inw, outw = (_np(L["roi-data"][k]) for k in (1, 2, 3, 4))
+    assert n_valid == n_s * 128 and labels.shape == (n_valid, 1) and tgt.shape == (n_valid, 12)
+    n_weak = int((rois_layer[:, 0] >= n_s).sum())
+    assert rois.shape[0] == n_valid + n_weak
+    assert np.array_equal(rois[n_valid:], rois_layer[rois_layer[:, 0] >= n_s])   # the weak images' rois, whole, in order
+    from test_gpu_parity import ulp_diff_f32
+    for i in range(n_s):
+        rows = slice(i * 128, (i + 1) * 128)
+        live = rois[rows, 0] >= 0
+        assert np.all(rois[rows][live, 0] == i) and np.all(rois[rows][~live] == [-1, 0, 0, 0, 0])
+        pos = gt[i, :ng[i]]
+        pos = pos[pos[:, 4] > 0]
+        cand = np.vstack((rois_layer[rois_layer[:, 0] == i][:, 1:], pos[:, :4]))
+        # every sampled row is a candidate of its image, none more often than it occurs
+        import collections
+        have = collections.Counter(map(bytes, np.ascontiguousarray(cand)))
+        took = collections.Counter(map(bytes, np.ascontiguousarray(rois[rows][live, 1:])))
+        assert all(have[k] >= v for k, v in took.items())
+        ov = O.bbox_overlaps(rois[rows][live, 1:].astype(np.float64), pos[:, :4].astype(np.float64))
+        mx, am = ov.max(axis=1), ov.argmax(axis=1)
+        lab_i = labels[rows][live, 0]
+        fgm = lab_i > 0
+        assert fgm.sum() <= 32 and live.sum() <= 128
+        assert np.all(mx[fgm] >= 0.5) and np.all(mx[~fgm] < 0.5) and np.all(mx >= 0)
+        assert np.array_equal(lab_i[fgm], pos[am[fgm], 4])
+        n_fg_avail = int((O.bbox_overlaps(cand.astype(np.float64), pos[:, :4].astype(np.float64)).max(axis=1) >= 0.5).sum())
+        assert fgm.sum() == min(32, n_fg_avail)
+        want_t = O.bbox_transform(rois[rows][live, 1:][fgm], pos[am[fgm], :4])
+        t_i, iw_i, ow_i = tgt[rows][live], inw[rows][live], outw[rows][live]
+        for r_, (k, w) in enumerate(zip(lab_i[fgm].astype(int), want_t.astype(np.float32))):
+            row = np.where(fgm)[0][r_]
+            assert ulp_diff_f32(t_i[row, 4 * k:4 * k + 4], w).max() <= 4
+            e = np.zeros(12, np.float32)
+            e[4 * k:4 * k + 4] = 1
+            assert np.array_equal(iw_i[row], e) and np.array_equal(ow_i[row], e)
+        assert not t_i[~fgm].any() and not iw_i[~fgm].any() and not ow_i[~fgm].any()
+
+    # ---- a11 / a12: RoI pooling on ALL of the step's RoIs ---------------------------------------------------------
+    R = rois.shape[0]
+    assert tuple(top.shape) == (R, 7, 7, C) and 4000 < R <= n_valid + 8000
+    f_np = _np(feat.detach().contiguous())
+    livem = rois[:, 0] >= 0
+    et, ea = c_oracle.roi_pool_forward(f_np, rois[livem], 7, 7, 1.0 / 16, "cuda", threads=16)
+    top_np = _np(top)
+    assert np.array_equal(top_np[livem], et)                                    # bit for bit, every RoI
+    assert not top_np[~livem].any()
+    rt = L["roi-data"][0]
+    arg8 = op.roi_pool_compact(feat.detach().contiguous(), rt, 7, 7, 1.0 / 16)[1]
+    arg = _np(op.expand_argmax(arg8, rt, (N, H, W, C), 7, 7, 1.0 / 16))
+    assert np.array_equal(arg[livem], ea) and np.all(arg[~livem] == -1)
+    top_diff = top.grad
+    assert float(top_diff.abs().sum()) > 0
+    td = _np(top_diff)
+    want_g = c_oracle.roi_pool_backward(td[livem], ea, rois[livem], f_np.shape, 7, 7, 1.0 / 16)
+    scale = float(np.abs(want_g).max())
+    # the default form of this launch (what the step ran and the bench times): the bin-owner walk
+    assert op.owner_plan((N, H, W, C), R) == 0
+    g_default = torch.autograd.grad(top, feat, top_diff, retain_graph=True)[0]
+    g_again = torch.autograd.grad(top, feat, top_diff, retain_graph=True)[0]
+    assert torch.equal(g_default, g_again)
+    assert np.abs(_np(g_default) - want_g).max() <= 1e-5 * scale
+    # the exact walk on the same inputs: the reference's summation order, bit for bit
+    cfg.ROI_POOL_BWD_EXACT = True
+    f2 = feat.detach().contiguous().requires_grad_(True)
+    top2, _ = op.RoiPoolFunction.apply(f2, rt, 7, 7, 1.0 / 16, None)
+    assert torch.equal(top2, top)
+    g_exact = torch.autograd.grad(top2, f2, top_diff)[0]
+    assert np.array_equal(_np(g_exact), want_g)
+    cfg.ROI_POOL_BWD_EXACT = False
+
+    # ---- a13: the five losses --------------------------------------------------------------------------------------
+    layers = {k: (tuple(_np(x) for x in L[k]) if isinstance(L[k], tuple) else _np(L[k]))
+              for k in ("rpn_cls_score_reshape", "rpn-data", "rpn_bbox_pred", "cls_score", "bbox_pred", "roi-data", "im_info")}
+    want = O.multi_task_loss_combined(layers, n_s, n_ws, solver.global_step, [_np(w) for w in net.weight_decay_params()])
+    for k in ("rpn_cross_entropy", "rpn_loss_box", "cross_entropy", "loss_box", "mil_cross_entropy", "weight_decay", "loss"):
+        assert abs(float(losses[k]) - want[k]) <= 1e-5 * max(1.0, abs(want[k])), (k, float(losses[k]), want[k])
+    op.check_flags()
+
+
 # ------------------------------------------------------------------ f1: MIL op ---
 
 def test_mil_select_matches_oracle(torch_cuda):

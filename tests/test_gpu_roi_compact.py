@@ -474,11 +474,13 @@ def test_compact_full_size_properties(torch_cuda):
     assert not op.compact_overflowed()
 
 
-def roofline_set_parity(torch, images=(0, 4), plans=(None,)):
+def roofline_set_parity(torch, images=tuple(range(8)), plans=(None,), owners=()):
     """The RoI-pool pair on the FIXED set bench.py's roofline is quoted on
     (profiles/roofline_rois_r8512.npy: 4 x 128 sampled rows + 4 x 2000 topped-up proposals), run at
     full size, against the C oracle image by image: top, expanded arg-max and bottom_diff bit for
-    bit (roi_pooling_op_gpu.cu.cc:20-85,114-190).  Also used by tools/roofline_leg.py --check."""
+    bit (roi_pooling_op_gpu.cu.cc:20-85,114-190) for the exact walk's `plans`; the bin-owner form's `owners` (what the
+    bench line times since round 5) within 1e-6 of every element's own sum of |terms| and 1e-5 of the tensor's scale,
+    and bit-repeatable.  All 8512 RoIs by default.  Also used by tools/roofline_leg.py --check."""
     from wssdl_bus_amd import _lib
     from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -497,6 +499,13 @@ def roofline_set_parity(torch, images=(0, 4), plans=(None,)):
         with _lib.tuned(roi_bwd_plan=-1 if p is None else p):
             plan = op.roi_pool_grad_prepare((N, H, W, C), rois, 7, 7, 1.0 / 16)
             grads.append((plan, op.roi_pool_grad_compact((N, H, W, C), rois, arg8, d, 7, 7, 1.0 / 16, plan=plan)))
+    own = []
+    for o in owners:
+        plan = op.roi_pool_grad_prepare_owner((N, H, W, C), rois, 7, 7, 1.0 / 16, o)
+        a = op.roi_pool_grad_compact((N, H, W, C), rois, arg8, d, 7, 7, 1.0 / 16, plan=plan)
+        b = op.roi_pool_grad_compact((N, H, W, C), rois, arg8, d, 7, 7, 1.0 / 16, plan=plan)
+        assert torch.equal(a, b), ("owner plan not repeatable", o)
+        own.append((o, a))
     assert not op.flags_raised()          # no window overflow, lists within their workspace
     # the prepare's record count against the bound the workspace was sized with
     off = _lib.lib().wssdl_roi_pool_backward_status_offset(R, N, H, W, 7, 7)
@@ -516,16 +525,26 @@ def roofline_set_parity(torch, images=(0, 4), plans=(None,)):
         want = c_oracle.roi_pool_backward(d[sl].cpu().numpy(), ea, sub, (1, H, W, C), 7, 7, 1.0 / 16)
         for plan, g in grads:
             assert np.array_equal(g[n].cpu().numpy(), want[0]), ("bottom_diff", n, plan.plan)
+        if own:
+            mag = c_oracle.roi_pool_backward(np.abs(d[sl].cpu().numpy()), ea, sub, (1, H, W, C), 7, 7, 1.0 / 16)[0]
+            scale = float(np.abs(want[0]).max())
+            for o, g in own:
+                got = g[n].cpu().numpy()
+                assert np.all(np.abs(got - want[0]) <= 1e-6 * mag + 1e-30), ("owner", o, n)
+                assert np.abs(got - want[0]).max() <= 1e-5 * scale, ("owner", o, n)
         checked[n] = len(idx)
     return checked, [p.plan for p, _ in grads]
 
 
 def test_roofline_roi_set_matches_oracle(torch_cuda):
-    """Parity ON the timed workload: one supervised image (128 rows) and one weak image (2000 topped-up,
-    heavily overlapping rows) of the fixed roofline set: the plan the library picks, 6x6 tiles with two
-    and three records in flight, and a 64-channel plan."""
-    checked, plans = roofline_set_parity(torch_cuda, images=(0, 4), plans=(None, 11, 13, 23))
-    assert checked == {0: 128, 4: 2000}
+    """Parity ON the timed workload, in full (round 5: all eight images = all 8512 RoIs of the fixed roofline set):
+    top, expanded arg-max and the exact walk's bottom_diff bit for bit -- the plan the library picks for the exact
+    walk, 6x6 tiles with two and three records in flight, a 64-channel plan -- and the bin-owner form the bench line
+    times (owner plans 0 and 1) at its tolerance."""
+    from wssdl_bus_amd import _lib
+    assert _lib.lib().wssdl_roi_pool_backward_owner_plan(8512, 8, 38, 63, 1024) == 0
+    checked, plans = roofline_set_parity(torch_cuda, images=tuple(range(8)), plans=(None, 11, 13, 23), owners=(0, 1))
+    assert checked == {0: 128, 1: 128, 2: 128, 3: 128, 4: 2000, 5: 2000, 6: 2000, 7: 2000}
 
 
 def test_oversized_roi_flags_and_i32_fallback(torch_cuda):

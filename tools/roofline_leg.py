@@ -126,8 +126,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--roi-bwd-plan", type=int, default=-1, help="force a backward plan (wssdl_set_tuning)")
     ap.add_argument("--check", action="store_true",
-                    help="before timing: the pair's outputs on this RoI set against the C oracle, bit for bit "
-                         "(one supervised and one weak image; tests/test_gpu_roi_compact.py)")
+                    help="before timing: the pair's outputs on this RoI set against the C oracle (all 8512 RoIs: top, arg-max "
+                         "and the exact walk bit for bit, the bin-owner form at its tolerance; tests/test_gpu_roi_compact.py)")
     ap.add_argument("--rois", default="", metavar="PATH.npy", help="another RoI set (float32 [R,5]) instead of the fixed one")
     ap.add_argument("--map", default="38,63,1024", help="H,W,C of the feature map the set belongs to")
     args = ap.parse_args()
@@ -136,7 +136,7 @@ def main():
     if args.check:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from test_gpu_roi_compact import roofline_set_parity
-        checked, plans = roofline_set_parity(torch)
+        checked, plans = roofline_set_parity(torch, owners=(0,))
         print(json.dumps(dict(check="top, argmax, bottom_diff == C oracle", rois_per_image=checked, plans=plans)))
     rois, tag = load_rois(args.rois) if args.rois else load_rois()
     if args.roi_bwd_plan >= 0:
