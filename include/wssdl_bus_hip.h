@@ -52,6 +52,10 @@ enum wssdl_roi_rounding {
     WSSDL_ROI_ROUND_CPU = 1    /* (int)(ph*bin), (int)((ph+1)*bin): roi_pooling_op.cc:167-170 */
 };
 
+/* wssdl_roi_pool_forward's N when the caller does not know the batch size (the reference's ROIPoolForwardLaucher,
+ * roi_pooling_op_gpu.h:17-21): no range check of rois[:, 0] above zero.  N == 0 with RoIs to pool is an error. */
+#define WSSDL_ROI_BATCH_UNKNOWN (-1)
+
 /* dataset switch of the anchor-target layer, anchor_target_layer_tf_bus.py:120-199 */
 enum wssdl_dataset {
     WSSDL_DATASET_SNUBH = 0,     /* gt holds positive boxes first, then background boxes */
@@ -261,9 +265,10 @@ WSSDL_API int wssdl_roi_targets(const float *rois, const int32_t *keep, const ui
 
 /* ---------------------------------------------------------------- a11, a12 ---
  * RoiPool forward: roi_pooling_op.cc:31-52 (op), kernels roi_pooling_op_gpu.cu.cc:20-85
- * (rounding CUDA) / roi_pooling_op.cc:137-196 (rounding CPU).  N <= 0 = "batch size unknown": the
+ * (rounding CUDA) / roi_pooling_op.cc:137-196 (rounding CPU).  N = WSSDL_ROI_BATCH_UNKNOWN (-1) = "batch size unknown": the
  * reference's ROIPoolForwardLaucher is not told it (roi_pooling_op_gpu.h:17-21) and never range-checks
- * rois[:, 0]; then only a negative batch index makes a RoI empty (with N > 0 an index >= N does too).
+ * rois[:, 0]; then only a negative batch index makes a RoI empty and the caller vouches for the rest (with N > 0 an
+ * index >= N makes an empty RoI too; N == 0 with R > 0 returns WSSDL_ERR_INVALID_ARGUMENT).
  * bottom [N,H,W,C] f32, rois [R,5] f32, top [R,PH,PW,C] f32, argmax [R,PH,PW,C] i32
  * (flat NHWC index within the roi's image, -1 for an empty bin). */
 WSSDL_API int wssdl_roi_pool_forward(const float *bottom, int N, int H, int W, int C, const float *rois,

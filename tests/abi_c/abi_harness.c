@@ -87,10 +87,18 @@ int main(void) {
             int32_t *da = NULL;
             CHECK_HIP(hipMalloc((void **)&dt, sizeof(float) * nt));
             CHECK_HIP(hipMalloc((void **)&da, sizeof(int32_t) * nt));
-            /* N = 0: the reference's ROIPoolForwardLaucher is not told the batch size (roi_pooling_op_gpu.h:17-21);
-             * the harness calls the entry the way that launcher body would */
-            (void)N;
-            CHECK_WS(wssdl_roi_pool_forward(df, 0, H, W, C, dr, R, 7, 7, 1.0f / 16.0f, WSSDL_ROI_ROUND_CUDA, dt, da, st));
+            /* the checked form first (the real N: a batch index >= N would be an empty RoI), then the way the reference's
+             * launcher body would call it: ROIPoolForwardLaucher is not told the batch size (roi_pooling_op_gpu.h:17-21),
+             * N = WSSDL_ROI_BATCH_UNKNOWN.  Every index here is in range, so both give the
+             * same tensors; the second call's are the ones printed.  N = 0 with RoIs is refused. */
+            CHECK_WS(wssdl_roi_pool_forward(df, N, H, W, C, dr, R, 7, 7, 1.0f / 16.0f, WSSDL_ROI_ROUND_CUDA, dt, da, st));
+            if (wssdl_roi_pool_forward(df, 0, H, W, C, dr, R, 7, 7, 1.0f / 16.0f, WSSDL_ROI_ROUND_CUDA, dt, da, st) !=
+                WSSDL_ERR_INVALID_ARGUMENT) {
+                fprintf(stderr, "N = 0 with RoIs must be WSSDL_ERR_INVALID_ARGUMENT\n");
+                return 3;
+            }
+            CHECK_WS(wssdl_roi_pool_forward(df, WSSDL_ROI_BATCH_UNKNOWN, H, W, C, dr, R, 7, 7, 1.0f / 16.0f, WSSDL_ROI_ROUND_CUDA,
+                                            dt, da, st));
             CHECK_HIP(hipStreamSynchronize(st));
             CHECK_HIP(hipMemcpy(top, dt, sizeof(float) * nt, hipMemcpyDeviceToHost));
             CHECK_HIP(hipMemcpy(arg, da, sizeof(int32_t) * nt, hipMemcpyDeviceToHost));

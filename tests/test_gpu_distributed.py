@@ -122,7 +122,8 @@ def test_force_dist_single_rank_rccl_step_equals_plain_step():
     else:
         # `repeat` is the largest difference among FOUR plain repeats (six pairs), `dist` the distance of the RCCL
         # step to the nearest of them: a lost or unscaled bucket shows up at the scale of `moved`, orders above
-        assert res["dist"] <= 2 * res["repeat"], res
+        # (an absolute floor beside it: four noisy repeats can by chance lie closer together than the fifth run does)
+        assert res["dist"] <= max(2 * res["repeat"], 1e-3 * res["moved"]), res
     assert abs(res["loss"][0] - res["loss"][2]) <= 4 * abs(res["loss"][0] - res["loss"][1]) + 1e-6
 
 

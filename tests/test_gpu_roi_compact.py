@@ -224,7 +224,7 @@ def test_i32_contract_forward_on_the_wave_uniform_kernel(torch_cuda, shape, R, P
     """wssdl_roi_pool_forward (the reference op's own two outputs: f32 top + i32 flat-index argmax) runs the
     round-3 forward (one wave per bin row, scalar windows, shared bin columns) with an i32 store for train-sized
     RoI lists: top and argmax bit-equal to the C oracle, RoIs reaching far outside the map included (no window
-    limit on this path), and N = 0 ("batch size unknown", the declared ROIPoolForwardLaucher signature)."""
+    limit on this path), and N = -1 ("batch size unknown", the declared ROIPoolForwardLaucher signature)."""
     torch = torch_cuda
     from wssdl_bus_amd import _lib
     from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
@@ -250,14 +250,21 @@ def test_i32_contract_forward_on_the_wave_uniform_kernel(torch_cuda, shape, R, P
     _lib.check(_lib.lib().wssdl_roi_pool_backward(_lib.ptr(wt), _lib.ptr(arg), _lib.ptr(rt), R, N, H, W, C, P, P, 1.0 / 16,
                                                   _lib.ptr(g0), _lib.stream()), "wssdl_roi_pool_backward")
     assert torch.equal(g0, g)
-    # N = 0: no range check of the batch index (every index here is in range, so the result is the same)
+    # N = -1 (WSSDL_ROI_BATCH_UNKNOWN): no range check of the batch index (every index here is in range, so the result
+    # is the same); N = 0 with RoIs to pool is refused (round 5: it used to mean "unknown" as well)
     top0 = torch.empty_like(top)
     arg0 = torch.empty_like(arg)
-    _lib.check(_lib.lib().wssdl_roi_pool_forward(_lib.ptr(ft), 0, H, W, C, _lib.ptr(rt), R, P, P, 1.0 / 16,
+    _lib.check(_lib.lib().wssdl_roi_pool_forward(_lib.ptr(ft), -1, H, W, C, _lib.ptr(rt), R, P, P, 1.0 / 16,
                                                  {"cuda": 0, "cpu": 1}[mode], _lib.ptr(top0), _lib.ptr(arg0), _lib.stream()),
-               "wssdl_roi_pool_forward(N=0)")
+               "wssdl_roi_pool_forward(N=-1)")
     assert torch.equal(top0, top) and torch.equal(arg0, arg)
-    # with N given, an index >= N is an empty RoI (zeros, -1); with N = 0 it would be read (not tested: out of bounds)
+    assert _lib.lib().wssdl_roi_pool_forward(_lib.ptr(ft), 0, H, W, C, _lib.ptr(rt), R, P, P, 1.0 / 16,
+                                             {"cuda": 0, "cpu": 1}[mode], _lib.ptr(top0), _lib.ptr(arg0),
+                                             _lib.stream()) == _lib.ERR_INVALID_ARGUMENT
+    # a tuned backward plan the i32 form is not built for must not fail the op (advisor, round 4): it takes its own choice
+    with _lib.tuned(roi_bwd_plan=7):
+        assert torch.equal(op.roi_pool_grad(ft, rt, arg, wt, P, P, 1.0 / 16), g)
+    # with N given, an index >= N is an empty RoI (zeros, -1); with N = -1 it would be read (not tested: out of bounds)
     bad = rois.copy()
     bad[7, 0] = N + 3
     bad[8, 0] = -1

@@ -27,3 +27,26 @@ def test_imread_refuses_colour_and_16_bit_files(tmp_path):
     for f in (rgb, deep):
         with pytest.raises(ValueError):
             B.imread(f)
+
+
+def test_imread_palette_and_bilevel_files(tmp_path):
+    """skimage.io.imread expands a colour palette to RGB and returns bool for 1-bit files: neither is the plane the
+    reference's pipeline stacks, so both are refused; an identity grey palette decodes to the plane 'L' would give."""
+    from PIL import Image
+    from wssdl_bus_amd.utils import blob as B
+    p = np.random.RandomState(1).randint(0, 256, (9, 11)).astype(np.uint8)
+    grey = Image.fromarray(p).convert("P")
+    grey.putpalette([v for k in range(256) for v in (k, k, k)])
+    f = str(tmp_path / "grey_palette.png")
+    grey.save(f)
+    assert np.array_equal(B.imread(f), p)
+    colour = Image.fromarray(p).convert("P")
+    colour.putpalette([v for k in range(256) for v in (k, 255 - k, (3 * k) % 256)])
+    f = str(tmp_path / "colour_palette.png")
+    colour.save(f)
+    with pytest.raises(ValueError, match="palette"):
+        B.imread(f)
+    f = str(tmp_path / "bilevel.png")
+    Image.fromarray(p > 127).save(f)
+    with pytest.raises(ValueError, match="mode 1"):
+        B.imread(f)

@@ -524,10 +524,12 @@ extern "C" int wssdl_roi_pool_forward(const float *bottom, int N, int H, int W, 
     if ((long long)H * W * C > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;  // argmax is i32
     if (R == 0) return WSSDL_OK;
     if (!bottom || !rois || !top || !argmax) return WSSDL_ERR_INVALID_ARGUMENT;
-    // N <= 0: the batch size is unknown -- the reference's ROIPoolForwardLaucher is not told it
-    // (roi_pooling_op_gpu.h:17-21) and never range-checks the batch index -- so only a negative index
-    // makes a RoI empty here; with N > 0 an index >= N does too.
-    if (N <= 0) N = 0x7fffffff;
+    // N = WSSDL_ROI_BATCH_UNKNOWN (-1): the batch size is unknown -- the reference's ROIPoolForwardLaucher is not told
+    // it (roi_pooling_op_gpu.h:17-21) and never range-checks the batch index -- so only a negative index makes a RoI
+    // empty here and an index beyond the caller's tensor is read, as in the reference; with N > 0 an index >= N makes
+    // an empty RoI too.  N == 0 with RoIs to pool is a caller's mistake, not a request for the unchecked form.
+    if (N == 0 || N < WSSDL_ROI_BATCH_UNKNOWN) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (N == WSSDL_ROI_BATCH_UNKNOWN) N = 0x7fffffff;
     hipStream_t st = as_stream(stream);
     {   // the round-3 kernel (one wave per bin row, scalar windows, shared columns) with an i32 store
         const int rc = launch_fwd_rows_i32(bottom, N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top,
@@ -585,7 +587,11 @@ extern "C" int wssdl_roi_pool_backward_ws(const float *top_diff, const int32_t *
         // 8 bytes per element instead of 5: the train-sized launch is even more bandwidth-bound than on the 1-byte
         // path and wants the larger 6x8 tiles (fewer border re-reads): 0.83 against 0.87 ms at R = 8512 x 1024
         // channels (tools/bwd_fixed_sweep.py --i32); "roi_bwd_plan" still overrides
-        const int force = (tuning().roi_bwd_plan < 0 && walk_plan_auto_id(N, H, W, C) == 11) ? 9 : -1;
+        // a tuned plan the i32 form is not built for (the knob must not change results, let alone fail the call): the
+        // automatic choice instead
+        const int tuned = tuning().roi_bwd_plan;
+        const int auto_plan = walk_plan_auto_id(N, H, W, C) == 11 ? 9 : walk_plan_auto_id(N, H, W, C);
+        const int force = (tuned >= 0 && walk_i32_plan_built(tuned)) ? tuned : auto_plan;
         // (the window starts the lists also carry are not read on this path: the rounding mode does not matter)
         int rc = walk_prepare(rois, R, N, H, W, C, pooled_h, pooled_w, spatial_scale, WSSDL_ROI_ROUND_CUDA, workspace,
                               workspace_bytes, &plan, st, force);

@@ -110,6 +110,7 @@ int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, 
                 int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, hipStream_t st,
                 int nseg = 1, float *partial = nullptr, bool i32 = false /* arg8 points at the i32 arg-max */);
 bool walk_i32_supported(int R, int N, int H, int W, int C, int PH, int PW);
+bool walk_i32_plan_built(int id);
 int walk_split_segments(int R, int N, int H, int W, int C);
 // bin-owner form (round 5): every bin listed by one tile, halos merged afterwards
 int owner_plan_count();

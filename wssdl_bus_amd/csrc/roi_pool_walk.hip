@@ -875,6 +875,12 @@ static bool walk_i32_params(int H, int W, int C, WalkI32 *q) {
     return false;
 }
 
+// the plans the i32 form of the walk is instantiated for (launch_walk_t: I32_BUILT)
+bool walk_i32_plan_built(int id) {
+    return id == 11 || id == 5 || id == 23 || id == 18 || id == 22 || id == 19 || id == 21 || id == 9 || id == 12 ||
+           id == 17 || id == 4 || id == 13 || id == 14;
+}
+
 bool walk_i32_supported(int R, int N, int H, int W, int C, int PH, int PW) {
     WalkI32 q;
     return walk_supported(R, N, H, W, C, PH, PW) && walk_i32_params(H, W, C, &q);
@@ -900,7 +906,7 @@ static int launch_walk_t(const float *top_diff, const unsigned char *arg8, int R
     WalkI32 q = {0, 0u, 0u};
     // (the i32 form is only built for the plans walk_plan_auto can pick)
     constexpr bool I32_BUILT = ID == 11 || ID == 5 || ID == 23 || ID == 18 || ID == 22 || ID == 19 || ID == 21 ||
-                               ID == 9 || ID == 12 || ID == 17 || ID == 4 || ID == 13 || ID == 14;      // + candidates of the i32 plan sweep
+                               ID == 9 || ID == 12 || ID == 17 || ID == 4 || ID == 13 || ID == 14;      // == walk_i32_plan_built(ID)
     if (i32 && !I32_BUILT) return WSSDL_ERR_INVALID_ARGUMENT;
     if constexpr (I32_BUILT) if (i32) {
         if (!walk_i32_params(H, W, C, &q)) return WSSDL_ERR_INVALID_ARGUMENT;

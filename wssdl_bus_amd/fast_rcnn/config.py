@@ -33,8 +33,10 @@ __C.TRAIN.WS_MAL_PCT = 0.2209                       # :60
 __C.TRAIN.MAX_GT_PER_IMAGE = 20                     # :92
 __C.TRAIN.SCALES = (600,)                           # :109
 __C.TRAIN.MAX_SIZE = 1000                           # :112
-# augmentation of the host image path (utils/blob.py): rotation needs skimage.transform.rotate, which is
-# absent and unpinned -- the reference's default True is not available here
+# augmentation of the image path (utils/blob.py): the reference's default.  skimage.transform.rotate / resize are
+# restated from scikit-image 0.14.2's published algorithm as device kernels (csrc/image.hip; the library itself is
+# absent): that part of the DEFAULT input pipeline is PARITY UNPINNED -- checked against this repo's own restatement
+# and a second scipy implementation, never against a scikit-image run (README.md)
 __C.TRAIN.USE_ROTATION = True                       # :136
 __C.TRAIN.ROTATION_MAX_ANGLE = 5                    # :137
 __C.TRAIN.USE_CROPPING = True                       # :140

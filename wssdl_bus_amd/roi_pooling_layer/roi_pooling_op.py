@@ -338,7 +338,8 @@ def prepare_backward(shape, rois, pooled_height, pooled_width, spatial_scale, ro
 
 def split_segments(shape, R):
     """How many segments the list-driven backward cuts a tile's slot stream into for this launch:
-    cfg.ROI_POOL_BWD_SPLIT = 'auto' (the library's rule: few images with >= 1000 RoIs each -> 8), an int, or
+    cfg.ROI_POOL_BWD_SPLIT = 'auto' (the library's rule, wssdl_roi_pool_backward_split_segments: at most 4 images with
+    >= 1000 RoIs each -> 8 segments, 4 for two / three images x 1024 channels, else 1), an int, or
     0 / 1 for the exact walk.  > 1 is deterministic but NOT bit-identical to the reference's summation order."""
     v = cfg.get("ROI_POOL_BWD_SPLIT", "auto")
     N, H, W, C = shape

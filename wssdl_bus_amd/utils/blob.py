@@ -245,8 +245,17 @@ def imread(path):
     the decoded plane on runs on the device.  Colour / 16-bit files are refused rather than converted silently."""
     from PIL import Image
     with Image.open(path) as im:
-        if im.mode not in ("L", "P", "1"):
-            raise ValueError("%s: mode %s -- the reference's pipeline stacks ONE grey plane three times "
+        if im.mode == "P":
+            # skimage.io.imread expands a palette: a COLOUR palette gives an RGB array (not this pipeline's input),
+            # an identity grey palette gives the same plane 'L' would -- only that one is accepted
+            pal = im.getpalette() or []
+            grey = len(pal) >= 768 and all(pal[3 * k] == pal[3 * k + 1] == pal[3 * k + 2] == k for k in range(256))
+            if not grey:
+                raise ValueError("%s: palette image whose palette is not the identity grey ramp -- skimage.io.imread "
+                                 "would hand the reference an RGB array; convert the file first" % path)
+        elif im.mode != "L":
+            # ('1' included: skimage.io.imread returns a bool array for it, not a 0/255 plane)
+            raise ValueError("%s: mode %s -- the reference's pipeline stacks ONE 8-bit grey plane three times "
                              "(minibatch_bus.py:270); convert the file first" % (path, im.mode))
         plane = np.asarray(im.convert("L"), dtype=np.uint8)
     if plane.ndim != 2:
