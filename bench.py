@@ -283,9 +283,11 @@ def hbm_traffic(kernel_key, meta):
     have = tj.get("launch", {})
     if any(have.get(k) != v for k, v in want.items()):
         return None, "stale: profiles/hotpath_traffic.json was taken for %s, this run is %s" % (have, want)
-    for k, v in tj.get("kernels", {}).items():
-        if kernel_key in k:
-            return int(v["hbm_bytes_per_launch"]), "profiles/hotpath_traffic.json (%s)" % k
+    # (the bin-owner backward is two kernels, the walk and the halo merge: their bytes add up)
+    keys = {"roi_pool_bwd": ("roi_pool_bwd_walk_kernel", "walk_merge_kernel")}.get(kernel_key, (kernel_key,))
+    hit = [(k, v) for k, v in tj.get("kernels", {}).items() if any(q in k for q in keys)]
+    if hit:
+        return int(sum(v["hbm_bytes_per_launch"] for _, v in hit)), "profiles/hotpath_traffic.json (%s)" % " + ".join(k for k, _ in hit)
     return None, "kernel not in profiles/hotpath_traffic.json"
 
 
@@ -523,12 +525,22 @@ def main():
             frac_moved_with_helpers=round(moved / ((d["avg_ms"] + helper_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             launches=d["calls"], measured_d2d_copy=round(measured_copy_gbps(), 1),
             note="achieved / frac = bytes this implementation must move (f32 top_diff + 1-byte arg-max codes + "
-                 "bottom_diff once) / launch time of the dominant kernel alone; its helper launches (window "
+                 "bottom_diff once) / launch time of the dominant op alone (the slower of the RoI-pool pair; the backward's "
+                 "default form since round 5 is the bin-owner walk = walk kernel + halo merge, see launch.backward_variant, "
+                 "with the exact walk kept as the bit-for-bit parity reference); its helper launches (window "
                  "table / list building, latency-bound chains) are in helper_launches_ms and "
                  "frac_moved_with_helpers.  frac_8d uses SURVEY.md 8(d)'s bytes for the reference's f32 + i32 "
                  "layout.  RoI-pool parity is pinned by hand-computed cases and two independent oracle "
                  "restatements, not by reference outputs (TensorFlow op cannot be built here: 'parity unpinned', "
                  "DESIGN.md section 2)",
+            # both kernels of the pair (round 5: within a few per cent of each other, so which one is "dominant" can
+            # change from box to box): launch time, fraction of peak on moved bytes, HBM-side bytes of the PMC passes
+            pair={k: dict(avg_ms=round(leg[k]["avg_ms"], 4),
+                          frac_moved=round(leg[k].get("min_moved_bytes", leg[k]["alg_bytes_per_launch"]) / (leg[k]["avg_ms"] * 1e-3)
+                                           / 1e9 / HBM_PEAK_GBPS, 4),
+                          traffic=hbm_traffic({"roi_pool_forward": "roi_pool_fwd", "roi_pool_backward": "roi_pool_bwd"}[k], leg_meta)[0],
+                          kernels=(2 if (k == "roi_pool_backward" and (leg_meta.get("backward_owner_plan") or -1) >= 0) else 1))
+                  for k in single},
             fixed_set={k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                        for k, v in leg.items()},
             per_kernel={k: dict(avg_ms=round(v["avg_ms"], 4), calls=v["calls"],

@@ -394,6 +394,14 @@ WSSDL_API int wssdl_roi_pool_backward_compact_owner(const float *top_diff, const
                             int pooled_w, float spatial_scale, int rounding, float *bottom_diff,
                             void *workspace, size_t workspace_bytes, int owner_plan,
                             void *scratch, size_t scratch_bytes, wssdl_stream_t stream);
+/* The bin-owner form reading the reference op's OWN arg-max layout (i32 flat index, roi_pooling_op_gpu.cu.cc:71-79): list
+ * building + walk + halo merge in one call, owner plans 0 and 1.  Opt-in: RoiPoolGrad's declared contract
+ * (wssdl_roi_pool_backward / _ws) stays the exact walk, bit for bit; this one is deterministic within the owner form's
+ * bounds.  workspace = wssdl_roi_pool_backward_workspace_bytes, scratch = ..._owner_scratch_bytes. */
+WSSDL_API int wssdl_roi_pool_backward_owner_i32(const float *top_diff, const int32_t *argmax, const float *rois, int R, int N,
+                            int H, int W, int C, int pooled_h, int pooled_w, float spatial_scale, float *bottom_diff,
+                            void *workspace, size_t workspace_bytes, int owner_plan, void *scratch, size_t scratch_bytes,
+                            wssdl_stream_t stream);
 WSSDL_API int wssdl_roi_argmax_expand(const uint8_t *argmax8, const float *rois, int R, int H, int W,
                             int C, int pooled_h, int pooled_w, float spatial_scale, int rounding,
                             int32_t *argmax, wssdl_stream_t stream);

@@ -397,6 +397,49 @@ def test_owner_walk_vs_oracle(torch_cuda, shape, mode):
         assert not op.flags_raised()
 
 
+@pytest.mark.parametrize("shape", [(3, 38, 63, 1024), (2, 25, 40, 256)])
+def test_owner_form_with_the_reference_ops_i32_argmax(torch_cuda, shape):
+    """wssdl_roi_pool_backward_owner_i32: the bin-owner walk reading the reference op's own arg-max layout (i32 flat index,
+    roi_pooling_op_gpu.cu.cc:71-79), list building + walk + merge in one call (opt-in; the declared contract stays
+    the exact walk).  Integer-valued top_diff: bit-equal to the oracle; real-valued: repeatable, within 1e-5 of scale."""
+    torch = torch_cuda
+    from wssdl_bus_amd import _lib
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    N, H, W, C = shape
+    rs = np.random.RandomState(C + 11)
+    f = np.maximum(rs.normal(size=shape), 0).astype(np.float32)
+    rois = _rois_for(rs, 600, N, H, W)
+    et, ea = c_oracle.roi_pool_forward(f, rois, 7, 7, 1.0 / 16, "cuda", threads=16)
+    ft, rt = torch.from_numpy(f).cuda(), torch.from_numpy(rois).cuda()
+    top, arg = op.roi_pool(ft, rt, 7, 7, 1.0 / 16)
+    assert np.array_equal(arg.cpu().numpy(), ea)
+    L = _lib.lib()
+    R = rois.shape[0]
+    for owner in (0, 1):
+        nws = L.wssdl_roi_pool_backward_workspace_bytes(R, N, H, W, 7, 7)
+        nscr = L.wssdl_roi_pool_backward_owner_scratch_bytes(N, H, W, C, owner)
+        ws = torch.empty((nws,), dtype=torch.uint8, device="cuda")
+        scr = torch.empty((nscr,), dtype=torch.uint8, device="cuda")
+
+        def run(d):
+            out = torch.empty(shape, dtype=torch.float32, device="cuda")
+            _lib.check(L.wssdl_roi_pool_backward_owner_i32(_lib.ptr(d), _lib.ptr(arg), _lib.ptr(rt), R, N, H, W, C, 7, 7, 1.0 / 16,
+                                                           _lib.ptr(out), _lib.ptr(ws), nws, owner, _lib.ptr(scr), nscr,
+                                                           _lib.stream()), "wssdl_roi_pool_backward_owner_i32")
+            return out
+        ints = rs.randint(-8, 9, size=et.shape).astype(np.float32)
+        assert np.array_equal(run(torch.from_numpy(ints).cuda()).cpu().numpy(),
+                              c_oracle.roi_pool_backward(ints, ea, rois, f.shape, 7, 7, 1.0 / 16)), owner
+        real = rs.normal(size=et.shape).astype(np.float32)
+        want = c_oracle.roi_pool_backward(real, ea, rois, f.shape, 7, 7, 1.0 / 16)
+        rl = torch.from_numpy(real).cuda()
+        a, b = run(rl), run(rl)
+        assert torch.equal(a, b)
+        assert np.abs(a.cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()
+    assert L.wssdl_roi_pool_backward_owner_i32(_lib.ptr(rl), _lib.ptr(arg), _lib.ptr(rt), R, N, H, W, C, 7, 7, 1.0 / 16,
+                                               _lib.ptr(a), _lib.ptr(ws), nws, 2, _lib.ptr(scr), nscr, _lib.stream()) != 0
+
+
 def test_owner_rule_and_autograd(torch_cuda):
     """Which launches the library sends to the bin-owner form (wssdl_roi_pool_backward_owner_plan; measured in
     tools/owner_ab.sh) and the autograd pair under cfg.ROI_POOL_BWD_OWNER / _EXACT."""

@@ -111,6 +111,24 @@ def main():
                                   alg8d_TBps=round(ab / ms / 1e9, 3), frac_8d=round(ab / ms / 1e9 / 8.0, 3))), flush=True)
             assert same, p
         _lib.set_tuning("roi_bwd_plan", -1)
+        scale = float(ref.abs().max())
+        for o in (0, 1):
+            nws = L.wssdl_roi_pool_backward_workspace_bytes(R, N, H, W, 7, 7)
+            nscr = L.wssdl_roi_pool_backward_owner_scratch_bytes(N, H, W, C, o)
+            ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
+            scr = torch.empty((nscr,), dtype=torch.uint8, device=dev)
+            out = torch.empty(shape, dtype=torch.float32, device=dev)
+
+            def call():
+                _lib.check(L.wssdl_roi_pool_backward_owner_i32(_lib.ptr(diff), _lib.ptr(arg), _lib.ptr(rois), R, N, H, W, C, 7, 7,
+                                                               1.0 / 16, _lib.ptr(out), _lib.ptr(ws), nws, o, _lib.ptr(scr), nscr,
+                                                               _lib.stream()), "wssdl_roi_pool_backward_owner_i32")
+            call()
+            rel = float((out - ref).abs().max()) / scale
+            ms = timeit(call, args.iters)
+            print(json.dumps(dict(i32=True, owner=o, prepare_plus_walk_plus_merge_ms=round(ms, 4), max_diff_over_max_abs=rel,
+                                  alg8d_TBps=round(ab / ms / 1e9, 3), frac_8d=round(ab / ms / 1e9 / 8.0, 3))), flush=True)
+            assert rel <= 1e-5, o
         return
     if args.one_owner:
         plan = op.roi_pool_grad_prepare_owner(shape, rois, 7, 7, 1.0 / 16, int(args.one_owner))

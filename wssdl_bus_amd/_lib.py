@@ -78,6 +78,7 @@ SYMBOLS = {
     "wssdl_roi_pool_backward_owner_prepare": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _i, _vp]),
     "wssdl_roi_pool_backward_compact_owner": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _i,
                                                    _vp, _sz, _vp]),
+    "wssdl_roi_pool_backward_owner_i32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _sz, _i, _vp, _sz, _vp]),
     "wssdl_roi_argmax_expand": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "wssdl_image_prep_workspace_bytes": (_sz, []),
     "wssdl_image_prep": (_i, [_vp, _i, _i, _i, _i, _i, _f, _i, _f, _d, _vp, _vp, _sz, _vp]),

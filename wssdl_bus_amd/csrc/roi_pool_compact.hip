@@ -983,6 +983,30 @@ extern "C" int wssdl_roi_pool_backward_compact_owner(const float *top_diff, cons
                         owner_plan, static_cast<float *>(scratch), as_stream(stream));
 }
 
+extern "C" int wssdl_roi_pool_backward_owner_i32(const float *top_diff, const int32_t *argmax, const float *rois, int R, int N,
+                                                 int H, int W, int C, int pooled_h, int pooled_w, float spatial_scale,
+                                                 float *bottom_diff, void *workspace, size_t workspace_bytes, int owner_plan,
+                                                 void *scratch, size_t scratch_bytes, wssdl_stream_t stream) {
+    if (N < 0 || R < 0 || H < 1 || W < 1 || C < 1 || pooled_h < 1 || pooled_w < 1) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (N == 0) return WSSDL_OK;
+    if (!bottom_diff || (R > 0 && (!top_diff || !argmax || !rois))) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (!workspace || !owner_supported(R, N, H, W, C, pooled_h, pooled_w) || !walk_i32_supported(R, N, H, W, C, pooled_h, pooled_w))
+        return WSSDL_ERR_INVALID_ARGUMENT;
+    const size_t need = owner_scratch_bytes(N, H, W, C, owner_plan);
+    if (need == 0) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (!scratch || scratch_bytes < need || (reinterpret_cast<uintptr_t>(scratch) & 15) ||
+        (reinterpret_cast<uintptr_t>(bottom_diff) & 15) || (reinterpret_cast<uintptr_t>(argmax) & 7) ||
+        (reinterpret_cast<uintptr_t>(top_diff) & 7))
+        return WSSDL_ERR_WORKSPACE;
+    // (the lists carry window starts this path does not read: the rounding mode does not matter)
+    const int rc = owner_prepare(rois, R, N, H, W, C, pooled_h, pooled_w, spatial_scale, WSSDL_ROI_ROUND_CUDA, workspace,
+                                 workspace_bytes, owner_plan, as_stream(stream));
+    if (rc != WSSDL_OK) return rc;
+    return launch_owner(top_diff, reinterpret_cast<const unsigned char *>(argmax), R, N, H, W, C, pooled_h, pooled_w,
+                        bottom_diff, workspace, workspace_bytes, owner_plan, static_cast<float *>(scratch), as_stream(stream),
+                        true);
+}
+
 extern "C" int wssdl_roi_pool_backward_compact(const float *top_diff, const uint8_t *argmax8,
                                                const float *rois, int R, int N, int H, int W, int C,
                                                int pooled_h, int pooled_w, float spatial_scale,

@@ -1033,9 +1033,10 @@ int owner_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, 
     }
 }
 
-template <int RH, int RW, int SH, int SW, int DEPTH, int MINW, int CPL, int AUX>
+template <int ID, int RH, int RW, int SH, int SW, int DEPTH, int MINW, int CPL, int AUX>
 static int launch_owner_t(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH,
-                          int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, float *halo, hipStream_t st) {
+                          int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, float *halo, hipStream_t st,
+                          bool i32) {
     const int tiles_h = cdiv(H, SH), tiles_w = cdiv(W, SW), tiles = tiles_h * tiles_w;
     const int items = N * tiles;
     WalkWs ws;
@@ -1049,6 +1050,16 @@ static int launch_owner_t(const float *top_diff, const unsigned char *arg8, int 
     else blocks = (long long)items * G;
     if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
     WalkI32 q = {0, 0u, 0u};
+    // (the i32 arg-max -- the reference op's own layout -- is built for owner plans 0 and 1: tools/bwd_fixed_sweep.py --i32-owner)
+    constexpr bool I32_BUILT = ID == 0 || ID == 1;
+    if (i32 && !I32_BUILT) return WSSDL_ERR_INVALID_ARGUMENT;
+    if constexpr (I32_BUILT) if (i32) {
+        if (!walk_i32_params(H, W, C, &q)) return WSSDL_ERR_INVALID_ARGUMENT;
+        hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<RH, RW, DEPTH, MINW, CPL, true, true, AUX>), dim3((unsigned)blocks, 1u), dim3(64),
+                           0, st, top_diff, arg8, reinterpret_cast<const unsigned *>(ws.slots), ws.tile_off, ws.tile_slots,
+                           ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff, 1, halo, 0ull, q, SH, SW);
+    }
+    if (!i32)
     hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<RH, RW, DEPTH, MINW, CPL, false, true, AUX>), dim3((unsigned)blocks, 1u), dim3(64),
                        0, st, top_diff, arg8, reinterpret_cast<const unsigned *>(ws.slots), ws.tile_off, ws.tile_slots,
                        ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff, 1, halo, 0ull, q, SH, SW);
@@ -1061,11 +1072,11 @@ static int launch_owner_t(const float *top_diff, const unsigned char *arg8, int 
 }
 
 int launch_owner(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH, int PW,
-                 float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, float *halo, hipStream_t st) {
+                 float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, float *halo, hipStream_t st, bool i32) {
     switch (plan) {
 #define WSSDL_X(ID, RH, RW, SH, SW, D, MW, CPL, AUX) \
-        case ID: return launch_owner_t<RH, RW, SH, SW, D, MW, CPL, AUX>(top_diff, arg8, R, N, H, W, C, PH, PW, bottom_diff, workspace, \
-                                                                workspace_bytes, halo, st);
+        case ID: return launch_owner_t<ID, RH, RW, SH, SW, D, MW, CPL, AUX>(top_diff, arg8, R, N, H, W, C, PH, PW, bottom_diff, workspace, \
+                                                                workspace_bytes, halo, st, i32);
         WSSDL_OWNER_PLANS(WSSDL_X)
 #undef WSSDL_X
         default: return WSSDL_ERR_INVALID_ARGUMENT;
