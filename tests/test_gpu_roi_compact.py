@@ -448,11 +448,11 @@ def test_owner_rule_and_autograd(torch_cuda):
     from wssdl_bus_amd.fast_rcnn.config import cfg
     from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
     L = _lib.lib()
-    assert L.wssdl_roi_pool_backward_owner_plan(8512, 8, 38, 63, 1024) == 0      # the default workload
-    assert L.wssdl_roi_pool_backward_owner_plan(4000, 2, 38, 63, 1024) == 0      # alternating weak step
-    assert L.wssdl_roi_pool_backward_owner_plan(4128, 3, 38, 63, 1024) == 0      # the reference's default 1 + 2 batch
-    assert L.wssdl_roi_pool_backward_owner_plan(4128, 3, 37, 62, 512) == 1       # VGG-16: 4x4 tiles
-    assert L.wssdl_roi_pool_backward_owner_plan(2000, 1, 38, 63, 1024) == 1
+    assert L.wssdl_roi_pool_backward_owner_plan(8512, 8, 38, 63, 1024) == 8      # the default workload
+    assert L.wssdl_roi_pool_backward_owner_plan(4000, 2, 38, 63, 1024) == 8      # alternating weak step
+    assert L.wssdl_roi_pool_backward_owner_plan(4128, 3, 38, 63, 1024) == 8      # the reference's default 1 + 2 batch
+    assert L.wssdl_roi_pool_backward_owner_plan(4128, 3, 37, 62, 512) == -1      # VGG-16 (1536 pairs): the split form
+    assert L.wssdl_roi_pool_backward_owner_plan(2000, 1, 38, 63, 1024) == -1
     assert L.wssdl_roi_pool_backward_owner_plan(4000, 2, 38, 63, 256) == -1      # ResNet-18: the split form
     assert L.wssdl_roi_pool_backward_owner_plan(1024, 8, 38, 63, 1024) == -1     # supervised-only step: the exact walk
     assert L.wssdl_roi_pool_backward_owner_plan(300, 1, 63, 100, 1024) == -1
@@ -460,7 +460,7 @@ def test_owner_rule_and_autograd(torch_cuda):
     nscr = L.wssdl_roi_pool_backward_owner_scratch_bytes(8, 38, 63, 1024, 0)
     assert nscr == 8 * 10 * 13 * 6 * 7 * 1024 * 4                                 # tiles of 4 x 5 cells, regions of 6 x 7
     rs = np.random.RandomState(33)
-    N, H, W, C = 2, 38, 63, 512
+    N, H, W, C = 2, 38, 63, 1024
     R = 2400
     f_np = np.maximum(rs.normal(size=(N, H, W, C)), 0).astype(np.float32)
     ctr = rs.normal([500, 300], [200, 120], size=(R, 2))
@@ -474,7 +474,7 @@ def test_owner_rule_and_autograd(torch_cuda):
     mag = c_oracle.roi_pool_backward(np.abs(w_np), want_a, rois_np, f_np.shape, 7, 7, 1.0 / 16)
     scale = float(np.abs(want_g).max())
     ft, rt, wt = torch.from_numpy(f_np).cuda(), torch.from_numpy(rois_np).cuda(), torch.from_numpy(w_np).cuda()
-    assert cfg.ROI_POOL_BWD_OWNER == "auto" and not cfg.ROI_POOL_BWD_EXACT and op.owner_plan((N, H, W, C), R) == 1
+    assert cfg.ROI_POOL_BWD_OWNER == "auto" and not cfg.ROI_POOL_BWD_EXACT and op.owner_plan((N, H, W, C), R) == 8
     saved = (cfg.ROI_POOL_BWD_OWNER, cfg.ROI_POOL_BWD_EXACT)
     try:
         for owner, exact, bits in (("auto", False, False), (0, False, False), ("auto", True, True), (-1, False, False)):
@@ -590,10 +590,10 @@ def test_roofline_roi_set_matches_oracle(torch_cuda):
     """Parity ON the timed workload, in full (round 5: all eight images = all 8512 RoIs of the fixed roofline set):
     top, expanded arg-max and the exact walk's bottom_diff bit for bit -- the plan the library picks for the exact
     walk, 6x6 tiles with two and three records in flight, a 64-channel plan -- and the bin-owner form the bench line
-    times (owner plans 0 and 1) at its tolerance."""
+    times (owner plan 8 = plan 0 with the lean decode; plans 0 and 1) at its tolerance."""
     from wssdl_bus_amd import _lib
-    assert _lib.lib().wssdl_roi_pool_backward_owner_plan(8512, 8, 38, 63, 1024) == 0
-    checked, plans = roofline_set_parity(torch_cuda, images=tuple(range(8)), plans=(None, 11, 13, 23), owners=(0, 1))
+    assert _lib.lib().wssdl_roi_pool_backward_owner_plan(8512, 8, 38, 63, 1024) == 8
+    checked, plans = roofline_set_parity(torch_cuda, images=tuple(range(8)), plans=(None, 11, 13, 23), owners=(8, 0, 1))
     assert checked == {0: 128, 1: 128, 2: 128, 3: 128, 4: 2000, 5: 2000, 6: 2000, 7: 2000}
 
 

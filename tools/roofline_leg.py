@@ -136,7 +136,7 @@ def main():
     if args.check:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from test_gpu_roi_compact import roofline_set_parity
-        checked, plans = roofline_set_parity(torch, owners=(0,))
+        checked, plans = roofline_set_parity(torch, owners=(8,))
         print(json.dumps(dict(check="top, argmax, bottom_diff == C oracle", rois_per_image=checked, plans=plans)))
     rois, tag = load_rois(args.rois) if args.rois else load_rois()
     if args.roi_bwd_plan >= 0:

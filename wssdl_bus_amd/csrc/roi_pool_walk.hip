@@ -312,6 +312,29 @@ __global__ __launch_bounds__(FILL_BLOCK) void walk_count_kernel(
     if (threadIdx.x == 0) tile_slots[item] = nslots;
 }
 
+// Lean decode (round 5, bin-owner plans): a slot's row mask is an INTERVAL of region lines -- in_roi is one, the
+// candidate test phstart(h) <= ph < phend(h) (roi_pooling_op_gpu.cu.cc:169-177) intersects a prefix and a suffix
+// because floor((h - rs) / bin) and ceil((h - rs + 1) / bin) are monotone in h, the owner form's cover range is one --
+// and so is the column mask.  With th = hs + ch (ch = code >> 4) the test "bit th of rm" becomes
+// (ch - lo_h) <u n_h with lo_h = first line of the interval - hs, and the cell th * RW + tw = ch * RW + cw + base with
+// base = hs * RW + ws: two subtract-and-compare pairs and one multiply-add per channel instead of two variable
+// shifts, four ANDs and the range bookkeeping.  The empty code 0xff (ch = 15) can never pass: lo_h + n_h > 15 would
+// need a window of 16 rows.  w1 = lo_h (signed 6) | n_h (4) << 6 | lo_w (signed 6) << 10 | n_w (4) << 16 | base (signed 10) << 20.
+__device__ __forceinline__ unsigned lean_word(unsigned w, int rw, bool *interval) {      // (the format, slot by slot; walk_fill_kernel builds the same word from per-axis halves)
+    const unsigned rm = w & 0xffu, cm = (w >> 8) & 0xffu;
+    const int hs = ((int)(w << 11)) >> 27, ws = ((int)(w << 6)) >> 27;
+    const int h0 = rm ? __ffs((int)rm) - 1 : 0, hn = __popc(rm);
+    const int w0 = cm ? __ffs((int)cm) - 1 : 0, wn = __popc(cm);
+    *interval = (rm == (((1u << hn) - 1u) << h0)) && (cm == (((1u << wn) - 1u) << w0));
+    // an empty mask on either axis: n = 0 fails every code; a clamped window start (|hs| = 16: the window lies wholly
+    // outside the region) keeps lo out of the codes' range
+    const int lo_h = min(max(h0 - hs, -32), 31), lo_w = min(max(w0 - ws, -32), 31);
+    const int base = hs * rw + ws;
+    const int nh = (rm && cm) ? hn : 0, nw = (rm && cm) ? wn : 0;
+    return ((unsigned)lo_h & 63u) | ((unsigned)nh << 6) | (((unsigned)lo_w & 63u) << 10) | ((unsigned)nw << 16) |
+           (((unsigned)base & 1023u) << 20);
+}
+
 // pass 2 (after the offsets are known): the slot stream of one (image, tile), in (roi, ph, pw) order
 //   slot = w0 | w1 << 32:  w0 = element offset of the bin (r * PH*PW*C + bin * C),
 //   w1 = rm | cm << 8 | (hs & 31) << 16 | (ws & 31) << 21: the 8 mask bits of the bin's row /
@@ -322,7 +345,9 @@ __global__ __launch_bounds__(FILL_BLOCK) void walk_fill_kernel(
     const int *__restrict__ img_span, const unsigned long long *__restrict__ rowtab,
     const unsigned long long *__restrict__ coltab, const int *__restrict__ tile_off,
     const int *__restrict__ tile_slots, unsigned long long *__restrict__ slots, long long cap_records,
-    unsigned total_elems, int *__restrict__ total) {
+    unsigned total_elems, int *__restrict__ total, int lean_rw) {
+    // lean_rw > 0 (owner plans with the lean decode, round 5): w1 carries the masks as INTERVALS in code space and the
+    // region cell of code (0, 0) -- see lean_word() -- for a region lean_rw cells wide
     __shared__ int wave_sums[FILL_BLOCK / 64];
     const int tiles = tiles_h * tiles_w;
     const int item = blockIdx.x;
@@ -353,6 +378,40 @@ __global__ __launch_bounds__(FILL_BLOCK) void walk_fill_kernel(
             long long pos = first + run + ex;
             const int phn = axis_pn(rinfo), pwn = axis_pn(cinfo);
             const unsigned e0 = (unsigned)r * (unsigned)(PHPW * C) + (unsigned)((axis_p0(rinfo) * PW + axis_p0(cinfo)) * C);
+            if (lean_rw > 0) {
+                // the column halves of the lean words once per RoI (at most 8 bins), the row half once per bin row
+                unsigned cpart[8];
+                int cws[8];
+                bool good = true;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned cm = (unsigned)(cmask >> (8 * j)) & 0xffu;
+                    const int ws = ((int)(((unsigned)(cinfo >> (5 * j)) & 31u) << 27)) >> 27;
+                    const int w0 = cm ? __ffs((int)cm) - 1 : 0, wn = __popc(cm);
+                    good = good && (cm == (((1u << wn) - 1u) << w0));
+                    cpart[j] = (((unsigned)min(max(w0 - ws, -32), 31) & 63u) << 10) | ((unsigned)wn << 16);
+                    cws[j] = ws;
+                }
+                for (int q = 0; q < phn; ++q) {
+                    const unsigned rm = (unsigned)(rmask >> (8 * q)) & 0xffu;
+                    const int hs = ((int)(((unsigned)(rinfo >> (5 * q)) & 31u) << 27)) >> 27;
+                    const int h0 = rm ? __ffs((int)rm) - 1 : 0, hn = __popc(rm);
+                    good = good && (rm == (((1u << hn) - 1u) << h0));
+                    const unsigned rpart = ((unsigned)min(max(h0 - hs, -32), 31) & 63u) | ((unsigned)hn << 6);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (j >= pwn) break;
+                        // (an empty mask on either axis: n_h = 0 fails every code)
+                        const bool any = rm != 0u && ((cpart[j] >> 16) & 15u) != 0u;
+                        const unsigned whi = (any ? rpart : (rpart & 63u)) | cpart[j] |
+                                             (((unsigned)(hs * lean_rw + cws[j]) & 1023u) << 20);
+                        const unsigned wlo = e0 + (unsigned)((q * PW + j) * C);
+                        if (pos < cap) slots[pos] = (unsigned long long)wlo | ((unsigned long long)whi << 32);
+                        ++pos;
+                    }
+                }
+                if (!good) atomicOr(&total[1], 2);          // a mask that is not an interval: cannot happen (lean_word); never silent
+            } else
             for (int q = 0; q < phn; ++q) {
                 const unsigned hq = ((unsigned)(rmask >> (8 * q)) & 0xffu) | (((unsigned)(rinfo >> (5 * q)) & 31u) << 16);
                 for (int j = 0; j < pwn; ++j, ++pos) {
@@ -530,6 +589,34 @@ __device__ __forceinline__ void process_rec(const SlotData<CPL> &d, const SlotRe
     }
 }
 
+// the lean decode of a record (owner plans, 1-byte codes, every lane inside C): see lean_word()
+template <int TH, int TW, int CPL>
+__device__ __forceinline__ void process_rec_lean(const SlotData<CPL> &d, const SlotRec &r, float *acc, int lane) {
+    constexpr int DUMMY = TH * TW;
+#pragma unroll
+    for (int s = 0; s < WALK_SLOTS; ++s) {
+        const unsigned w = r.hi[s];
+        const int lo_h = ((int)(w << 26)) >> 26, lo_w = ((int)(w << 16)) >> 26, base = ((int)(w << 2)) >> 22;
+        const unsigned n_h = (w >> 6) & 15u, n_w = (w >> 16) & 15u;
+        const unsigned a = d.a[s][0];
+        int idx[CPL];
+        float val[CPL];
+#pragma unroll
+        for (int p = 0; p < CPL; ++p) {
+            const unsigned ch = (a >> (8 * p + 4)) & 15u, cw = (a >> (8 * p)) & 15u;
+            const bool ok = ((unsigned)((int)ch - lo_h) < n_h) & ((unsigned)((int)cw - lo_w) < n_w);
+            const int cell = ok ? (int)__umul24(ch, (unsigned)TW) + (int)cw + base : DUMMY;
+            idx[p] = (cell * CPL + p) * 64 + lane;
+            val[p] = ok ? d.td[s][p] : 0.0f;
+        }
+        float v[CPL];
+#pragma unroll
+        for (int p = 0; p < CPL; ++p) v[p] = acc[idx[p]];
+#pragma unroll
+        for (int p = 0; p < CPL; ++p) acc[idx[p]] = v[p] + val[p];
+    }
+}
+
 template <int TH, int TW, int DEPTH, int MINW, int CPL, bool I32, bool OWN = false, int AUX = 0>
 __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
     const float *__restrict__ top_diff, const unsigned char *__restrict__ arg8 /* I32: the i32 arg-max */,
@@ -570,6 +657,7 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
     const int c0 = g * (64 * CPL) + CPL * lane;
     const bool lane_ok = c0 < C;
     const int cl = lane_ok ? c0 : 0;
+    const bool lean = (C % (64 * CPL)) == 0;          // the lists of a lean plan are in the lean format exactly then
 
 #pragma unroll
     for (int i = 0; i < (TH * TW + 1) * CPL; ++i) acc[i * 64 + lane] = 0.0f;
@@ -606,7 +694,8 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
             const unsigned next = fetch_rec(rp, i + j + DEPTH, nrec, lane);
             r[x] = spread_rec(pending, i + j + DEPTH - 1 < nrec, total_elems);
             issue_rec<CPL, I32, (AUX & 31)>(d[x], r[x], ra, rt, voff8, voff);
-            process_rec<TH, TW, CPL, I32>(d[j], r[j], acc, lane, lane_ok, q, h0, w0, W);
+            if (OWN && !I32 && (AUX & 128) && lean) process_rec_lean<TH, TW, CPL>(d[j], r[j], acc, lane);
+            else process_rec<TH, TW, CPL, I32>(d[j], r[j], acc, lane, lane_ok, q, h0, w0, W);
             pending = next;
         }
     }
@@ -823,7 +912,7 @@ static int prepare_t(const float *rois, int R, int N, int H, int W, int C, int P
                        ws.total);
     hipLaunchKernelGGL(walk_fill_kernel, dim3(items), dim3(FILL_BLOCK), 0, st, rois, C, PW, PH * PW, R, tiles_h,
                        tiles_w, ws.img_span, ws.rowtab, ws.coltab, ws.tile_off, ws.tile_slots, ws.slots, cap,
-                       total_elems, ws.total);
+                       total_elems, ws.total, 0);
     return check_launch();
 }
 
@@ -943,7 +1032,7 @@ int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, 
 
 
 // ---- bin-owner form: plans, prepare, launch ----------------------------------------------------
-//   X(id, region h, region w, tile h, tile w, records in flight, waves per SIMD asked for, channels per lane, cache policy: bits 0-4 of the data loads (gfx950: 1 = sc0, 2 = nt, 16 = sc1), 64 = non-temporal stores)
+//   X(id, region h, region w, tile h, tile w, records in flight, waves per SIMD asked for, channels per lane, cache policy: bits 0-4 of the data loads (gfx950: 1 = sc0, 2 = nt, 16 = sc1), 64 = non-temporal stores, 128 = lean decode)
 #define WSSDL_OWNER_PLANS(X) \
     X(0, 6, 7, 4, 5, 2, 1, 2, 66)  /* the default: 128-channel waves, 21.5 KiB of LDS (7 waves per CU), halo 2 x 2 */ \
     X(1, 6, 6, 4, 4, 2, 2, 2, 66)  /* at the exact walk's LDS (18.5 KiB) */ \
@@ -952,7 +1041,11 @@ int launch_walk(const float *top_diff, const unsigned char *arg8, int R, int N, 
     X(4, 6, 6, 4, 4, 2, 2, 2, 0)   /* plan 1 with plain loads and stores (the A/B of the cache policy) */ \
     X(5, 7, 7, 5, 5, 2, 1, 2, 66)  /* 25 KiB: 6 waves per CU */ \
     X(6, 5, 5, 4, 4, 2, 2, 2, 66)  /* halo 1: 13.3 KiB, 12 waves per CU */ \
-    X(7, 6, 7, 5, 5, 2, 1, 2, 66)  /* halo 1 x 2 */
+    X(7, 6, 7, 5, 5, 2, 1, 2, 66)  /* halo 1 x 2 */ \
+    X(8, 6, 7, 4, 5, 2, 1, 2, 66 + 128)  /* plan 0 with the lean decode (intervals in code space) */ \
+    X(9, 6, 6, 4, 4, 2, 2, 2, 66 + 128)  /* plan 1 ... */ \
+    X(10, 6, 7, 4, 5, 3, 1, 2, 66 + 128) \
+    X(11, 7, 7, 5, 5, 2, 1, 2, 66 + 128)
 
 struct OwnerPlan {
     int rh, rw, sh, sw, depth, minw, cpl;
@@ -982,8 +1075,13 @@ int owner_plan_auto(int R, int N, int H, int W, int C) {
     if (v >= 0 && v < OWNER_PLANS) return v;
     if (v < -1) return -1;                                       // -2: never (tools, A/B runs)
     const long long pairs = (long long)N * C;
-    if (R < 1536 || N < 1 || (C & 127) || pairs < 1024) return -1;
-    return pairs >= 2048 ? 0 : 1;
+    // (1024-2047 pairs -- VGG-16's 1 + 2 x 512, one weak image x 1024 -- stay on the split form: on the default set's
+    // small RoIs owner plan 9 ties with it (0.17 / 0.16 against 0.18 / 0.16 ms), on VGG-16's own 24 x 24-cell proposals it
+    // loses a little (0.257 against 0.245) and the plain 4x4-tile plan 1 a lot in the bench's leg (0.40 against 0.28): windows of
+    // 4-5 cells do not fit a 6x6 region and are listed in chains.  From 2048 pairs on plan 8 (6x7 regions, lean decode) wins on
+    // every set measured, large proposals included: alternating weak step 0.288 -> 0.223 on 21 x 17-cell RoIs.)
+    if (R < 1536 || N < 1 || (C & 127) || pairs < 2048) return -1;
+    return 8;
 }
 
 bool owner_supported(int R, int N, int H, int W, int C, int PH, int PW) {
@@ -998,7 +1096,7 @@ size_t owner_scratch_bytes(int N, int H, int W, int C, int plan) {
 
 template <int RH, int RW, int SH, int SW>
 static int prepare_own_t(const float *rois, int R, int N, int H, int W, int C, int PH, int PW, float scale,
-                         int rounding, void *workspace, size_t workspace_bytes, hipStream_t st) {
+                         int rounding, void *workspace, size_t workspace_bytes, hipStream_t st, bool lean) {
     const int tiles_h = cdiv(H, SH), tiles_w = cdiv(W, SW), tiles = tiles_h * tiles_w;
     const int items = N * tiles;
     const long long cap = walk_record_bound(R, N, H, W, PH, PW, SH, SW);      // a chain lists a bin no more often than the exact form
@@ -1018,7 +1116,7 @@ static int prepare_own_t(const float *rois, int R, int N, int H, int W, int C, i
                        ws.total);
     hipLaunchKernelGGL(walk_fill_kernel, dim3(items), dim3(FILL_BLOCK), 0, st, rois, C, PW, PH * PW, R, tiles_h,
                        tiles_w, ws.img_span, ws.rowtab, ws.coltab, ws.tile_off, ws.tile_slots, ws.slots, cap,
-                       total_elems, ws.total);
+                       total_elems, ws.total, lean ? RW : 0);
     return check_launch();
 }
 
@@ -1026,7 +1124,8 @@ int owner_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, 
                   void *workspace, size_t workspace_bytes, int plan, hipStream_t st) {
     switch (plan) {
 #define WSSDL_X(ID, RH, RW, SH, SW, D, MW, CPL, AUX) \
-        case ID: return prepare_own_t<RH, RW, SH, SW>(rois, R, N, H, W, C, PH, PW, scale, rounding, workspace, workspace_bytes, st);
+        case ID: return prepare_own_t<RH, RW, SH, SW>(rois, R, N, H, W, C, PH, PW, scale, rounding, workspace, workspace_bytes, st, \
+                                                      ((AUX) & 128) != 0 && (C % (64 * CPL)) == 0);
         WSSDL_OWNER_PLANS(WSSDL_X)
 #undef WSSDL_X
         default: return WSSDL_ERR_INVALID_ARGUMENT;
