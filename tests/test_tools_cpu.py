@@ -99,3 +99,23 @@ def test_every_tool_script_parses():
     for f in files:
         with open(f) as fh:
             ast.parse(fh.read(), filename=f)
+
+
+def test_owner_model_listing_rule_and_numbers():
+    """tools/owner_model.py restates the bin-owner form's listing rule (csrc/roi_pool_walk.hip: axis_entry_own) on the CPU:
+    a window is listed once when it fits the region of the tile that holds its first line, otherwise it continues in the
+    tile of its first uncovered line; on the fixed roofline set that gives the re-read factors EXPERIMENTS.md quotes."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import numpy as np
+    import owner_model as om
+    assert om.listings(3, 3, 4, 6) == 0                       # empty window
+    assert om.listings(3, 6, 4, 6) == 1                       # starts in tile 0 (lines 0-3), region reaches line 5
+    assert om.listings(3, 7, 4, 6) == 2                       # line 6 is beyond the region: continues in tile 1
+    assert om.listings(0, 16, 4, 6) == 3                      # chain: [0,6) tile 0, [6,10) tile 1, [10,16) tile 2
+    assert om.listings(5, 9, 6, 6) == 2                       # tile == region: every tile the window touches (the exact walk)
+    rois = np.load(os.path.join(ROOT, "profiles", "roofline_rois_r8512.npy"))
+    wins = [om.windows(x) for x in rois]
+    exact = om.model(rois, wins, 6, 6, 6, 6)
+    own = om.model(rois, wins, 4, 5, 6, 7)
+    assert abs(exact["f"] - 1.58) < 0.005 and abs(own["f"] - 1.119) < 0.005
+    assert abs(own["traffic_over_moved"] - 1.242) < 0.005     # measured: 1.227 (profiles/hotpath_traffic.json)
