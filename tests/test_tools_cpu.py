@@ -111,7 +111,7 @@ def test_owner_model_listing_rule_and_numbers():
     assert om.listings(3, 3, 4, 6) == 0                       # empty window
     assert om.listings(3, 6, 4, 6) == 1                       # starts in tile 0 (lines 0-3), region reaches line 5
     assert om.listings(3, 7, 4, 6) == 2                       # line 6 is beyond the region: continues in tile 1
-    assert om.listings(0, 16, 4, 6) == 3                      # chain: [0,6) tile 0, [6,10) tile 1, [10,16) tile 2
+    assert om.listings(0, 16, 4, 6) == 4                      # chain: [0,6) tile 0, [6,10) tile 1, [10,14) tile 2, [14,16) tile 3
     assert om.listings(5, 9, 6, 6) == 2                       # tile == region: every tile the window touches (the exact walk)
     rois = np.load(os.path.join(ROOT, "profiles", "roofline_rois_r8512.npy"))
     wins = [om.windows(x) for x in rois]
