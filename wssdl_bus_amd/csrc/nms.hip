@@ -370,16 +370,17 @@ __device__ __forceinline__ void nms_store_word(unsigned long long *p, unsigned l
 // launch the sweep is usually PAST a row block by the time the mask role reaches the block's far column segments
 // (at chunk c the sweep needs columns <= c + 7; segment s of row block rb with 16 s > rb + 4 is computed when the sweep
 // is near chunk 16 s - 8).  The sweep's spare wave publishes every resolved chunk's kept bitmask (`keptpub`); a mask
-// block that finds its row block resolved runs this TRANSPOSED form: column boxes in lanes, a scalar loop over the
-// kept rows (their boxes in this wave's LDS slice, read as broadcasts), the word of (row, column block) = one ballot.
-// ~8 instructions per (kept row, column block) against ~17 per (row, column block) of the dense form, and 10-30 %
-// of the rows are kept.  Same pair arithmetic (cpu_nms.pyx:43-66: every step is symmetric in the two boxes), so the
+// block that finds its row block resolved -- with at most `sparse_max` (16) of its 64 boxes kept: beyond ~40 % kept the
+// dense block wins -- runs this TRANSPOSED form: column boxes in lanes, a scalar loop over the kept rows (the row boxes
+// stay in the lanes' registers, lane = row, and reach the scalar registers with v_readlane: an LDS broadcast read per
+// kept row put a dependent LDS round trip into the loop), the word of (row, column block) = one ballot.
+// ~8 instructions per (kept row, column block) without a candidate (~45 with one) against ~17 per (row, column block)
+// of the dense form, and 10-30 % of the rows are kept.  Same pair arithmetic (cpu_nms.pyx:43-66: every step is symmetric in the two boxes), so the
 // words of kept rows are bit for bit those of the dense form; rows that were not kept get no words and no summary
 // bits -- nothing reads them (the helpers walk the kept list, the dense band next to the diagonal stays dense).
 template <bool COHERENT>
 __device__ __forceinline__ void nms_mask_block_sparse(const MaskArgs &A, int rb, int seg, int img, int wave, int lane, int n,
-                                                      unsigned long long kept, float ix1, float iy1, float ix2, float iy2,
-                                                      float (*rbox_w)[64] /* [5][64] */, nms_float4v *rgeo_w /* [64] */) {
+                                                      unsigned long long kept, float ix1, float iy1, float ix2, float iy2) {
     const float *__restrict__ b = A.boxes + (size_t)img * A.box_stride_img;
     const int n_max = A.n_max, ncb = A.ncb;
     const double thresh = A.thresh;
@@ -404,7 +405,6 @@ __device__ __forceinline__ void nms_mask_block_sparse(const MaskArgs &A, int rb,
     // v_readlane (no LDS round trip inside the row loop)
     const float iarea = box_area_ref(ix1, iy1, ix2, iy2);
     const nms_float4v ig = geometry(ix1, iy1, ix2, iy2, true);
-    (void)rbox_w;  (void)rgeo_w;
     auto bcast = [](float v, int r) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r)); };
     const int cb_first = max(rb, A.cb_min);
     const int cb_end = min((n + 63) / 64, (seg + 1) * MASK_SEG);
@@ -503,7 +503,7 @@ __device__ __forceinline__ void nms_mask_block(const MaskArgs &A, int rb, int se
         const unsigned long long kept = (kp0 & 0xffffffffull) | (kp1 << 32);
         // (a row loop per kept box pays off while few are kept; a chunk that kept most of its boxes takes the dense form)
         if (__popcll(kept) <= A.sparse_max) {
-            nms_mask_block_sparse<COHERENT>(A, rb, seg, img, wave, lane, n, kept, ix1, iy1, ix2, iy2, cbox_w, cgeo_w);
+            nms_mask_block_sparse<COHERENT>(A, rb, seg, img, wave, lane, n, kept, ix1, iy1, ix2, iy2);
             return;
         }
     }

@@ -320,20 +320,8 @@ __global__ __launch_bounds__(FILL_BLOCK) void walk_count_kernel(
 // base = hs * RW + ws: two subtract-and-compare pairs and one multiply-add per channel instead of two variable
 // shifts, four ANDs and the range bookkeeping.  The empty code 0xff (ch = 15) can never pass: lo_h + n_h > 15 would
 // need a window of 16 rows.  w1 = lo_h (signed 6) | n_h (4) << 6 | lo_w (signed 6) << 10 | n_w (4) << 16 | base (signed 10) << 20.
-__device__ __forceinline__ unsigned lean_word(unsigned w, int rw, bool *interval) {      // (the format, slot by slot; walk_fill_kernel builds the same word from per-axis halves)
-    const unsigned rm = w & 0xffu, cm = (w >> 8) & 0xffu;
-    const int hs = ((int)(w << 11)) >> 27, ws = ((int)(w << 6)) >> 27;
-    const int h0 = rm ? __ffs((int)rm) - 1 : 0, hn = __popc(rm);
-    const int w0 = cm ? __ffs((int)cm) - 1 : 0, wn = __popc(cm);
-    *interval = (rm == (((1u << hn) - 1u) << h0)) && (cm == (((1u << wn) - 1u) << w0));
-    // an empty mask on either axis: n = 0 fails every code; a clamped window start (|hs| = 16: the window lies wholly
-    // outside the region) keeps lo out of the codes' range
-    const int lo_h = min(max(h0 - hs, -32), 31), lo_w = min(max(w0 - ws, -32), 31);
-    const int base = hs * rw + ws;
-    const int nh = (rm && cm) ? hn : 0, nw = (rm && cm) ? wn : 0;
-    return ((unsigned)lo_h & 63u) | ((unsigned)nh << 6) | (((unsigned)lo_w & 63u) << 10) | ((unsigned)nw << 16) |
-           (((unsigned)base & 1023u) << 20);
-}
+// (walk_fill_kernel builds the word from per-axis halves: the column halves once per RoI, the row half once per bin row;
+// an empty mask on either axis gives n_h = 0, which fails every code; a clamped window start keeps lo out of the codes' range.)
 
 // pass 2 (after the offsets are known): the slot stream of one (image, tile), in (roi, ph, pw) order
 //   slot = w0 | w1 << 32:  w0 = element offset of the bin (r * PH*PW*C + bin * C),
@@ -347,7 +335,7 @@ __global__ __launch_bounds__(FILL_BLOCK) void walk_fill_kernel(
     const int *__restrict__ tile_slots, unsigned long long *__restrict__ slots, long long cap_records,
     unsigned total_elems, int *__restrict__ total, int lean_rw) {
     // lean_rw > 0 (owner plans with the lean decode, round 5): w1 carries the masks as INTERVALS in code space and the
-    // region cell of code (0, 0) -- see lean_word() -- for a region lean_rw cells wide
+    // region cell of code (0, 0) -- "Lean decode" above -- for a region lean_rw cells wide
     __shared__ int wave_sums[FILL_BLOCK / 64];
     const int tiles = tiles_h * tiles_w;
     const int item = blockIdx.x;
@@ -410,7 +398,7 @@ __global__ __launch_bounds__(FILL_BLOCK) void walk_fill_kernel(
                         ++pos;
                     }
                 }
-                if (!good) atomicOr(&total[1], 2);          // a mask that is not an interval: cannot happen (lean_word); never silent
+                if (!good) atomicOr(&total[1], 2);          // a mask that is not an interval: cannot happen ("Lean decode" above); never silent
             } else
             for (int q = 0; q < phn; ++q) {
                 const unsigned hq = ((unsigned)(rmask >> (8 * q)) & 0xffu) | (((unsigned)(rinfo >> (5 * q)) & 31u) << 16);
@@ -589,7 +577,7 @@ __device__ __forceinline__ void process_rec(const SlotData<CPL> &d, const SlotRe
     }
 }
 
-// the lean decode of a record (owner plans, 1-byte codes, every lane inside C): see lean_word()
+// the lean decode of a record (owner plans, 1-byte codes, every lane inside C): the word is described under "Lean decode"
 template <int TH, int TW, int CPL>
 __device__ __forceinline__ void process_rec_lean(const SlotData<CPL> &d, const SlotRec &r, float *acc, int lane) {
     constexpr int DUMMY = TH * TW;
