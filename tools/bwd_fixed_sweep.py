@@ -4,9 +4,13 @@ lane) on the FIXED roofline RoI set (profiles/roofline_rois_r8512.npy) and check
 bit against plan 11.
 
     python3 tools/bwd_fixed_sweep.py --plans 11,13,16 [--iters 20] [--one PLAN]
+    python3 tools/bwd_fixed_sweep.py --plans 13 --owner 8,0,1 [--images 4,5] [--rois set.npy --map 37,62 --channels 512]
+    python3 tools/bwd_fixed_sweep.py --i32 --plans 9,11,13        (the declared op's i32 arg-max: exact walk and owner_i32)
 
---one runs a single plan a few times and nothing else: the form to put under `rocprofv3 --pmc ...`
-for the HBM traffic of one variant.
+--owner times plans of the bin-owner form (wssdl_roi_pool_backward_compact_owner: walk + halo merge) after the exact plans and
+checks them against plan 11 at the owner form's tolerance + repeatability.  --one / --one-owner run a single plan a few
+times and nothing else: the form to put under `rocprofv3 --pmc ...` for the HBM traffic / SQ counters of one variant
+(tools/pmc_owner.sh, tools/pmc_sq_owner.sh).
 """
 import argparse
 import json
