@@ -113,6 +113,18 @@ def test_owner_model_listing_rule_and_numbers():
     assert om.listings(3, 7, 4, 6) == 2                       # line 6 is beyond the region: continues in tile 1
     assert om.listings(0, 16, 4, 6) == 4                      # chain: [0,6) tile 0, [6,10) tile 1, [10,14) tile 2, [14,16) tile 3
     assert om.listings(5, 9, 6, 6) == 2                       # tile == region: every tile the window touches (the exact walk)
+    # property: for every window and every (tile, region) the library builds, the pieces partition the window, every piece
+    # lies inside the region of the tile that lists it, and no tile lists a window twice
+    rs = np.random.RandomState(4)
+    for tile, region in ((4, 6), (5, 7), (6, 8), (4, 5), (5, 6), (6, 6), (2, 2), (8, 8)):
+        for _ in range(400):
+            s0 = int(rs.randint(0, 60))
+            e0 = s0 + int(rs.randint(0, 17))
+            pieces = om.chain_pieces(s0, e0, tile, region)
+            covered = [line for _, a, b in pieces for line in range(a, b)]
+            assert covered == list(range(s0, e0)), (s0, e0, tile, region, pieces)
+            assert all(t * tile <= a and b <= t * tile + region for t, a, b in pieces)
+            assert len({t for t, _, _ in pieces}) == len(pieces)
     rois = np.load(os.path.join(ROOT, "profiles", "roofline_rois_r8512.npy"))
     wins = [om.windows(x) for x in rois]
     exact = om.model(rois, wins, 6, 6, 6, 6)

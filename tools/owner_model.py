@@ -29,15 +29,21 @@ def windows(roi):
     return hs, he, ws, we
 
 
-def listings(s, e, tile, region):
-    """tiles (per axis) that list the window [s, e): the chain of axis_entry_own"""
-    if e <= s:
-        return 0                    # an empty window is listed nowhere
-    n, u = 0, s
+def chain_pieces(s, e, tile, region):
+    """[(tile index, first line, one past the last line)] of the window [s, e): the chain of axis_entry_own -- the tile of
+    the first uncovered line lists the lines from there to the end of ITS region, and so on"""
+    out, u = [], s
     while u < e:
-        u = (u // tile) * tile + region
-        n += 1
-    return n
+        t = u // tile
+        end = min(e, t * tile + region)
+        out.append((t, u, end))
+        u = t * tile + region
+    return out
+
+
+def listings(s, e, tile, region):
+    """tiles (per axis) that list the window [s, e); an empty window is listed nowhere"""
+    return len(chain_pieces(s, e, tile, region))
 
 
 def model(rois, wins, sh, sw, rh, rw):
