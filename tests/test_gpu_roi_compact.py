@@ -143,6 +143,89 @@ def test_window_table_path_on_a_train_sized_list(torch_cuda):
         assert not op.compact_overflowed()
 
 
+@pytest.mark.parametrize("shape", [(2, 38, 63, 256), (2, 38, 63, 1024), (1, 63, 100, 1024), (3, 37, 62, 512),
+                                   (1, 20, 30, 2048), (4, 12, 17, 512)])
+@pytest.mark.parametrize("mode", ["cuda", "cpu"])
+def test_block_table_forward_vs_oracle(torch_cuda, shape, mode):
+    """The forward for many proposals per image (csrc/roi_pool_blocks.hip: block-maximum tables of the feature map,
+    four table reads per covered bin, bin rows walked in (image, first window row) order): top and the expanded
+    arg-max bit-equal to the C oracle -- on ReLU data (ties at 0: the first cell in (h, w) order must win across
+    overlapping blocks), on a map whose every value is one of three (ties everywhere), with cells the scan never
+    takes (NaN, -inf, -FLT_MAX) and with a -0.0 in the map (the kernel then scans cells), sorted and in RoI order."""
+    torch = torch_cuda
+    from wssdl_bus_amd import _lib
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    N, H, W, C = shape
+    L = _lib.lib()
+    R = 1100
+    assert L.wssdl_roi_pool_forward_blocks_bytes(R, N, H, W, C, 7, 7) > 0
+    rs = np.random.RandomState(H * 100 + C + (mode == "cpu"))
+    rois = _rois_for(rs, R, N, H, W)
+    rt = torch.from_numpy(rois).cuda()
+    maps = {"relu": np.maximum(rs.normal(size=shape), 0).astype(np.float32),
+            "three values": rs.randint(0, 3, size=shape).astype(np.float32) - 1.0}
+    odd = rs.normal(size=shape).astype(np.float32)
+    pick = rs.uniform(size=shape)
+    odd[pick < 0.2] = np.nan
+    odd[(pick >= 0.2) & (pick < 0.4)] = -np.inf
+    odd[(pick >= 0.4) & (pick < 0.6)] = -np.finfo(np.float32).max
+    odd[(pick >= 0.6) & (pick < 0.62)] = np.inf
+    odd[:, : H // 2, : W // 2] = np.nan                   # whole windows without a cell the scan takes
+    maps["cells the scan never takes"] = odd
+    mz = maps["relu"].copy()
+    mz[mz == 0] = np.where(rs.uniform(size=int((mz == 0).sum())) < 0.5, np.float32(-0.0), np.float32(0.0))
+    maps["minus zero"] = mz
+    for name, f in maps.items():
+        et, ea = c_oracle.roi_pool_forward(f, rois, 7, 7, 1.0 / 16, mode, threads=16)
+        ft = torch.from_numpy(f).cuda()
+        for sort in (1, 0):
+            with _lib.tuned(roi_fwd_blocks=1, roi_fwd_blocks_sort=sort):
+                _lib.timeline.reset(True)
+                top, arg8 = op.roi_pool_compact(ft, rt, 7, 7, 1.0 / 16, rounding=mode)
+                torch.cuda.synchronize()
+                assert "roi_pool_forward_blocks_prepare" in _lib.timeline.summary(), "the block-table path did not run"
+                _lib.timeline.reset(False)
+            got = top.cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), et.view(np.uint32)), (name, sort)      # bit for bit, -0.0 and NaN-free
+            arg = op.expand_argmax(arg8, rt, shape, 7, 7, 1.0 / 16, rounding=mode)
+            assert np.array_equal(arg.cpu().numpy(), ea), (name, sort)
+        # and the rows kernel on the same inputs
+        with _lib.tuned(roi_fwd_blocks=0):
+            top0, arg80 = op.roi_pool_compact(ft, rt, 7, 7, 1.0 / 16, rounding=mode)
+        assert torch.equal(top0.view(torch.int32), top.view(torch.int32)) and torch.equal(arg80, arg8), name
+    assert not op.flags_raised()
+
+
+@pytest.mark.parametrize("which", ["resnet50_alter_weak_r4000_large", "vgg16_joint_r4128", "resnet50_alter_weak_r4000"])
+def test_block_table_forward_on_the_saved_proposal_sets(torch_cuda, which):
+    """Every RoI of the saved proposal sets the block-table forward is meant for (the alternating weak step's and
+    VGG-16's own proposals): top and arg-max codes equal to the rows kernel's, which the tests above tie to the oracle,
+    and -- on one image's worth -- to the C oracle directly."""
+    torch = torch_cuda
+    from wssdl_bus_amd import _lib
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    rois = np.load(os.path.join(os.path.dirname(__file__), "..", "profiles", "roofline_rois_%s.npy" % which))
+    H, W, C = (37, 62, 512) if which.startswith("vgg") else (38, 63, 1024)
+    N = int(rois[:, 0].max()) + 1
+    g = torch.Generator(device="cuda").manual_seed(5)
+    f = torch.relu(torch.randn((N, H, W, C), device="cuda", generator=g))
+    rt = torch.from_numpy(rois).cuda()
+    with _lib.tuned(roi_fwd_blocks=1):
+        top, arg8 = op.roi_pool_compact(f, rt, 7, 7, 1.0 / 16)
+    with _lib.tuned(roi_fwd_blocks=0):
+        top0, arg80 = op.roi_pool_compact(f, rt, 7, 7, 1.0 / 16)
+    assert torch.equal(top, top0) and torch.equal(arg8, arg80)
+    n = N - 1
+    idx = np.nonzero(rois[:, 0] == n)[0]
+    sub = rois[idx].copy()
+    sub[:, 0] = 0
+    et, ea = c_oracle.roi_pool_forward(f[n:n + 1].cpu().numpy(), sub, 7, 7, 1.0 / 16, "cuda", threads=16)
+    it = torch.from_numpy(idx).cuda()
+    assert np.array_equal(top[it].cpu().numpy(), et)
+    arg = op.expand_argmax(arg8[it].contiguous(), torch.from_numpy(sub).cuda(), (1, H, W, C), 7, 7, 1.0 / 16)
+    assert np.array_equal(arg.cpu().numpy(), ea)
+
+
 def _lib_windows_bytes(R, H, W, C):
     from wssdl_bus_amd import _lib
     return _lib.lib().wssdl_roi_pool_forward_windows_bytes(R, H, W, C, 7, 7)

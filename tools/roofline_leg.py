@@ -130,6 +130,8 @@ def main():
                          "and the exact walk bit for bit, the bin-owner form at its tolerance; tests/test_gpu_roi_compact.py)")
     ap.add_argument("--rois", default="", metavar="PATH.npy", help="another RoI set (float32 [R,5]) instead of the fixed one")
     ap.add_argument("--map", default="38,63,1024", help="H,W,C of the feature map the set belongs to")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
+                    help="wssdl_set_tuning(KEY, INT) before the run, e.g. roi_fwd_blocks=1 (repeatable)")
     args = ap.parse_args()
     import torch
     assert torch.cuda.is_available()
@@ -142,6 +144,10 @@ def main():
     if args.roi_bwd_plan >= 0:
         from wssdl_bus_amd import _lib
         _lib.set_tuning("roi_bwd_plan", args.roi_bwd_plan)
+    for kv in args.tune:
+        from wssdl_bus_amd import _lib
+        key, val = kv.split("=")
+        _lib.set_tuning(key, int(val))
     N = int(rois[:, 0].max()) + 1
     H, W, C = (int(v) for v in args.map.split(","))
     ops, meta = run(rois, N, H, W, C, args.iters, args.warmup)

@@ -19,6 +19,8 @@ static int *tuning_field(const char *key) {
     if (!strcmp(key, "roi_bwd_plan")) return &t.roi_bwd_plan;
     if (!strcmp(key, "roi_bwd_owner")) return &t.roi_bwd_owner;
     if (!strcmp(key, "roi_fwd_variant")) return &t.roi_fwd_variant;
+    if (!strcmp(key, "roi_fwd_blocks")) return &t.roi_fwd_blocks;
+    if (!strcmp(key, "roi_fwd_blocks_sort")) return &t.roi_fwd_blocks_sort;
     if (!strcmp(key, "roi_bwdc_variant")) return &t.roi_bwdc_variant;
     if (!strcmp(key, "roi_bwd_cg")) return &t.roi_bwd_cg;
     if (!strcmp(key, "nms_one_pass")) return &t.nms_one_pass;

@@ -51,6 +51,13 @@ __device__ __forceinline__ void bin_window(const RoiGeom &g, int ph, int pw, int
     we = min(max(we + g.sw, 0), W);
 }
 
+// 1-byte arg-max of the training path (roi_pool_compact.hip): (h - hstart) << 4 | (w - wstart), 0xff = empty bin
+constexpr unsigned ARG8_EMPTY = 0xffu;
+constexpr int ARG8_MAX_WIN_H = 15;    // dh <= 14: the code 0xff = (15, 15) can never be produced
+constexpr int ARG8_MAX_WIN_W = 16;
+// window table of the forward: one 32-byte entry per (roi, bin row), written by roi_windows_kernel
+constexpr int WIN_ENTRY_WORDS = 8;
+
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef int int4v __attribute__((ext_vector_type(4)));
 

@@ -32,9 +32,7 @@
 
 namespace wssdl {
 
-constexpr unsigned ARG8_EMPTY = 0xffu;
-constexpr int ARG8_MAX_WIN_H = 15;    // dh <= 14: the code 0xff = (15, 15) can never be produced
-constexpr int ARG8_MAX_WIN_W = 16;
+// (ARG8_EMPTY, ARG8_MAX_WIN_H / _W and the window-table layout: roi_pool.hip.h)
 
 // clipped window start of bin p: roi_pooling_op_gpu.cu.cc:51-52,61-63 / roi_pooling_op.cc:167-168,173-175
 __device__ __forceinline__ int win_start(int p, float bin, int rs, int limit, int rounding) {
@@ -115,7 +113,6 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_compact_kernel(
 // Written by roi_windows_kernel (one lane per bin row), read by the forward with two scalar loads: the
 // RoI geometry -- coordinates, two IEEE divisions, floor / ceil per bin -- then costs a forward wave no
 // vector instruction at all instead of ~170 of its ~890.
-constexpr int WIN_ENTRY_WORDS = 8;
 
 __global__ __launch_bounds__(256) void roi_windows_kernel(const float *__restrict__ rois, int R, int N, int H, int W,
                                                           float scale, int rounding, unsigned *__restrict__ table,
@@ -125,8 +122,9 @@ __global__ __launch_bounds__(256) void roi_windows_kernel(const float *__restric
     const int r = (int)(item / 7), ph = (int)(item - (long long)r * 7);
     const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, 7, 7);
     const int hs = win_start(ph, g.bin_h, g.sh, H, rounding), he = win_end(ph, g.bin_h, g.sh, H, rounding);
-    unsigned wsb[2] = {0u, 0u}, web[2] = {0u, 0u};
+    unsigned wsb[2] = {0u, 0u}, web[2] = {0u, 0u}, blk = 0u;
     bool wide = false, any = false;
+    const int a = he - hs;
 #pragma unroll
     for (int pw = 0; pw < 7; ++pw) {
         const int ws = win_start(pw, g.bin_w, g.sw, W, rounding), we = win_end(pw, g.bin_w, g.sw, W, rounding);
@@ -134,12 +132,22 @@ __global__ __launch_bounds__(256) void roi_windows_kernel(const float *__restric
         web[pw >> 2] |= (unsigned)we << (8 * (pw & 3));
         wide |= we - ws > ARG8_MAX_WIN_W;
         any |= we > ws;
+        // block-table forward (roi_pool_blocks.hip): the window is the union of four k x k blocks anchored at its
+        // corners when k <= min(a, b) and max(a, b) <= 2k; the largest such k in {2, 3, 4}, as k - 1 (0: none)
+        const int b = we - ws, lo = min(a, b), hi = max(a, b);
+        unsigned kc = 0u;
+#pragma unroll
+        for (int k = 2; k <= 4; ++k)
+            if (k <= lo && hi <= 2 * k) kc = (unsigned)(k - 1);
+        blk |= kc << (2 * pw);
     }
+    const bool bad = g.batch < 0 || g.batch >= N;
     unsigned *e = table + (size_t)item * WIN_ENTRY_WORDS;
     e[0] = (unsigned)g.batch;
     e[1] = (unsigned)hs | ((unsigned)he << 8);
-    e[2] = wsb[0];  e[3] = wsb[1];  e[4] = web[0];  e[5] = web[1];  e[6] = 0u;  e[7] = 0u;
-    const bool bad = g.batch < 0 || g.batch >= N;
+    e[2] = wsb[0];  e[3] = wsb[1];  e[4] = web[0];  e[5] = web[1];
+    e[6] = blk;                                                            // 2 bits per bin column
+    e[7] = bad ? 0u : (unsigned)(g.batch * H + min(hs, H - 1));           // sort key of the bin row: (image, first window row)
     if (overflow && !bad && he > hs && any && (wide || he - hs > ARG8_MAX_WIN_H)) atomicOr(overflow, 1);
 }
 
