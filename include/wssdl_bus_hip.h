@@ -333,15 +333,20 @@ WSSDL_API int wssdl_roi_pool_forward_compact_windows(const float *bottom, int N,
  * bin whose window is covered by the four k x k blocks at its corners reads four table entries instead of its
  * cells; "maximum value, then smallest (h, w)" is associative and idempotent, so top and arg-max are the same bits.
  * Other bins (and every bin when the map holds a -0.0, which equals +0.0 in the reference's compare) are scanned
- * cell by cell.  Order of calls: wssdl_roi_pool_forward_windows (its table also carries the block choice per bin and
- * the sort key of the bin row), wssdl_roi_pool_forward_blocks_prepare (tables + the bin rows sorted by (image, first
- * window row) so that an XCD's L2 holds the band of the tables its waves read), wssdl_roi_pool_forward_compact_blocks.
+ * cell by cell.  Order of calls, same stream: wssdl_roi_pool_forward_windows_blocks (the window table -- it also
+ * carries the block choice per bin and the sort key of the bin row -- and the counters of `blocks` cleared),
+ * wssdl_roi_pool_forward_blocks_prepare (tables + the bin rows sorted by (image, first window row) so that an XCD's
+ * L2 holds the band of the tables its waves read), wssdl_roi_pool_forward_compact_blocks.
  * `blocks` = wssdl_roi_pool_forward_blocks_bytes() bytes, 256-byte aligned (0: shape not supported -- 7 x 7 bins,
  * C % 256 == 0, H, W in 4..255).  wssdl_roi_pool_forward_blocks_auto = 1 where the library suggests this form for
  * the launch shape ("roi_fwd_blocks": -1 that rule, 0 never, 1 wherever supported; "roi_fwd_blocks_sort" = 0 keeps
  * the bin rows in RoI order). */
 WSSDL_API size_t wssdl_roi_pool_forward_blocks_bytes(int R, int N, int H, int W, int C, int pooled_h, int pooled_w);
 WSSDL_API int wssdl_roi_pool_forward_blocks_auto(int R, int N, int H, int W, int C, int pooled_h, int pooled_w);
+WSSDL_API int wssdl_roi_pool_forward_windows_blocks(const float *rois, int R, int N, int H, int W, int C, int pooled_h,
+                                          int pooled_w, float spatial_scale, int rounding, void *table,
+                                          size_t table_bytes, int32_t *overflow, void *blocks, size_t blocks_bytes,
+                                          wssdl_stream_t stream);
 WSSDL_API int wssdl_roi_pool_forward_blocks_prepare(const float *bottom, int N, int H, int W, int C, int R,
                                           int pooled_h, int pooled_w, const void *table, void *blocks,
                                           size_t blocks_bytes, wssdl_stream_t stream);

@@ -178,17 +178,17 @@ def test_block_table_forward_vs_oracle(torch_cuda, shape, mode):
     for name, f in maps.items():
         et, ea = c_oracle.roi_pool_forward(f, rois, 7, 7, 1.0 / 16, mode, threads=16)
         ft = torch.from_numpy(f).cuda()
-        for sort in (1, 0):
-            with _lib.tuned(roi_fwd_blocks=1, roi_fwd_blocks_sort=sort):
+        for sort, pipe in ((1, 1), (0, 1), (1, 2)):           # (sorted bin rows, waves per bin row)
+            with _lib.tuned(roi_fwd_blocks=1, roi_fwd_blocks_sort=sort, roi_fwd_blocks_parts=pipe):
                 _lib.timeline.reset(True)
                 top, arg8 = op.roi_pool_compact(ft, rt, 7, 7, 1.0 / 16, rounding=mode)
                 torch.cuda.synchronize()
                 assert "roi_pool_forward_blocks_prepare" in _lib.timeline.summary(), "the block-table path did not run"
                 _lib.timeline.reset(False)
             got = top.cpu().numpy()
-            assert np.array_equal(got.view(np.uint32), et.view(np.uint32)), (name, sort)      # bit for bit, -0.0 and NaN-free
+            assert np.array_equal(got.view(np.uint32), et.view(np.uint32)), (name, sort, pipe)      # bit for bit, -0.0 too
             arg = op.expand_argmax(arg8, rt, shape, 7, 7, 1.0 / 16, rounding=mode)
-            assert np.array_equal(arg.cpu().numpy(), ea), (name, sort)
+            assert np.array_equal(arg.cpu().numpy(), ea), (name, sort, pipe)
         # and the rows kernel on the same inputs
         with _lib.tuned(roi_fwd_blocks=0):
             top0, arg80 = op.roi_pool_compact(ft, rt, 7, 7, 1.0 / 16, rounding=mode)

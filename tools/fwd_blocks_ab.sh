@@ -13,7 +13,8 @@ run() {   # name rois map tune...
 import json,sys
 d=json.loads(sys.stdin.readlines()[-1]); o=d['ops']
 def g(k): return o[k]['avg_ms'] if k in o else 0.0
-f=g('roi_pool_forward'); p=g('roi_pool_forward_blocks_prepare'); w=g('roi_pool_forward_windows')
+pm=o['roi_pool_forward'].get('parts_ms'); w=g('roi_pool_forward_windows')
+f=pm['pooling'] if pm else g('roi_pool_forward'); p=pm['tables_and_order'] if pm else 0.0
 mv=o['roi_pool_forward'].get('min_moved_bytes',0)
 print('%-14s %-40s fwd %.4f  prepare %.4f  windows %.4f  sum %.4f ms  frac_moved(fwd+prepare) %.3f' % ('$name', '$*', f, p, w, f+p+w, mv/((f+p)*1e-3)/8e12))
 " >> "$out" || return 1
@@ -25,6 +26,11 @@ for rep in ${REPS:-1 2}; do
     run alter profiles/roofline_rois_resnet50_alter_weak_r4000.npy 38,63,1024 roi_fwd_blocks=$blk || exit 1
     run vgg profiles/roofline_rois_vgg16_joint_r4128.npy 37,62,512 roi_fwd_blocks=$blk || exit 1
   done
+done
+for parts in 1 2; do
+run alter_large profiles/roofline_rois_resnet50_alter_weak_r4000_large.npy 38,63,1024 roi_fwd_blocks=1 roi_fwd_blocks_parts=$parts
+run alter profiles/roofline_rois_resnet50_alter_weak_r4000.npy 38,63,1024 roi_fwd_blocks=1 roi_fwd_blocks_parts=$parts
+run vgg profiles/roofline_rois_vgg16_joint_r4128.npy 37,62,512 roi_fwd_blocks=1 roi_fwd_blocks_parts=$parts
 done
 run alter_large profiles/roofline_rois_resnet50_alter_weak_r4000_large.npy 38,63,1024 roi_fwd_blocks=1 roi_fwd_blocks_sort=0
 run vgg profiles/roofline_rois_vgg16_joint_r4128.npy 37,62,512 roi_fwd_blocks=1 roi_fwd_blocks_sort=0

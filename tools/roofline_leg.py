@@ -24,7 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ROIS_PATH = os.path.join(ROOT, "profiles", "roofline_rois_r8512.npy")
-KERNEL_SOURCES = ("roi_pool.hip", "roi_pool.hip.h", "roi_pool_compact.hip", "roi_pool_walk.hip")
+KERNEL_SOURCES = ("roi_pool.hip", "roi_pool.hip.h", "roi_pool_compact.hip", "roi_pool_blocks.hip", "roi_pool_walk.hip")
 
 
 def kernel_source_id():
@@ -106,17 +106,28 @@ def run(rois_np, N, H, W, C, iters=20, warmup=3, seed=3):
     finally:
         _lib.timeline.enabled, _lib.timeline.records = saved_enabled, saved_records
     out = {}
+    # the block-table forward is one op of three launches (tables + bin-row order, then the pooling kernel): quoted
+    # together, like the bin-owner backward's walk + merge; the parts stay visible in `parts_ms`
+    prep = tl.pop("roi_pool_forward_blocks_prepare", None)
+    if prep is not None and "roi_pool_forward" in tl:
+        f = tl["roi_pool_forward"]
+        f["parts_ms"] = dict(tables_and_order=prep["avg_ms"], pooling=f["avg_ms"])
+        f["avg_ms"] += prep["avg_ms"]
     for name, d in tl.items():
         ab = alg_bytes(name, N, H, W, C, R)
         out[name] = dict(avg_ms=d["avg_ms"], calls=d["calls"], alg_bytes_per_launch=ab,
                          GBps=(ab / (d["avg_ms"] * 1e-3) / 1e9) if ab else None)
         if ab and compact:
             out[name]["min_moved_bytes"] = moved_bytes(name, N, H, W, C, R)
+        if "parts_ms" in d:
+            out[name]["parts_ms"] = d["parts_ms"]
     meta = dict(N=N, H=H, W=W, C=C, R=R, argmax_bytes=1 if compact else 4,
                 backward_plan=(plan.plan if plan is not None else None),
                 backward_owner_plan=(plan.owner if plan is not None else None),
                 backward_variant=(plan.variant if plan is not None else "i32 pair"),
-                backward_segments=segs, kernel_source_id=kernel_source_id())
+                backward_segments=segs, kernel_source_id=kernel_source_id(),
+                forward_variant=("block tables (k = 2, 3, 4) + bin rows in (image, first window row) order: 3 launches"
+                                 if prep is not None else "rows kernel"))
     return out, meta
 
 

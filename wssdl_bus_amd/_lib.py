@@ -63,6 +63,7 @@ SYMBOLS = {
     "wssdl_roi_pool_forward_compact_windows": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "wssdl_roi_pool_forward_blocks_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "wssdl_roi_pool_forward_blocks_auto": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "wssdl_roi_pool_forward_windows_blocks": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp, _sz, _vp]),
     "wssdl_roi_pool_forward_blocks_prepare": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "wssdl_roi_pool_forward_compact_blocks": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "wssdl_roi_pool_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),

@@ -21,6 +21,7 @@ static int *tuning_field(const char *key) {
     if (!strcmp(key, "roi_fwd_variant")) return &t.roi_fwd_variant;
     if (!strcmp(key, "roi_fwd_blocks")) return &t.roi_fwd_blocks;
     if (!strcmp(key, "roi_fwd_blocks_sort")) return &t.roi_fwd_blocks_sort;
+    if (!strcmp(key, "roi_fwd_blocks_parts")) return &t.roi_fwd_blocks_parts;
     if (!strcmp(key, "roi_bwdc_variant")) return &t.roi_bwdc_variant;
     if (!strcmp(key, "roi_bwd_cg")) return &t.roi_bwd_cg;
     if (!strcmp(key, "nms_one_pass")) return &t.nms_one_pass;

@@ -104,6 +104,11 @@ constexpr int WSSDL_ROWS_I32_UNSUPPORTED = -1000;
 int launch_fwd_rows_i32(const float *bottom, int N, int H, int W, int C, const float *rois, int R, int pooled_h,
                         int pooled_w, float spatial_scale, int rounding, float *top, int32_t *argmax, hipStream_t st);
 
+// block-table forward (roi_pool_blocks.hip)
+bool blocks_supported(int R, int N, int H, int W, int C, int PH, int PW);
+size_t blocks_workspace_bytes(int R, int N, int H, int W, int C);
+void blocks_zero_region(void *ws, int R, int N, int H, int W, int C, unsigned **ptr, int *words);
+
 // list-driven backward of the training path (roi_pool_walk.hip)
 int walk_plan_count();
 size_t walk_flags_offset(int R, int N, int H, int W, int PH, int PW);

@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_compact_kernel(
 
 __global__ __launch_bounds__(256) void roi_windows_kernel(const float *__restrict__ rois, int R, int N, int H, int W,
                                                           float scale, int rounding, unsigned *__restrict__ table,
-                                                          int *__restrict__ overflow) {
+                                                          int *__restrict__ overflow, unsigned *__restrict__ zero,
+                                                          int zero_words) {
+    // (block-table forward: the counters of its sort start from zero -- cleared here instead of by a memset launch)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < zero_words; i += gridDim.x * 256) zero[i] = 0u;
     const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
     if (item >= (long long)R * 7) return;
     const int r = (int)(item / 7), ph = (int)(item - (long long)r * 7);
@@ -746,7 +749,28 @@ extern "C" int wssdl_roi_pool_forward_windows(const float *rois, int R, int N, i
     if (!rois || !table || (reinterpret_cast<uintptr_t>(table) & 31)) return WSSDL_ERR_INVALID_ARGUMENT;
     if (table_bytes < wssdl_roi_pool_forward_windows_bytes(R, H, W, C, pooled_h, pooled_w)) return WSSDL_ERR_WORKSPACE;
     hipLaunchKernelGGL(roi_windows_kernel, dim3(cdiv((long long)R * 7, 256)), dim3(256), 0, as_stream(stream), rois, R, N,
-                       H, W, spatial_scale, rounding, static_cast<unsigned *>(table), overflow);
+                       H, W, spatial_scale, rounding, static_cast<unsigned *>(table), overflow, nullptr, 0);
+    return check_launch();
+}
+
+extern "C" int wssdl_roi_pool_forward_windows_blocks(const float *rois, int R, int N, int H, int W, int C, int pooled_h,
+                                                     int pooled_w, float spatial_scale, int rounding, void *table,
+                                                     size_t table_bytes, int32_t *overflow, void *blocks,
+                                                     size_t blocks_bytes, wssdl_stream_t stream) {
+    if (R < 1 || N < 1 || !window_table_supported(H, W, C, pooled_h, pooled_w) ||
+        !blocks_supported(R, N, H, W, C, pooled_h, pooled_w))
+        return WSSDL_ERR_INVALID_ARGUMENT;
+    if (rounding != WSSDL_ROI_ROUND_CUDA && rounding != WSSDL_ROI_ROUND_CPU) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (!rois || !table || (reinterpret_cast<uintptr_t>(table) & 31) || !blocks || (reinterpret_cast<uintptr_t>(blocks) & 255))
+        return WSSDL_ERR_INVALID_ARGUMENT;
+    if (table_bytes < wssdl_roi_pool_forward_windows_bytes(R, H, W, C, pooled_h, pooled_w) ||
+        blocks_bytes < blocks_workspace_bytes(R, N, H, W, C))
+        return WSSDL_ERR_WORKSPACE;
+    unsigned *zero = nullptr;
+    int zero_words = 0;
+    blocks_zero_region(blocks, R, N, H, W, C, &zero, &zero_words);
+    hipLaunchKernelGGL(roi_windows_kernel, dim3(cdiv((long long)R * 7, 256)), dim3(256), 0, as_stream(stream), rois, R, N,
+                       H, W, spatial_scale, rounding, static_cast<unsigned *>(table), overflow, zero, zero_words);
     return check_launch();
 }
 

@@ -226,17 +226,17 @@ def roi_pool_compact(data, rois, pooled_height, pooled_width, spatial_scale, rou
             # the RoI geometry once per (roi, bin row) into a table, then the pooling kernel reads it with
             # scalar loads (two launches, timed apart: the second is the kernel the roofline is quoted on)
             table = torch.empty((nwin,), dtype=torch.uint8, device=data.device)
-            with _lib.timed("roi_pool_forward_windows", dict(R=R)):
-                _lib.check(L.wssdl_roi_pool_forward_windows(
-                    _lib.ptr(rois), R, N, H, W, C, int(pooled_height), int(pooled_width), float(spatial_scale), mode,
-                    _lib.ptr(table), nwin, _lib.ptr(_overflow_flag(data.device)), _lib.stream()),
-                    "wssdl_roi_pool_forward_windows")
             # many proposals per image (large, overlapping windows): block-maximum tables of this step's feature map,
             # four table reads per bin instead of a scan of its cells (csrc/roi_pool_blocks.hip; same bits)
             nblk = L.wssdl_roi_pool_forward_blocks_bytes(R, N, H, W, C, int(pooled_height), int(pooled_width)) \
                 if L.wssdl_roi_pool_forward_blocks_auto(R, N, H, W, C, int(pooled_height), int(pooled_width)) else 0
             if nblk:
                 blocks = torch.empty((nblk,), dtype=torch.uint8, device=data.device)
+                with _lib.timed("roi_pool_forward_windows", dict(R=R)):
+                    _lib.check(L.wssdl_roi_pool_forward_windows_blocks(
+                        _lib.ptr(rois), R, N, H, W, C, int(pooled_height), int(pooled_width), float(spatial_scale), mode,
+                        _lib.ptr(table), nwin, _lib.ptr(_overflow_flag(data.device)), _lib.ptr(blocks), nblk,
+                        _lib.stream()), "wssdl_roi_pool_forward_windows_blocks")
                 with _lib.timed("roi_pool_forward_blocks_prepare", dict(N=N, H=H, W=W, C=C, R=R)):
                     _lib.check(L.wssdl_roi_pool_forward_blocks_prepare(
                         _lib.ptr(data), N, H, W, C, R, int(pooled_height), int(pooled_width), _lib.ptr(table),
@@ -247,6 +247,11 @@ def roi_pool_compact(data, rois, pooled_height, pooled_width, spatial_scale, rou
                         _lib.ptr(blocks), nblk, _lib.ptr(top), _lib.ptr(arg8), _lib.stream()),
                         "wssdl_roi_pool_forward_compact_blocks")
                 return top, arg8
+            with _lib.timed("roi_pool_forward_windows", dict(R=R)):
+                _lib.check(L.wssdl_roi_pool_forward_windows(
+                    _lib.ptr(rois), R, N, H, W, C, int(pooled_height), int(pooled_width), float(spatial_scale), mode,
+                    _lib.ptr(table), nwin, _lib.ptr(_overflow_flag(data.device)), _lib.stream()),
+                    "wssdl_roi_pool_forward_windows")
             with _lib.timed("roi_pool_forward", dict(N=N, H=H, W=W, C=C, R=R, argmax_bytes=1)):
                 _lib.check(L.wssdl_roi_pool_forward_compact_windows(
                     _lib.ptr(data), N, H, W, C, _lib.ptr(rois), R, int(pooled_height), int(pooled_width),
