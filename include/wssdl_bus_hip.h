@@ -65,7 +65,7 @@ enum wssdl_dataset {
 
 #define WSSDL_MAX_ANCHORS 32     /* base anchors per cell (reference uses 9 or 12) */
 /* roi_counts[i] / num_keep of an image whose NMS sweep gave up waiting for the mask blocks of the fused
- * launch (0.5 s without progress: the GPU is held by another process or kernel).  The image's rows are
+ * launch (50 ms without progress, tuning key "nms_wait_us": the GPU is held by another process or kernel).  The image's rows are
  * incomplete; every consumer must treat a negative count as an error, never as "no proposals". */
 #define WSSDL_NMS_TIMED_OUT (-1)
 #define WSSDL_MAX_GT 64          /* gt boxes per image (reference: MAX_GT_PER_IMAGE = 20) */
@@ -80,7 +80,9 @@ WSSDL_API const char *wssdl_last_error(void);
  * "roi_bwdc_variant", "roi_bwd_cg" (shapes of the compact forward / the fallback backwards, 0 =
  * automatic), "nms_one_pass" (1: the proposal layer skips the probe pass), "nms_fused" (0: mask and sweep of a one-pass
  * NMS as two launches instead of the fused one), "topk_sort" (order of the proposal candidates: 1 sorted runs +
- * cross ranks, the default; 0 the select + sample sort).  Results do not depend on
+ * cross ranks, the default; 0 the select + sample sort), "nms_wait_us" (how long a sweep of the fused launch waits for
+ * the mask blocks before it reports WSSDL_NMS_TIMED_OUT; default 50000), "roi_fwd_blocks" / "roi_fwd_blocks_sort" /
+ * "roi_fwd_blocks_parts" (block-table forward, see there).  Results do not depend on
  * any of them.  One more key is a fault injector for tests, not a knob: "nms_fused_fault" (> 0: the fused
  * NMS launch withholds image 0's progress counts and that image's sweep gives up after this many microseconds,
  * reporting WSSDL_NMS_TIMED_OUT).  Unknown key -> WSSDL_ERR_INVALID_ARGUMENT. */
@@ -413,6 +415,10 @@ WSSDL_API int wssdl_roi_pool_backward_compact_split(const float *top_diff, const
  * ..._compact_owner with the same plan.  ..._owner_plan suggests a plan by launch shape, -1 = keep the exact walk. */
 WSSDL_API int wssdl_roi_pool_backward_owner_plan_count(void);
 WSSDL_API int wssdl_roi_pool_backward_owner_plan(int R, int N, int H, int W, int C);
+/* the same rule for a given pooled size: -1 as well when the owner form does not take the launch (pooled_h or
+ * pooled_w > 8, R * pooled_h * pooled_w * C >= 2^30 elements, N * H * W * C >= 2^31) -- what a caller that pools
+ * other sizes than 7 x 7 must ask (wssdl_roi_pool_backward_owner_plan assumes 7 x 7) */
+WSSDL_API int wssdl_roi_pool_backward_owner_plan_for(int R, int N, int H, int W, int C, int pooled_h, int pooled_w);
 WSSDL_API size_t wssdl_roi_pool_backward_owner_scratch_bytes(int N, int H, int W, int C, int owner_plan);
 WSSDL_API int wssdl_roi_pool_backward_owner_prepare(const float *rois, int R, int N, int H, int W, int C,
                             int pooled_h, int pooled_w, float spatial_scale, int rounding,

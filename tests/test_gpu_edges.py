@@ -866,12 +866,30 @@ def test_fused_nms_time_out_is_reported_not_swallowed(torch_cuda):
         import warnings
         from wssdl_bus_amd.rpn_msr import proposal_layer_tf_bus as plt
         plt._timeout_warned[0] = False
+        plt._cooldown[0] = 0
+        import time
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
-            again = proposal_layer(prob, pred, info, True, False)
-            again2 = proposal_layer(prob, pred, info, True, False)
-        assert np.array_equal(again, good) and np.array_equal(again2, good)
+            with _lib.tuned(nms_fused_fault=200000):                            # a stall one can time: 0.2 s
+                t0 = time.perf_counter()
+                again = proposal_layer(prob, pred, info, True, False)
+                t1 = time.perf_counter()
+                # sticky: the following calls stay on two launches for a cool-down -- ONE stall, not one per call
+                assert plt._cooldown[0] == plt.NMS_TIMEOUT_COOLDOWN_CALLS
+                again2 = proposal_layer(prob, pred, info, True, False)
+                again3 = proposal_layer(prob, pred, info, True, False)
+                t2 = time.perf_counter()
+            assert t1 - t0 >= 0.2 and t2 - t1 < 0.15, (t1 - t0, t2 - t1)
+            assert plt._cooldown[0] == plt.NMS_TIMEOUT_COOLDOWN_CALLS - 2
+        assert np.array_equal(again, good) and np.array_equal(again2, good) and np.array_equal(again3, good)
         assert sum("timed out" in str(w.message) for w in caught) == 1          # logged once
+        # after the cool-down the fused launch is tried again (and, the fault still injected, times out again)
+        plt._cooldown[0] = 1
+        assert np.array_equal(proposal_layer(prob, pred, info, True, False), good) and plt._cooldown[0] == 0
+        assert np.array_equal(proposal_layer(prob, pred, info, True, False), good)
+        assert plt._cooldown[0] == plt.NMS_TIMEOUT_COOLDOWN_CALLS
+        plt._cooldown[0] = 0
+        assert _lib.get_tuning("nms_wait_us") == 50000
         with _lib.tuned(nms_fused=0):
             assert np.array_equal(proposal_layer(prob, pred, info, True, False), again)
         blob = padded_blob(rois, counts)                       # the form that never reads the counts back
@@ -886,6 +904,12 @@ def test_fused_nms_time_out_is_reported_not_swallowed(torch_cuda):
         rp.poll_flags()
         assert _lib.get_tuning("nms_fused") == 0
         _lib.set_tuning("nms_fused", 1)
+    # the step the poll let through ran without image 0's proposals: counted, and named by the next synchronising check
+    # (what the train loop runs before a snapshot)
+    assert rp.tainted_steps() == 1
+    with pytest.raises(_lib.HipCallError, match="proposals missing"):
+        rp.check_flags()
+    assert rp.tainted_steps() == 0
     rp.check_flags()                                            # reported once, then clean
     assert np.array_equal(proposal_layer(prob, pred, info, True, False), good)
 

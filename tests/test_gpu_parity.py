@@ -105,6 +105,53 @@ def test_nms_threshold_rule_and_max_keep(torch_cuda):
     assert keep.is_cuda and keep.cpu().tolist() == full
 
 
+def test_use_gpu_nms_switch_applies_the_cuda_rule(torch_cuda):
+    """cfg.USE_GPU_NMS (reference: fast_rcnn/nms_wrapper.py:18-19 -> nms/nms_kernel.cu:24-32,71): suppression when
+    iou > (float)thresh, both f32, instead of cpu_nms's (double)iou >= thresh.  Hand-derived boundary pairs:
+      * thresh 0.5, boxes 10 x 10 and 10 x 5 inside it: inter 50, union 100, iou = 0.5 exactly in f32 --
+        cpu rule 0.5 >= 0.5 suppresses, cuda rule 0.5 > 0.5f keeps;
+      * thresh 0.7, inter 70 / union 100: iou = 0.7f, (double)0.7f = 0.69999998... --
+        cpu rule keeps (0.69999998 < 0.7), cuda rule keeps (0.7f > 0.7f is false): the two agree at the default;
+      * thresh 0.3 (TEST.NMS), inter 30 / union 100: iou = 0.3f = 0.30000001192...: cpu rule 0.3000000119 >= 0.3
+        suppresses, cuda rule 0.3f > 0.3f keeps.
+    On the 12000-box fixture the cuda rule equals a direct f32 evaluation of the kernel's test."""
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.fast_rcnn.nms_wrapper import nms
+    half = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 4, 0.8]], np.float32)
+    seven = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 6, 0.8]], np.float32)
+    three = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 2, 0.8]], np.float32)
+    assert not cfg.USE_GPU_NMS
+    assert nms(half, 0.5) == [0] and nms(seven, 0.7) == [0, 1] and nms(three, 0.3) == [0]
+    g = load_golden("nms")
+    dets = g["n12000/dets"][:3000]
+    try:
+        cfg.USE_GPU_NMS = True
+        assert nms(half, 0.5) == [0, 1] and nms(seven, 0.7) == [0, 1] and nms(three, 0.3) == [0, 1]
+        assert nms(half, 0.5, force_cpu=True) == [0]
+        for th in (0.5, 0.3):
+            # nms_kernel.cu evaluated directly: f32 devIoU, `>` against the f32 threshold, greedy in score order
+            order = dets[:, 4].argsort()[::-1]
+            b = dets[order, :4]
+            area = (b[:, 2] - b[:, 0] + np.float32(1)) * (b[:, 3] - b[:, 1] + np.float32(1))
+            alive = np.ones(len(b), bool)
+            want = []
+            for i in range(len(b)):
+                if not alive[i]:
+                    continue
+                want.append(int(order[i]))
+                w = np.maximum(np.minimum(b[i, 2], b[:, 2]) - np.maximum(b[i, 0], b[:, 0]) + np.float32(1), np.float32(0))
+                h = np.maximum(np.minimum(b[i, 3], b[:, 3]) - np.maximum(b[i, 1], b[:, 1]) + np.float32(1), np.float32(0))
+                inter = w * h
+                iou = inter / (area[i] + area - inter)
+                assert iou.dtype == np.float32
+                kill = iou > np.float32(th)
+                kill[:i + 1] = False
+                alive &= ~kill
+            assert nms(dets, th) == want, th
+    finally:
+        cfg.USE_GPU_NMS = False
+
+
 def test_utils_nms_and_nms_new_golden(torch_cuda):
     """f3 on the file the reference calls: utils/nms.pyx `nms` (fast_rcnn/test_bus.py:366) and `nms_new`
     (:70-123), fixtures produced by that file's own functions (tests/golden/make_golden.py)."""

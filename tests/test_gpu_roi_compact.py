@@ -523,6 +523,42 @@ def test_owner_form_with_the_reference_ops_i32_argmax(torch_cuda, shape):
                                                _lib.ptr(a), _lib.ptr(ws), nws, 2, _lib.ptr(scr), nscr, _lib.stream()) != 0
 
 
+def test_owner_rule_respects_the_pooled_size(torch_cuda):
+    """A train-sized launch with 14 x 14 bins: the 1-byte pair takes it, the list-driven backward (walk and owner forms:
+    pooled sizes up to 8) does not.  The rule must say -1 for it -- with cfg.ROI_POOL_BWD_OWNER = 'auto' the autograd
+    pair used to hand owner plan 8 to wssdl_roi_pool_backward_owner_prepare, which refused the launch (round-5 advice)
+    -- and the autograd pair must run the fallback kernel and agree with the i32 pair of the reference contract."""
+    torch = torch_cuda
+    from wssdl_bus_amd import _lib
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    L = _lib.lib()
+    N, H, W, C, R = 2, 20, 30, 1024, 1536
+    assert cfg.ROI_POOL_BWD_OWNER == "auto" and not cfg.ROI_POOL_BWD_EXACT
+    assert L.wssdl_roi_pool_backward_owner_plan(R, N, H, W, C) == 8                      # the 7 x 7 rule by shape alone
+    assert L.wssdl_roi_pool_backward_owner_plan_for(R, N, H, W, C, 7, 7) == 8
+    assert L.wssdl_roi_pool_backward_owner_plan_for(R, N, H, W, C, 14, 14) == -1
+    assert L.wssdl_roi_pool_backward_owner_plan_for(R, N, H, W, C, 8, 8) == 8
+    assert L.wssdl_roi_pool_backward_owner_plan_for(6_000_000, 2, 38, 63, 1024, 7, 7) == -1    # R * 49 * C beyond the walk's offsets
+    assert op.compact_supported(H, W, C, 14, 14) and op.owner_plan((N, H, W, C), R, 14, 14) == -1
+    rs = np.random.RandomState(8)
+    f_np = np.maximum(rs.normal(size=(N, H, W, C)), 0).astype(np.float32)
+    rois_np = _rois_for(rs, R, N, H, W)
+    rois_np = rois_np[np.argsort(rois_np[:, 0], kind="stable")]
+    rt = torch.from_numpy(rois_np).cuda()
+    f = torch.from_numpy(f_np).cuda().requires_grad_(True)
+    top, arg8 = op.RoiPoolFunction.apply(f, rt, 14, 14, 1.0 / 16, None)
+    assert arg8.dtype == torch.uint8
+    w = torch.randn(top.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    (top * w).sum().backward()
+    top_i, arg_i = op.roi_pool(f.detach(), rt, 14, 14, 1.0 / 16)
+    assert torch.equal(top.detach(), top_i)
+    assert torch.equal(op.expand_argmax(arg8, rt, (N, H, W, C), 14, 14, 1.0 / 16), arg_i)
+    want = op.roi_pool_grad(f.detach(), rt, arg_i, w, 14, 14, 1.0 / 16)
+    assert torch.equal(f.grad, want)                    # both are the reference's summation order
+    assert not op.flags_raised()
+
+
 def test_owner_rule_and_autograd(torch_cuda):
     """Which launches the library sends to the bin-owner form (wssdl_roi_pool_backward_owner_plan; measured in
     tools/owner_ab.sh) and the autograd pair under cfg.ROI_POOL_BWD_OWNER / _EXACT."""

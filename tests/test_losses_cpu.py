@@ -102,3 +102,18 @@ def test_reshape_layer_index_map():
         assert y[0, a * H + h, w, c] == x[0, h, w, c * A + a]
     z = net.feed('rpn_cls_score_reshape').reshape_layer(2 * A, name='rpn_cls_prob_reshape').get_output('rpn_cls_prob_reshape')
     assert torch.equal(z, x)                                                          # inverse map
+
+
+def test_gpu_nms_rule_as_a_threshold_of_the_cpu_rule():
+    """fast_rcnn/nms_wrapper.gpu_rule_threshold: for every f32 iou, iou > (float)thresh (nms_kernel.cu:71) is
+    (double)iou >= gpu_rule_threshold(thresh) -- the compare the HIP kernel makes."""
+    import numpy as np
+    from wssdl_bus_amd.fast_rcnn.nms_wrapper import gpu_rule_threshold
+    rs = np.random.RandomState(0)
+    for th in (0.7, 0.5, 0.3, 0.05, 0.95, float(np.float32(0.7)), 1.0 / 3):
+        t32 = np.float32(th)
+        near = np.array([t32, np.nextafter(t32, np.float32(1)), np.nextafter(t32, np.float32(0))], np.float32)
+        iou = np.concatenate([near, rs.uniform(0, 1, 20000).astype(np.float32),
+                              (t32 + rs.uniform(-1e-6, 1e-6, 20000)).astype(np.float32)])
+        assert np.array_equal(iou > t32, iou.astype(np.float64) >= gpu_rule_threshold(th)), th
+    assert gpu_rule_threshold(0.7) < 0.7 and gpu_rule_threshold(0.5) > 0.5

@@ -79,6 +79,7 @@ SYMBOLS = {
                                                    _vp, _sz, _vp]),
     "wssdl_roi_pool_backward_owner_plan_count": (_i, []),
     "wssdl_roi_pool_backward_owner_plan": (_i, [_i, _i, _i, _i, _i]),
+    "wssdl_roi_pool_backward_owner_plan_for": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "wssdl_roi_pool_backward_owner_scratch_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "wssdl_roi_pool_backward_owner_prepare": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _i, _vp]),
     "wssdl_roi_pool_backward_compact_owner": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _i,

@@ -892,7 +892,7 @@ struct SweepArgs {
     // complete before the sweep starts.
     const int *segdone;  int nrb;
     // fused run: how long a stager waits for a column segment without progress before it gives up, in ticks of
-    // the 100 MHz real-time counter (0.5 s unless the fault-injection knob shortens it)
+    // the 100 MHz real-time counter (tuning "nms_wait_us", 50 ms, unless the fault-injection knob shortens it)
     unsigned long long wait_ticks;
     // fused run: where the spare wave publishes the kept bitmask of every resolved chunk for the mask role
     // (MaskArgs::keptpub); NULL: nobody reads it
@@ -900,7 +900,7 @@ struct SweepArgs {
 };
 
 // Wait (one wave, before it reads words of column segment `index`) until the mask blocks running beside
-// this sweep have finished that segment.  Bounded: after ~0.5 s without progress the wave gives up
+// this sweep have finished that segment.  Bounded: after ~50 ms ("nms_wait_us") without progress the wave gives up
 // and raises *timed_out; the image then reports num_keep = -1 (WSSDL_NMS_TIMED_OUT), which every consumer of
 // the counts treats as an error -- never a silent zero (the GPU shared with a long-running kernel of another
 // process is the realistic cause: the mask blocks this sweep waits for are then not being scheduled).
@@ -1441,9 +1441,13 @@ static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n
                         NMS_DENSE_AHEAD, segdone + ncb - 2, ncb, 0, sparse ? keptpub : nullptr, tuning().nms_sparse};
     const SweepArgs S = {mask, diag_t, summ, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
                          boxes, box_stride_img, rois_padded, 0x7fffffff, nullptr, nullptr, segdone, nrb,
-                         // 0.5 s; wssdl_set_tuning("nms_fused_fault", microseconds) shortens the wait AND withholds
-                         // image 0's segment counts: the test of the time-out path
-                         fault > 0 ? (unsigned long long)fault * 100ull : 50000000ull, sparse ? keptpub : nullptr};
+                         // "nms_wait_us" (50 ms: a column segment is ~50 us of mask work, so three orders of magnitude of
+                         // slack for a GPU shared with another queue; it was 0.5 s until round 6);
+                         // wssdl_set_tuning("nms_fused_fault", microseconds) shortens the wait AND withholds image 0's
+                         // segment counts: the test of the time-out path
+                         fault > 0 ? (unsigned long long)fault * 100ull
+                                   : (unsigned long long)(tuning().nms_wait_us > 0 ? tuning().nms_wait_us : 50000) * 100ull,
+                         sparse ? keptpub : nullptr};
     const size_t lds_mask = (size_t)(SWEEP_BLOCK / 64) * (5 * 64 * sizeof(float) + 64 * sizeof(nms_float4v));
     SegTable table;
     if (nseg > MASK_MAX_SEGS) return WSSDL_ERR_INVALID_ARGUMENT;

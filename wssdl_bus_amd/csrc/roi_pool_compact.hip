@@ -980,6 +980,12 @@ extern "C" int wssdl_roi_pool_backward_owner_plan(int R, int N, int H, int W, in
     return owner_plan_auto(R, N, H, W, C);
 }
 
+extern "C" int wssdl_roi_pool_backward_owner_plan_for(int R, int N, int H, int W, int C, int pooled_h, int pooled_w) {
+    if (R < 0 || N < 1 || !compact_supported(H, W, C, pooled_h, pooled_w) || !owner_supported(R, N, H, W, C, pooled_h, pooled_w))
+        return -1;
+    return owner_plan_auto(R, N, H, W, C);
+}
+
 extern "C" size_t wssdl_roi_pool_backward_owner_scratch_bytes(int N, int H, int W, int C, int owner_plan) {
     return owner_scratch_bytes(N, H, W, C, owner_plan);
 }

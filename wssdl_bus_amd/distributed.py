@@ -167,6 +167,16 @@ class DistContext(object):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_floats(self, value):
+        """[value of rank 0, ..., value of rank world_size - 1] on every rank (one all-gather)."""
+        if not self.enabled:
+            return [float(value)]
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        out = [torch.zeros_like(t) for _ in range(self.world_size)]
+        dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
     def count_ranks(self):
         """How many ranks the collective backend really connects: every rank adds 1 (an all-reduce over
         RCCL / gloo), so a scaling record shows that N processes took part, not just that N were asked for."""
@@ -220,6 +230,7 @@ class GradOverlap(object):
         self.handles = []
         if ctx.enabled:
             self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+        self.timing, self._spans, self.finishes, self.late_buckets = False, [], 0, 0
         self._reset()
 
     def _reset(self):
@@ -243,13 +254,49 @@ class GradOverlap(object):
         """Call after backward, before optimizer.step()."""
         if not self.ctx.enabled:
             return
+        self.late_buckets += len(self.buckets) - self.next_to_launch
         for b in range(self.next_to_launch, len(self.buckets)):
             self._launch(b)
+        # exposed all-reduce time = how long the compute stream stands still here waiting for the collectives that
+        # backward did not hide (RCCL: work.wait() makes the current stream wait, events on that stream bracket it; gloo:
+        # the wait blocks the host, a host clock brackets it).  Collected only while `timing` is on (bench.py).
+        t0 = self._mark() if self.timing else None
+        for b in range(len(self.buckets)):
+            self.launched[b][1].wait()
+        if self.timing:
+            self._spans.append((t0, self._mark()))
         for b, ps in enumerate(self.buckets):
             flat, work, had = self.launched[b]
             self.ctx._write_back(flat, work, ps, had)
         self.ctx.poll_patterns()
+        self.finishes += 1
         self._reset()
+
+    def _mark(self):
+        p = self.params[0] if self.params else None
+        if p is not None and p.is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        import time
+        return time.perf_counter()
+
+    def start_timing(self):
+        self.timing, self._spans, self.finishes, self.late_buckets = True, [], 0, 0
+
+    def stats(self):
+        """After a synchronize: what one scaling record needs to explain itself -- buckets and their bytes (gradients
+        + has-grad flags, as sent), all-reduce calls per finish(), exposed wait per finish() in ms, and how many buckets
+        were still unlaunched when backward ended (launched by finish(): never overlapped)."""
+        spans = []
+        for a, b in self._spans:
+            spans.append(a.elapsed_time(b) if hasattr(a, "elapsed_time") else (b - a) * 1e3)
+        sizes = [sum(p.numel() * p.element_size() for p in ps) + len(ps) * ps[0].element_size() for ps in self.buckets]
+        n = max(self.finishes, 1)
+        return dict(buckets=len(self.buckets), bucket_bytes=sizes, allreduce_bytes_per_finish=int(sum(sizes)),
+                    finishes=self.finishes, exposed_wait_ms_per_finish=(sum(spans) / len(spans) if spans else 0.0),
+                    exposed_wait_ms_max=(max(spans) if spans else 0.0),
+                    late_buckets_per_finish=self.late_buckets / n, bucket_bytes_cap=int(self.ctx.bucket_bytes))
 
     def remove(self):
         for h in self.handles:

@@ -81,8 +81,9 @@ __C.TEST.RPN_MIN_SIZE = 16                          # :265
 
 __C.RNG_SEED = 3                                    # :290
 __C.EPS = 1e-14                                     # :293
-__C.USE_GPU_NMS = False                             # :321 (kept for API parity; the HIP NMS
-                                                    #  implements the cpu_nms rule either way)
+__C.USE_GPU_NMS = False                             # :321.  True: nms_wrapper.nms and the proposal layer apply the CUDA
+                                                    #  kernel's rule (iou > (float)thresh, nms_kernel.cu:71) instead of
+                                                    #  cpu_nms's ((double)iou >= thresh); both run the HIP kernel
 
 # --- additions of this implementation (not in the reference) -----------------
 # 'reference': anchor / RoI sub-sampling draws from numpy's global legacy RandomState
@@ -114,17 +115,22 @@ __C.ROI_POOL_FLAG_CHECK = "deferred"
 # associates each element's f32 sum differently from the reference (within ~1e-7 of it; north_star's tolerance
 # for RoI pooling is 1e-5); the parity tests of the gradient run the exact walk.
 __C.ROI_POOL_BWD_SPLIT = 'auto'
-# RoI-pool backward of the training path on train-sized launches (>= 2048 RoIs, >= 1024 (image, channel) pairs): the
-# bin-owner form (round 5: every bin read once by the tile of its window's first cell, halos merged in a fixed order;
-# 10-25 % faster than the exact walk, deterministic, within ~1e-6 of the reference's ordered sum).  'auto' = the
-# library's rule (wssdl_roi_pool_backward_owner_plan), an int = that owner plan, -1 = never.  Takes precedence over
-# the split form.
+# RoI-pool backward of the training path on train-sized launches: the bin-owner form (round 5: every bin read once by
+# the tile of its window's first cell, halos merged in a fixed order; 10-25 % faster than the exact walk,
+# deterministic, within ~1e-6 of the reference's ordered sum).  'auto' = the library's rule
+# (wssdl_roi_pool_backward_owner_plan_for: R >= 1536 RoIs, C % 128 == 0, N * C >= 2048 (image, channel) pairs, pooled
+# size <= 8 x 8 -> owner plan 8; anything else -1 = the split form / exact walk), an int = that owner plan, -1 = never.
+# Takes precedence over the split form.  Its halo scratch is N * tiles * 42 cells * C * 4 bytes per backward call
+# (179 MB at 8 x 38 x 63 x 1024, 2.3 x bottom_diff; only the halo cells are touched).  train_bus prints the form the
+# first backward of a run takes (BackwardPlan.variant).
 __C.ROI_POOL_BWD_OWNER = 'auto'
 # True: the backward is ALWAYS the exact walk -- the reference's f32 summation order (roi, ph, pw), bit for bit
 # (roi_pooling_op_gpu.cu.cc:132-186) -- whatever the two keys above say.  The default training gradient is
 # tolerance-parity (north_star: 1e-5; measured <= 1e-6 of the tensor's scale), not bit-parity; every forward output
 # and every integer result is bit-exact in both settings.
 __C.ROI_POOL_BWD_EXACT = False
+# the first backward of each launch class (images x channels x form) prints the form it takes to stderr
+__C.ROI_POOL_ANNOUNCE_BWD_FORM = True
 __C.PADDED_ROIS = False
 # a13: the four supervised loss terms and their gradients as one device op (csrc/loss.hip) when the
 # layers are on the GPU; False = the chain of torch ops in fast_rcnn/train_bus.py

@@ -127,18 +127,21 @@ class _DeviceFlags(object):
 
     @staticmethod
     def _raise(v, strict=True):
-        if int(v[0]) != 0:
-            raise _lib.HipCallError(_OVERFLOW_MSG)
-        if int(v[1]) != 0:
-            raise _lib.HipCallError(_LISTS_MSG)
-        if int(v[2]) != 0:
-            if strict:
-                raise _lib.HipCallError(_NMS_TIMEOUT_MSG)
+        # the time-out first: its handling (two launches from here on, the step counted as tainted) must not be lost
+        # when one of the other two flags raises in the same poll
+        if int(v[2]) != 0 and not strict:
             # the sync-free training path: that step ran with no proposals for the image whose sweep gave up; from
             # here on mask and sweep run as two launches (no waits between workgroups, identical results)
             from ..rpn_msr.proposal_layer_tf_bus import note_nms_timeout
             note_nms_timeout("deferred flag of the padded path")
             _lib.set_tuning("nms_fused", 0)
+            _tainted["steps"] += 1
+        if int(v[0]) != 0:
+            raise _lib.HipCallError(_OVERFLOW_MSG)
+        if int(v[1]) != 0:
+            raise _lib.HipCallError(_LISTS_MSG)
+        if int(v[2]) != 0 and strict:
+            raise _lib.HipCallError(_NMS_TIMEOUT_MSG)
 
     def read_and_clear(self):
         v = self.flags.cpu()
@@ -160,6 +163,7 @@ class _DeviceFlags(object):
 
 
 _device_flags = {}
+_tainted = {"steps": 0}
 
 
 def _flags(dev):
@@ -186,9 +190,21 @@ def poll_flags():
 
 
 def check_flags():
-    """Synchronising check: raises HipCallError if any compact RoI-pool call raised a flag."""
+    """Synchronising check: raises HipCallError if any compact RoI-pool call raised a flag, or if an earlier sync-free
+    poll swallowed an NMS time-out (a step that was applied with an image's proposals missing: tainted_steps()).  The
+    train loop calls this before it writes a snapshot."""
     for f in list(_device_flags.values()):
         _DeviceFlags._raise(f.read_and_clear())
+    if _tainted["steps"]:
+        n, _tainted["steps"] = _tainted["steps"], 0
+        raise _lib.HipCallError("%d optimiser step(s) since the last check ran with an image's proposals missing (NMS sweep "
+                                "time-out seen by the sync-free poll; the process switched to two NMS launches).  " % n
+                                + _NMS_TIMEOUT_MSG)
+
+
+def tainted_steps():
+    """Steps applied since the last check_flags() although an NMS sweep had timed out (sync-free path)."""
+    return _tainted["steps"]
 
 
 def flags_raised():
@@ -303,7 +319,7 @@ def roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scal
     return BackwardPlan(ws, nws, int(plan.value))
 
 
-def owner_plan(shape, R):
+def owner_plan(shape, R, pooled_height=7, pooled_width=7):
     """The owner plan the bin-owner form of the list-driven backward should use for this launch, or -1 to keep
     the exact walk: cfg.ROI_POOL_BWD_OWNER = 'auto' (the library's rule by launch shape), an int plan id, or -1 / False
     for never.  >= 0 is deterministic but NOT bit-identical to the reference's summation order (like the split form)."""
@@ -312,7 +328,9 @@ def owner_plan(shape, R):
     if cfg.get("ROI_POOL_BWD_EXACT", False):
         return -1
     if v == "auto":
-        return int(_lib.lib().wssdl_roi_pool_backward_owner_plan(int(R), N, H, W, C))
+        # (-1 too when the owner form does not take the launch: pooled sizes above 8, very large R * C)
+        return int(_lib.lib().wssdl_roi_pool_backward_owner_plan_for(int(R), N, H, W, C, int(pooled_height),
+                                                                      int(pooled_width)))
     if v is False or v is None:
         return -1
     return int(v)
@@ -341,7 +359,7 @@ def prepare_backward(shape, rois, pooled_height, pooled_width, spatial_scale, ro
     bin-owner form where the library suggests it, else the split form where it suggests that, else the exact walk.
     The returned plan carries `.variant` (a description for logs and bench lines) and `.segments`."""
     R = rois.shape[0]
-    own = owner_plan(shape, R)
+    own = owner_plan(shape, R, pooled_height, pooled_width)
     if own >= 0:
         plan = roi_pool_grad_prepare_owner(shape, rois, pooled_height, pooled_width, spatial_scale, own, rounding)
         plan.segments = 1
@@ -432,6 +450,21 @@ def expand_argmax(arg8, rois, shape, pooled_height, pooled_width, spatial_scale,
     return out
 
 
+_announced_forms = set()
+
+
+def _announce_backward_form(shape, R, plan):
+    """Once per process and launch class: which form the training gradient takes (the default is tolerance parity --
+    the bin-owner / split forms -- not the reference's bit order; cfg.ROI_POOL_BWD_EXACT = True switches it)."""
+    key = (shape[0], shape[3], plan.variant)
+    if key in _announced_forms or not cfg.get("ROI_POOL_ANNOUNCE_BWD_FORM", True):
+        return
+    _announced_forms.add(key)
+    import sys
+    print("[wssdl_bus_amd] RoI-pool backward, %d images x %d channels, %d RoIs: %s" % (shape[0], shape[3], R, plan.variant),
+          file=sys.stderr)
+
+
 class RoiPoolFunction(torch.autograd.Function):
     """autograd wiring of the pair above (roi_pooling_op_grad.py:24-44): the
     gradient flows to the feature map only; rois get None.  The second output is the arg-max
@@ -459,6 +492,7 @@ class RoiPoolFunction(torch.autograd.Function):
             if data.requires_grad or bottom_data.requires_grad:
                 # the backward's lists depend on the RoIs only: build them now, behind the forward
                 ctx.plan = prepare_backward(tuple(data.shape), rois, pooled_height, pooled_width, spatial_scale, rounding)
+                _announce_backward_form(tuple(data.shape), rois.shape[0], ctx.plan)
         else:
             top, arg = roi_pool(data, rois, pooled_height, pooled_width, spatial_scale,
                                 rounding=rounding)

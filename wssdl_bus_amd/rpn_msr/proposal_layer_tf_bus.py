@@ -33,6 +33,11 @@ def proposal_layer_padded(rpn_cls_prob_reshape, rpn_bbox_pred, im_info, is_train
     if prob.dim() != 4 or pred.dim() != 4 or info.dim() != 2:
         raise ValueError("expected rpn_cls_prob_reshape/rpn_bbox_pred [N,H,W,C] and im_info [N,k]")
     pre, post, thresh, min_size = _rpn_params(bool(is_training))
+    if cfg.USE_GPU_NMS:
+        # the reference's proposal layer calls nms_wrapper.nms (proposal_layer_tf_bus.py:139), which cfg.USE_GPU_NMS sends
+        # to the CUDA kernel's `>` / f32-threshold rule
+        from ..fast_rcnn.nms_wrapper import gpu_rule_threshold
+        thresh = gpu_rule_threshold(thresh)
     anchors = generate_anchors(scales=np.array(anchor_scales))
     A = anchors.shape[0]
     N, H, W = prob.shape[:3]
@@ -124,16 +129,31 @@ def note_nms_timeout(where):
                       "process or kernel; falling back to the two-launch NMS (same results)" % where, RuntimeWarning)
 
 
+# After a time-out the per-call path stays on the two-launch NMS for this many calls before it tries the fused launch
+# again: a GPU that is shared with another process stays shared, and every fused call would stall for the whole wait
+# ("nms_wait_us") before it recovers.  Same results either way.
+NMS_TIMEOUT_COOLDOWN_CALLS = 1000
+_cooldown = [0]
+
+
 def _run(scores, rpn_bbox_pred, im_info, is_training, _feat_stride, anchor_scales, from_logits):
     as_np = _lib.wants_numpy(scores, rpn_bbox_pred, im_info)
-    rois, counts = proposal_layer_padded(scores, rpn_bbox_pred, im_info, is_training, _feat_stride, anchor_scales,
-                                         from_logits=from_logits)
+    if _cooldown[0] > 0 and not (cfg.PADDED_ROIS and not as_np):
+        _cooldown[0] -= 1
+        with _lib.tuned(nms_fused=0):
+            rois, counts = proposal_layer_padded(scores, rpn_bbox_pred, im_info, is_training, _feat_stride, anchor_scales,
+                                                 from_logits=from_logits)
+    else:
+        rois, counts = proposal_layer_padded(scores, rpn_bbox_pred, im_info, is_training, _feat_stride, anchor_scales,
+                                             from_logits=from_logits)
     if cfg.PADDED_ROIS and not as_np:
         return padded_blob(rois, counts)
     counts_host = counts.cpu().numpy()
     if (counts_host < 0).any():
-        # WSSDL_NMS_TIMED_OUT: recompute THIS call with mask and sweep as two launches (no cross-workgroup waits)
+        # WSSDL_NMS_TIMED_OUT: recompute THIS call with mask and sweep as two launches (no cross-workgroup waits) and
+        # keep the following calls on that form for a cool-down
         note_nms_timeout("image(s) %s" % np.nonzero(counts_host < 0)[0].tolist())
+        _cooldown[0] = int(NMS_TIMEOUT_COOLDOWN_CALLS)
         with _lib.tuned(nms_fused=0):
             rois, counts = proposal_layer_padded(scores, rpn_bbox_pred, im_info, is_training, _feat_stride,
                                                  anchor_scales, from_logits=from_logits)
