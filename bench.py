@@ -436,6 +436,8 @@ def main():
     for _ in range(args.warmup):
         step()
     _lib.timeline.reset(True)
+    if getattr(solver, "overlap", None) is not None:
+        solver.overlap.start_timing()      # exposed all-reduce wait per optimiser step (scaling_diag)
     ctx.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -445,6 +447,26 @@ def main():
     ctx.barrier()
     elapsed = time.perf_counter() - t0
     _lib.timeline.enabled = False
+    # what a single SCALE line needs to explain a miss: every rank's own step time, the all-reduce wait backward did
+    # not hide (per optimiser step, per rank), the buckets and their bytes, buckets launched only after backward
+    my_ms = elapsed / max(args.steps, 1) * 1e3
+    ov = getattr(solver, "overlap", None)
+    ov_stats = ov.stats() if ov is not None else None
+    scaling_diag = dict(
+        ms_per_step_per_rank=[round(v, 3) for v in ctx.gather_floats(my_ms)],
+        exposed_allreduce_ms_per_optimizer_step_per_rank=[round(v, 4) for v in ctx.gather_floats(
+            ov_stats["exposed_wait_ms_per_finish"] if ov_stats else 0.0)],
+        exposed_allreduce_ms_max_per_rank=[round(v, 4) for v in ctx.gather_floats(
+            ov_stats["exposed_wait_ms_max"] if ov_stats else 0.0)],
+        optimizer_steps_per_step=(round(ov_stats["finishes"] / max(args.steps, 1), 2) if ov_stats else None),
+        buckets=(ov_stats["buckets"] if ov_stats else 0), bucket_bytes=(ov_stats["bucket_bytes"] if ov_stats else []),
+        bucket_bytes_cap=(ov_stats["bucket_bytes_cap"] if ov_stats else None),
+        allreduce_bytes_per_optimizer_step=(ov_stats["allreduce_bytes_per_finish"] if ov_stats else 0),
+        late_buckets_per_optimizer_step=(round(ov_stats["late_buckets_per_finish"], 2) if ov_stats else None),
+        backend=(ctx.backend if ctx.enabled else None),
+        note="exposed = the compute stream's wait in GradOverlap.finish() for collectives backward did not hide "
+             "(events around the waits); late buckets = launched by finish(), never overlapped; one process per GPU, "
+             "image-parallel, no data-path collective")
     elapsed = ctx.max_over_ranks(elapsed)
     # the deferred device flags of the timed steps (RoI-pool window / list overflow, NMS time-out): the polls
     # inside the steps run one step late and never see the last one
@@ -567,6 +589,7 @@ def main():
                        "miopen_searched": miopen_db_grew(miopen_db),
                        "roi_pool_argmax_bytes": leg_meta["argmax_bytes"]},
             "roofline": roofline,
+            "scaling_diag": scaling_diag,
             "hot_path": {"gpu_ms_per_step": round(hot_ms, 3),
                          "gpu_images_per_s": round(images_per_step / (hot_ms * 1e-3), 1) if hot_ms > 0 else None,
                          "loss_op_ms_per_step": round(loss_ms, 4), "fused_loss": bool(cfg.get("FUSED_LOSS", True))},

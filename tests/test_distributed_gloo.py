@@ -51,6 +51,7 @@ def _worker(rank, world, port, q):
     ctx.bucket_bytes = 256
     ov = ctx.overlap(p2)
     assert len(ov.buckets) >= 2, [len(b) for b in ov.buckets]
+    ov.start_timing()                                             # the scaling diagnostics bench.py reports
     net2[:3](x).sum().backward()
     if rank == 0:
         (net2[3](torch.ones(2, 8)).sum()).backward()
@@ -70,6 +71,9 @@ def _worker(rank, world, port, q):
     out["overlap2"] = [None if p.grad is None else p.grad.clone() for p in p2]
     opt.step()
     out["adam_moved"] = [bool((p.detach() != b).any()) for p, b in zip(p2, before)]
+    st = ov.stats()
+    out["stats"] = dict(st)
+    out["gathered"] = ctx.gather_floats(10.0 + rank)
     ov.remove()
     out["tmax"] = ctx.max_over_ranks(1.0 + rank)
     out["tsum"] = ctx.sum_over_ranks(1.0 + rank)
@@ -118,6 +122,15 @@ def test_data_parallel_gloo_world2():
         assert res[r]["adam_moved"] == [False] * 4 + [True, True]
         assert torch.allclose(res[r]["overlap2"][4], torch.full((3, 8), 2 * 1.5))      # mean of 2*1 and 2*2
         assert torch.allclose(res[r]["overlap2"][5], torch.full((3,), 2.0))
+    for r in range(world):
+        st = res[r]["stats"]
+        assert st["finishes"] == 2 and st["buckets"] >= 2 and len(st["bucket_bytes"]) == st["buckets"]
+        # every parameter's bytes + one flag per parameter, as sent
+        assert st["allreduce_bytes_per_finish"] == (40 * 64 + 64 + 64 * 8 + 8 + 8 * 3 + 3 + 6) * 4
+        assert st["exposed_wait_ms_per_finish"] >= 0.0 and st["exposed_wait_ms_max"] >= st["exposed_wait_ms_per_finish"]
+        # step 2 produced gradients for the last layer only: the other buckets were launched by finish()
+        assert 0 < st["late_buckets_per_finish"] <= st["buckets"]
+        assert res[r]["gathered"] == [10.0, 11.0]
     assert res[0]["tmax"] == res[1]["tmax"] == 2.0
     assert res[0]["tsum"] == res[1]["tsum"] == 3.0
 

@@ -316,6 +316,15 @@ def test_bench_py_under_torch_distributed_run_two_ranks():
     assert 0 < rf["frac"] < 1 and rf["frac"] == rf["frac_moved"] and rf["frac_8d"] > rf["frac_moved"]
     assert r["final_loss"] is not None and r["final_loss"] == r["final_loss"]        # not NaN
     assert r["n_ranks_seen"] == 2                            # both ranks took part in a collective
+    # the diagnostics one SCALE line needs to explain a miss of the scaling target
+    sd = r["scaling_diag"]
+    assert len(sd["ms_per_step_per_rank"]) == 2 and all(v > 0 for v in sd["ms_per_step_per_rank"])
+    assert max(sd["ms_per_step_per_rank"]) <= r["ms_per_step"] * 1.001
+    assert len(sd["exposed_allreduce_ms_per_optimizer_step_per_rank"]) == 2
+    assert all(0 <= v < r["ms_per_step"] for v in sd["exposed_allreduce_ms_per_optimizer_step_per_rank"])
+    assert sd["buckets"] >= 1 and len(sd["bucket_bytes"]) == sd["buckets"] and sd["backend"] == "gloo"
+    assert sd["allreduce_bytes_per_optimizer_step"] == sum(sd["bucket_bytes"]) > 40e6       # ResNet-18 variant, f32 gradients
+    assert sd["optimizer_steps_per_step"] == 1.0 and sd["late_buckets_per_optimizer_step"] is not None
 
 
 @pytest.mark.timeout(900)

@@ -940,7 +940,11 @@ def test_deferred_flags_poll_raises_one_step_late_and_only_once(torch_cuda):
         rp.check_flags()
     rp.poll_flags()
     torch.cuda.synchronize()
-    rp.poll_flags()                                                   # clean again
+    rp.poll_flags()                                                   # the device flags are clean again
+    # ... but the step the poll let through is remembered until a synchronising check has named it (round 6)
+    assert rp.tainted_steps() == 1
+    with pytest.raises(_lib.HipCallError, match="proposals missing"):
+        rp.check_flags()
     rp.check_flags()
 
 

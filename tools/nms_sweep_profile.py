@@ -61,7 +61,27 @@ def read_profile():
     return buf
 
 
+def report_async(p, img, head):
+    """the form without the barrier: per wave the cycles of its loop and, of those, the cycles inside each of its waits"""
+    chunks = int(p[img, 0, 2])
+    rt_us = float(p[img, 0, 3]) / 100.0
+    head.update(chunks=chunks, resolver_loop_us=round(rt_us, 1), us_per_chunk=round(rt_us / max(chunks, 1), 3), form="no barrier")
+    print(json.dumps(head))
+    roles = ["resolver", "scribe", "scribe", "stager", "stager", "stager"] + ["helper"] * 10
+    sites = {"resolver": ("staged rows", "helpers' words", "-"), "scribe": ("chunk resolved", "rows staged (fused)", "-"),
+             "stager": ("slot free", "-", "-"), "helper": ("chunks expanded", "column stored", "batch landed")}
+    for w in range(16):
+        tot = float(p[img, w, 0])
+        a, b, c = float(p[img, w, 1]), float(p[img, w, 4]), float(p[img, w, 5])
+        n = max(chunks, 1)
+        print("    wave %2d %-8s loop %6.0f cycles per chunk: waits %5.0f (%s) + %5.0f (%s) + %5.0f (%s) = %3.0f %% of the loop; own work %5.0f" % (
+            w, roles[w], tot / n, a / n, sites[roles[w]][0], b / n, sites[roles[w]][1], c / n, sites[roles[w]][2],
+            100.0 * (a + b + c) / max(tot, 1.0), (tot - a - b - c) / n))
+
+
 def report(p, img, head):
+    if int(p[img, 0, 6]) == 0xA51C:
+        return report_async(p, img, head)
     iters = int(p[img, 0, 2])
     rt_us = float(p[img, 0, 3]) / 100.0
     cyc = float(p[img, 0, 0] + p[img, 0, 1])
@@ -98,11 +118,11 @@ prob, pred0 = synth_rpn(N, 38, 63, 9, 3)
 for name, scale, thresh in (("early stop", 1.0, 0.7), ("full walk", 0.3, 0.3)):
     cfg.TRAIN.RPN_NMS_THRESH = thresh
     pred = pred0 * scale
-    for fused in (1, 0):
-        with _lib.tuned(nms_fused=fused):
+    for fused, asyn in ((1, 0), (1, 1), (0, 0), (0, 1)):
+        with _lib.tuned(nms_fused=fused, nms_sweep_async=asyn):
             out = proposal_layer_padded(prob, pred, info, True)
             ms = timeit(lambda: proposal_layer_padded(prob, pred, info, True), args.iters, warmup=3)
             read_profile()                                  # (zeroes the counters)
             proposal_layer_padded(prob, pred, info, True)   # ONE call: the counters hold that walk
             p = read_profile()
-        report(p, 0, dict(case=name, nms_fused=fused, layer_ms=round(ms, 4), kept=int(out[1][0]), defines=args.define))
+        report(p, 0, dict(case=name, nms_fused=fused, nms_sweep_async=asyn, layer_ms=round(ms, 4), kept=int(out[1][0]), defines=args.define))

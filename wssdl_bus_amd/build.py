@@ -33,7 +33,7 @@ def is_stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__), os.path.join(HERE, "isa_check.py")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -48,11 +48,12 @@ def _digest(paths, extra=""):
 
 def _compile_one(args):
     src, obj, flags, verbose = args
-    cmd = [hipcc()] + flags + ["-c", src, "-o", obj + ".tmp"]
+    tmp = "%s.%d.tmp" % (obj, os.getpid())          # (several ranks may build at import time: no shared temporary names)
+    cmd = [hipcc()] + flags + ["-c", src, "-o", tmp]
     if verbose:
         print("[wssdl_bus_amd] " + " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    os.replace(obj + ".tmp", obj)
+    os.replace(tmp, obj)
     return obj
 
 
@@ -88,7 +89,8 @@ def build(force=False, verbose=True):
         import shutil
         shutil.rmtree(os.path.join(CSRC, "_obj"), ignore_errors=True)
     objs = compile_objects(SOURCES, HEADERS, FLAGS, verbose)
-    cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-fvisibility=hidden"] + objs + ["-o", OUT + ".tmp"]
+    tmp = "%s.%d.tmp" % (OUT, os.getpid())
+    cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-fvisibility=hidden"] + objs + ["-o", tmp]
     if verbose:
         print("[wssdl_bus_amd] " + " ".join(cmd))
     subprocess.check_call(cmd)
@@ -96,11 +98,11 @@ def build(force=False, verbose=True):
     # rule -- or that cannot be checked -- is not installed (isa_check.py)
     from . import isa_check
     try:
-        isa_check.check_library(OUT + ".tmp")
+        isa_check.check_library(tmp)
     except Exception:
-        os.remove(OUT + ".tmp")
+        os.remove(tmp)
         raise
-    os.replace(OUT + ".tmp", OUT)
+    os.replace(tmp, OUT)
     return OUT
 
 
@@ -117,11 +119,12 @@ def build_plumbing(force=False, verbose=True):
     if not force and os.path.exists(PLUMB_OUT) and \
             all(os.path.getmtime(f) <= os.path.getmtime(PLUMB_OUT) for f in srcs + [os.path.abspath(__file__)]):
         return PLUMB_OUT
-    cmd = [hipcc()] + PLUMB_FLAGS + srcs + ["-o", PLUMB_OUT + ".tmp"]
+    tmp = "%s.%d.tmp" % (PLUMB_OUT, os.getpid())
+    cmd = [hipcc()] + PLUMB_FLAGS + srcs + ["-o", tmp]
     if verbose:
         print("[wssdl_bus_amd] " + " ".join(cmd))
     subprocess.check_call(cmd)
-    os.replace(PLUMB_OUT + ".tmp", PLUMB_OUT)
+    os.replace(tmp, PLUMB_OUT)
     return PLUMB_OUT
 
 

@@ -28,6 +28,7 @@ static int *tuning_field(const char *key) {
     if (!strcmp(key, "nms_fused")) return &t.nms_fused;
     if (!strcmp(key, "nms_sparse")) return &t.nms_sparse;
     if (!strcmp(key, "nms_wait_us")) return &t.nms_wait_us;
+    if (!strcmp(key, "nms_sweep_async")) return &t.nms_sweep_async;
     if (!strcmp(key, "nms_fused_fault")) return &t.nms_fused_fault;
     if (!strcmp(key, "topk_sort")) return &t.topk_sort;
     return nullptr;

@@ -57,6 +57,7 @@ struct Tuning {
     int nms_fused = 1;          // 0: mask and sweep of a one-pass NMS as two launches instead of the fused one
     int nms_sparse = 16;        // fused launch: far column segments of a row block the sweep has resolved are computed for its kept rows
                                 //    only when it kept at most this many of its 64 boxes (0: never)
+    int nms_sweep_async = 0;    // 1: the NMS sweep's roles run without the per-chunk workgroup barrier (nms_sweep_async_block; measured slower: EXPERIMENTS.md), 0: the barrier version
     int nms_wait_us = 50000;    // fused launch: how long a sweep waits for a column segment of the mask before it reports WSSDL_NMS_TIMED_OUT
     int nms_fused_fault = 0;    // fault injection (tests): > 0 = the fused launch withholds image 0's segment counts
                                 //    and its sweep gives up after this many microseconds -> roi count -1

@@ -897,6 +897,8 @@ struct SweepArgs {
     // fused run: where the spare wave publishes the kept bitmask of every resolved chunk for the mask role
     // (MaskArgs::keptpub); NULL: nobody reads it
     unsigned long long *keptpub;
+    // 1: the roles run without the per-chunk workgroup barrier (nms_sweep_async_block); tuning "nms_sweep_async"
+    int async;
 };
 
 // Wait (one wave, before it reads words of column segment `index`) until the mask blocks running beside
@@ -1108,10 +1110,17 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
                      "v_mov_b32 v90, 0\n\tv_mov_b32 v91, 0\n\tv_mov_b32 v92, 0\n\tv_mov_b32 v93, 0\n\tv_mov_b32 v94, 0\n\t"
                      "v_mov_b32 v95, 0" ::: "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89",
                      "v90", "v91", "v92", "v93", "v94", "v95");
-    const int hall = hw * 64 + lane;
-    int hpos[HELPER_SLOTS];                  // this lane's list positions, held inside the LDS list
+    // Round 6: a helper wave owns 256 CONSECUTIVE list positions (slot j of lane l: hw * 256 + j * 64 + l; it was
+    // hw * 64 + l + j * 640, which puts a live slot into every wave as soon as the list holds 577 boxes), and a wave whose
+    // positions all lie beyond the list skips its turn altogether -- no loads, nothing to take, its batch registers stay
+    // the zero words they start as.  The list only grows, so a wave that has started never stops.  The sixteen waves
+    // of the sweep share four SIMDs: an idle helper's ~90 instructions per chunk are issue slots for the others.
+    const int wave_first = hw * (HELPER_SLOTS * 64);
+    bool helper_live = false;
+    int hposl[HELPER_SLOTS];                 // this lane's list positions; hpos = the same, held inside the LDS list
+    int hpos[HELPER_SLOTS];
 #pragma unroll
-    for (int j = 0; j < HELPER_SLOTS; ++j) hpos[j] = min(hall + j * HELPER_LANES, max_keep);
+    for (int j = 0; j < HELPER_SLOTS; ++j) { hposl[j] = wave_first + j * 64 + lane;  hpos[j] = min(hposl[j], max_keep); }
     // The helpers' turn is the longest of most iterations (tools/nms_sweep_profile.py: the last helper waves arrive
     // last at the barrier in 50-90 % of them) and what it costs is issue slots: one CU issues for all sixteen
     // waves, and a turn took the same ~1100-1400 cycles with nothing to gather as with a full list.  So it is
@@ -1126,6 +1135,9 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
     unsigned long long prof_mid = 0ull;      // helpers: cycles in take() (the wait for the batch); stagers: in the wait for their rows
 #endif
     auto helper_turn = [&](auto &take, auto &issue, int c) {
+        const int lim = (c >= 1 && c + 3 < nchunks) ? min(sh.pub[(c - 1) & 1].base, max_keep) : 0;
+        helper_live = helper_live || wave_first < lim;
+        if (!helper_live) return;
         // consume word c+1: this batch was issued at iteration c-2; the one issued at c-1 may stay in flight
         // (the instruction itself: atomicOr() on one address becomes a loop over the active lanes)
 #ifdef WSSDL_SWEEP_PROFILE
@@ -1143,19 +1155,18 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
         // checked by the launcher).  (A lane per CHUNK, walking the bits of kept & summary, needs no list -- but
         // a chunk can hold more such boxes than a lane has registers, and the overflow loads sat inside the
         // iteration: 0.49 against 0.37 ms in the step.)
-        const int lim = (c >= 1 && c + 3 < nchunks) ? min(sh.pub[(c - 1) & 1].base, max_keep) : 0;
         const unsigned *colsum_now = reinterpret_cast<const unsigned *>(sh.colsum[(c + 3) & 3]);
         unsigned row[HELPER_SLOTS], cw[HELPER_SLOTS];
 #pragma unroll
         for (int j = 0; j < HELPER_SLOTS; ++j) row[j] = (unsigned)kept_rows[hpos[j]];
 #pragma unroll
-        for (int j = 0; j < HELPER_SLOTS; ++j) row[j] = (hall + j * HELPER_LANES < lim) ? row[j] : 0u;
+        for (int j = 0; j < HELPER_SLOTS; ++j) row[j] = (hposl[j] < lim) ? row[j] : 0u;
 #pragma unroll
         for (int j = 0; j < HELPER_SLOTS; ++j) cw[j] = colsum_now[row[j] >> 5];
         const unsigned long long *src[HELPER_SLOTS];
 #pragma unroll
         for (int j = 0; j < HELPER_SLOTS; ++j) {
-            const unsigned hit = (unsigned)(hall + j * HELPER_LANES < lim) & (cw[j] >> (row[j] & 31u)) & 1u;
+            const unsigned hit = (unsigned)(hposl[j] < lim) & (cw[j] >> (row[j] & 31u)) & 1u;
             src[j] = hit ? m + (__umul24(row[j], (unsigned)ncb) + (unsigned)(c + 3)) : zero_word;
         }
 #pragma unroll
@@ -1275,11 +1286,377 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
     }
 }
 
+// ------------------------------------------- nms sweep, roles without a barrier ---
+// Round 6.  The role-pipelined sweep above joins its sixteen waves with ONE workgroup barrier per chunk, and an
+// iteration (1.05 us, 188 of them in a full walk) turned out to wait for that barrier and the LDS hand-overs around
+// it, not for any role's instructions (round 5: fewer helper instructions, same time).  Here every role runs ITS OWN
+// loop over the chunks and waits only for what it reads, through sequence numbers in LDS that their single writers
+// only ever count up:
+//   resolved      chunks the resolver has resolved           (writer: resolver)
+//   staged[s]     chunk + 1 of the last rows stager s wrote   (three stagers, chunk k belongs to stager k % 3)
+//   expanded[g]   chunk + 1 of the last chunk scribe g expanded into the kept list (scribe g: turns t with t & 1 == g,
+//                 turn t expands chunk t - 1)
+//   colstored[g]  column + 1 of the last column summary scribe g stored
+//   hdone[w & 7]  helper waves that have ORed their part of `removed` word w into the ring
+// The schedule is the barrier version's (who computes what, how far ahead: resolver = the four chunks before a word
+// from the staged rows, helpers = everything older from the kept list, two batches of gathers in flight); only the
+// joins differ.  resolver at chunk c: staged[c % 3] > c and, from word 5 on, hdone[c & 7] = all helpers.  Stager of
+// chunk k: the slot k & 3 is free once chunk k - 4 is resolved.  Scribe turn t: chunk t - 1 resolved.  Helpers at
+// index c (take word c + 1, issue word c + 3): chunks <= c - 2 expanded, column c + 3 stored.  No cycle: everything
+// waits for the resolver's past or for a role that does.  Every wait is bounded (spins, then `abort`: all roles leave,
+// the image reports WSSDL_NMS_TIMED_OUT) and ends when the resolver has stopped (`stop` = chunks resolved in all).
+// Results: the same kept sets by construction (same words, ORed in a different order); tests/test_gpu_parity.py
+// (reference keep lists), tools/nms_fuzz.py, tools/nms_fused_stress.py.
+constexpr int ASYNC_STAGERS = 3;
+constexpr int ASYNC_ROW_SLOTS = 4;
+constexpr int ASYNC_SPIN_LIMIT = 1 << 22;        // polls of ~100-200 cycles each: > 0.1 s
+
+struct SweepAsyncShared {
+    unsigned long long ring[8];
+    unsigned long long rowbuf[ASYNC_ROW_SLOTS][SWEEP_AHEAD + 1][64];   // [chunk & 3][0 = T, j = word c+j][row]
+    unsigned long long colsum[4][SWEEP_MAX_CHUNKS];                   // [column block & 3][row block]
+    struct __attribute__((aligned(16))) Publish {
+        unsigned long long kept;
+        int base, count;
+    } pub[8];                                                          // by chunk & 7
+    int hdone[8];
+    int resolved, stop, abort, timed_out;
+    int staged[ASYNC_STAGERS + 1];
+    int expanded[2], colstored[2];
+};
+
+// (every lane reads the same word; readfirstlane tells the compiler so -- a poll loop on a per-lane value becomes vector
+// control flow with saved exec masks, and the kernel spilled 217 scalar registers to vector lanes)
+__device__ __forceinline__ int lds_peek(const int *p) {
+    return __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int *>(p));
+}
+__device__ __forceinline__ void lds_post(int *p, int v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (LDS executes a wave's operations in order; this is for the compiler)
+    *reinterpret_cast<volatile int *>(p) = v;
+}
+// until *p >= v.  false: it never will (the resolver has stopped, or somebody gave up)
+template <int SLEEP>
+__device__ __forceinline__ bool lds_wait_ge_raw(const int *p, int v, SweepAsyncShared &sh) {
+    for (int spins = 0;; ++spins) {
+        if (lds_peek(p) >= v) return true;
+        if (lds_peek(&sh.abort)) return false;
+        if (lds_peek(&sh.stop) != 0x7fffffff) return lds_peek(p) >= v;
+        if (spins > ASYNC_SPIN_LIMIT) { *reinterpret_cast<volatile int *>(&sh.abort) = 1;  return false; }
+        __builtin_amdgcn_s_sleep(SLEEP);
+    }
+}
+#ifdef WSSDL_SWEEP_PROFILE
+// profile build (tools/nms_sweep_profile.py --async): cycles a wave spends in each of its waits, by site
+#define WSSDL_ASYNC_WAIT(SLEEP, P, V, SITE)                                                  \
+    [&]() {                                                                                  \
+        const unsigned long long w0 = __builtin_amdgcn_s_memtime();                          \
+        const bool r = lds_wait_ge_raw<SLEEP>(P, V, sh);                                     \
+        prof_site[SITE] += __builtin_amdgcn_s_memtime() - w0;                                \
+        return r;                                                                            \
+    }()
+#else
+#define WSSDL_ASYNC_WAIT(SLEEP, P, V, SITE) lds_wait_ge_raw<SLEEP>(P, V, sh)
+#endif
+
+__device__ __forceinline__ void nms_sweep_async_block(const SweepArgs &A, int img, int *kept_rows /* LDS [max_keep + 64] */,
+                                                      SweepAsyncShared &sh) {
+    const unsigned long long *__restrict__ mask = A.mask, *__restrict__ diag_t = A.diag_t, *__restrict__ summ = A.summ;
+    const int n_max = A.n_max, ncb = A.ncb, max_keep = A.max_keep, order_stride_img = A.order_stride_img,
+              box_stride_img = A.box_stride_img, n_limit = A.n_limit;
+    const int *__restrict__ n_dev = A.n_dev, *__restrict__ order = A.order, *__restrict__ done_in = A.done_in;
+    int *__restrict__ keep = A.keep, *__restrict__ num_keep = A.num_keep, *__restrict__ done_out = A.done_out;
+    const float *__restrict__ boxes = A.boxes;
+    float *__restrict__ rois_padded = A.rois_padded;
+    if (done_in && done_in[img]) return;
+    const int n = min(min(n_dev[img], n_max), n_limit);
+    const int nchunks = (n + 63) / 64;
+    const unsigned long long *m = mask + (size_t)img * n_max * ncb;
+    const unsigned long long *dt = diag_t + (size_t)img * n_max;
+    const unsigned long long *cs = summ + (size_t)img * ncb * ncb;        // [column block][row block]
+    const unsigned long long *zero_word = wssdl_sweep_zero_word;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 8) { sh.ring[tid] = 0ull;  sh.hdone[tid] = 0;  sh.pub[tid].kept = 0ull;  sh.pub[tid].base = 0;  sh.pub[tid].count = 0; }
+    if (tid == 0) {
+        sh.resolved = 0;  sh.stop = 0x7fffffff;  sh.abort = 0;  sh.timed_out = 0;
+        for (int i = 0; i <= ASYNC_STAGERS; ++i) sh.staged[i] = 0;
+        sh.expanded[0] = sh.expanded[1] = 0;  sh.colstored[0] = sh.colstored[1] = 0;
+    }
+    __syncthreads();
+    constexpr int NHELPERS = SWEEP_BLOCK / 64 - SWEEP_FIRST_HELPER;
+    int count = 0;
+#ifdef WSSDL_SWEEP_PROFILE
+    unsigned long long prof_site[4] = {0ull, 0ull, 0ull, 0ull};      // [0], [1]: the role's two waits; [2]: helpers' wait for a batch, stagers' for segments
+    const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(), prof_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    if (wave == 0) {
+        // ---------------------------------------------------------------- resolver ---
+        for (int c = 0; c < nchunks; ++c) {
+            bool ok = WSSDL_ASYNC_WAIT(0, &sh.staged[c % ASYNC_STAGERS], c + 1, 0);
+            if (ok && c >= SWEEP_AHEAD + 1) ok = WSSDL_ASYNC_WAIT(0, &sh.hdone[c & 7], NHELPERS, 1);
+            if (!ok) break;                                         // (only after an abort: nobody else sets `stop`)
+            unsigned long long rem = 0ull;
+            if (lane == 0) { rem = sh.ring[c & 7];  sh.ring[c & 7] = 0ull;  sh.hdone[c & 7] = 0; }   // slots reused by word c + 8
+            unsigned long long w[SWEEP_AHEAD + 1];
+#pragma unroll
+            for (int j = 0; j <= SWEEP_AHEAD; ++j) w[j] = sh.rowbuf[c & (ASYNC_ROW_SLOTS - 1)][j][lane];
+            rem = readlane_u64(rem, 0);
+            const int nv = n - c * 64;
+            const unsigned long long valid = (nv >= 64) ? ~0ull : ((1ull << nv) - 1ull);
+            const unsigned long long cand = ~rem & valid;
+            const unsigned long long t_mine = w[0];
+            unsigned long long kept = cand;
+            for (;;) {
+                const unsigned long long nk = cand & ~__ballot((t_mine & kept) != 0ull);
+                if (nk == kept) break;
+                kept = nk;
+            }
+            if ((kept >> lane) & 1ull) {
+#pragma unroll
+                for (int j = 1; j <= SWEEP_AHEAD; ++j)
+                    if (w[j] != 0ull) atomicOr(&sh.ring[(c + j) & 7], w[j]);
+            }
+            if (lane == 0) {
+                SweepAsyncShared::Publish pr;
+                pr.kept = kept;  pr.base = count;  pr.count = count + __popcll(kept);
+                sh.pub[c & 7] = pr;
+            }
+            count += __popcll(kept);
+            lds_post(&sh.resolved, c + 1);
+            if (count >= max_keep) break;
+        }
+        lds_post(&sh.stop, lds_peek(&sh.resolved));
+    } else if (wave == 1 || wave == 2) {
+        // ----------------------------------------------------------------- scribes ---
+        // turn t (t & 1 == g): column t + 4 to LDS (fetched at turn t - 2), the outputs of chunk t - 3 to memory
+        // (fetched at turn t - 2), chunk t - 1 into the kept list (+ its kept bitmask to the mask role), column t + 6
+        // requested
+        const int g = wave & 1;
+        constexpr int CS_PER_LANE = SWEEP_MAX_CHUNKS / 64;
+        unsigned long long column[CS_PER_LANE];
+        int out_pos = -1, out_idx = 0;
+        float out_box[4] = {0.f, 0.f, 0.f, 0.f};
+        auto fetch_column = [&](int cb) {
+#pragma unroll
+            for (int q = 0; q < CS_PER_LANE; ++q) {
+                const int rb = lane + 64 * q;
+                column[q] = (cb < nchunks && rb <= cb) ? cs[(size_t)cb * ncb + rb] : 0ull;
+            }
+        };
+        auto flush = [&]() {
+            if (out_pos >= 0) {
+                if (keep) keep[(size_t)img * max_keep + out_pos] = out_idx;
+                if (rois_padded) {
+                    float *o = rois_padded + ((size_t)img * max_keep + out_pos) * 5;
+                    o[0] = (float)img; o[1] = out_box[0]; o[2] = out_box[1]; o[3] = out_box[2]; o[4] = out_box[3];
+                }
+            }
+            out_pos = -1;
+        };
+#pragma unroll
+        for (int q = 0; q < CS_PER_LANE; ++q) column[q] = 0ull;
+        // (fused launch: column 5 belongs to segment 0, which the stager of chunk 0 waits for before anything is staged;
+        // scribe 1 fetches it behind its first wait for the resolver, i.e. behind that)
+        for (int t = g;; t += 2) {
+            // chunk t - 1 resolved: it is expanded this turn, and column t (whose slot column t + 4 takes) has been read
+            if (t > 0 && !WSSDL_ASYNC_WAIT(1, &sh.resolved, t, 0)) break;
+            if (t == 1) fetch_column(5);               // the first column the helpers read (index 2: word 5); waited for here, once
+            if (t >= 1) {
+#pragma unroll
+                for (int q = 0; q < CS_PER_LANE; ++q) sh.colsum[(t + 4) & 3][lane + 64 * q] = column[q];
+                lds_post(&sh.colstored[g], t + 5);
+            }
+            flush();
+            if (t > 0) {
+                const int chunk = t - 1;
+                const unsigned long long kept = sh.pub[chunk & 7].kept;
+                const int base = sh.pub[chunk & 7].base;
+                if (A.keptpub && lane == 0) {
+                    // the mask role computes the far column segments of a resolved row block for its kept rows only
+                    // (nms_mask_block_sparse).  Two tagged 8-byte halves, each atomic on its own: no ordering, no wait.
+                    const unsigned long long tag = (unsigned long long)(chunk + 1) << 32;
+                    unsigned long long *kp = A.keptpub + ((size_t)img * ncb + chunk) * 2;
+                    __hip_atomic_store(kp, (kept & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(kp + 1, (kept >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if ((kept >> lane) & 1ull) {
+                    const int row = chunk * 64 + lane;
+                    const int pos = base + __popcll(kept & ((1ull << lane) - 1ull));
+                    if (pos < max_keep) {
+                        kept_rows[pos] = row;
+                        out_pos = pos;
+                        out_idx = row;
+                        if (keep && order) out_idx = order[(size_t)img * order_stride_img + row];
+                        if (rois_padded) {
+                            const float *bx = boxes + (size_t)img * box_stride_img + (size_t)row * 4;
+                            out_box[0] = bx[0]; out_box[1] = bx[1]; out_box[2] = bx[2]; out_box[3] = bx[3];
+                        }
+                    }
+                }
+                lds_post(&sh.expanded[g], t);
+            }
+            if (t >= nchunks) break;                          // the last chunk was this turn's
+            // (fused launch: column t + 6 is complete once the stager of chunk t + 2 has waited for its segments)
+            if (A.segdone && t + 2 < nchunks && !WSSDL_ASYNC_WAIT(1, &sh.staged[(t + 2) % ASYNC_STAGERS], t + 3, 1)) break;
+            fetch_column(t + 6);
+        }
+        flush();
+    } else if (wave >= 3 && wave < 3 + ASYNC_STAGERS) {
+        // ----------------------------------------------------------------- stagers ---
+        // stager s: chunks k = s, s + 3, ...; T and the words k+1..k+4 of chunk k's rows, loaded three chunks before they
+        // are written to the slot k & 3 (free once chunk k - 4 is resolved)
+        const int sidx = wave - 3;
+        unsigned long long rows[SWEEP_AHEAD + 1];
+        int seg_ready = 0;
+        auto load_rows = [&](int chunk) {
+            if (A.segdone && chunk < nchunks) {
+                const int want = min(chunk + SWEEP_AHEAD, nchunks - 1) / MASK_SEG + 1;
+                while (seg_ready < want) {
+                    sweep_wait_segment(A.segdone, MASK_WAVES * min((seg_ready + 1) * MASK_SEG, A.nrb), img * ncb + seg_ready,
+                                       &sh.timed_out, A.wait_ticks);
+                    ++seg_ready;
+                }
+            }
+            const int row = chunk * 64 + lane;
+#pragma unroll
+            for (int j = 0; j <= SWEEP_AHEAD; ++j) rows[j] = 0ull;
+            if (row < n) {
+                rows[0] = dt[row];
+#pragma unroll
+                for (int j = 1; j <= SWEEP_AHEAD; ++j)
+                    if (chunk + j < nchunks) rows[j] = m[(size_t)row * ncb + chunk + j];
+            }
+        };
+        if (sidx < nchunks) load_rows(sidx);
+        for (int k = sidx; k < nchunks; k += ASYNC_STAGERS) {
+            if (k >= ASYNC_ROW_SLOTS && !WSSDL_ASYNC_WAIT(1, &sh.resolved, k - ASYNC_ROW_SLOTS + 1, 0)) break;
+#pragma unroll
+            for (int j = 0; j <= SWEEP_AHEAD; ++j) sh.rowbuf[k & (ASYNC_ROW_SLOTS - 1)][j][lane] = rows[j];
+            lds_post(&sh.staged[sidx], k + 1);
+            if (k + ASYNC_STAGERS < nchunks) load_rows(k + ASYNC_STAGERS);
+        }
+    } else {
+        // ----------------------------------------------------------------- helpers ---
+        // (the batches of gathers live in sixteen fixed registers, v80-v95, that only these asm statements name: see the
+        // barrier version above for why; helper waves issue no other vector memory operation)
+        constexpr int HELPER_SLOTS = 4;
+        constexpr int HELPER_LANES = NHELPERS * 64;
+        static_assert(HELPER_SLOTS * HELPER_LANES >= SWEEP_LH * SWEEP_GROUP, "every list position has a slot");
+#define WSSDL_TAKE(R0, R1, R2, R3, R4, R5, R6, R7)                                                                      \
+    [&]() {                                                                                                             \
+        unsigned lo, hi;                                                                                                \
+        asm volatile("s_waitcnt vmcnt(4)\n\tv_or3_b32 %0, " R0 ", " R2 ", " R4 "\n\tv_or3_b32 %1, " R1 ", " R3 ", " R5       \
+                     "\n\tv_or_b32 %0, %0, " R6 "\n\tv_or_b32 %1, %1, " R7                                              \
+                     : "=&v"(lo), "=&v"(hi)                                                                             \
+                     :                                                                                                  \
+                     : "memory");                                                                                       \
+        return ((unsigned long long)hi << 32) | lo;                                                                     \
+    }
+#define WSSDL_ISSUE(P0, P1, P2, P3, C0, C1, C2, C3, C4, C5, C6, C7)                                                     \
+    [&](int j, const unsigned long long *src) {                                                                         \
+        if (j == 0) asm volatile("global_load_dwordx2 " P0 ", %0, off" : : "v"(src) : "memory", C0, C1);                \
+        else if (j == 1) asm volatile("global_load_dwordx2 " P1 ", %0, off" : : "v"(src) : "memory", C2, C3);           \
+        else if (j == 2) asm volatile("global_load_dwordx2 " P2 ", %0, off" : : "v"(src) : "memory", C4, C5);           \
+        else asm volatile("global_load_dwordx2 " P3 ", %0, off" : : "v"(src) : "memory", C6, C7);                       \
+    }
+        auto take_a = WSSDL_TAKE("v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87");
+        auto take_b = WSSDL_TAKE("v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+        auto issue_a = WSSDL_ISSUE("v[80:81]", "v[82:83]", "v[84:85]", "v[86:87]", "v80", "v81", "v82", "v83", "v84",
+                                   "v85", "v86", "v87");
+        auto issue_b = WSSDL_ISSUE("v[88:89]", "v[90:91]", "v[92:93]", "v[94:95]", "v88", "v89", "v90", "v91", "v92",
+                                   "v93", "v94", "v95");
+#undef WSSDL_TAKE
+#undef WSSDL_ISSUE
+        asm volatile("v_mov_b32 v80, 0\n\tv_mov_b32 v81, 0\n\tv_mov_b32 v82, 0\n\tv_mov_b32 v83, 0\n\tv_mov_b32 v84, 0\n\t"
+                     "v_mov_b32 v85, 0\n\tv_mov_b32 v86, 0\n\tv_mov_b32 v87, 0\n\tv_mov_b32 v88, 0\n\tv_mov_b32 v89, 0\n\t"
+                     "v_mov_b32 v90, 0\n\tv_mov_b32 v91, 0\n\tv_mov_b32 v92, 0\n\tv_mov_b32 v93, 0\n\tv_mov_b32 v94, 0\n\t"
+                     "v_mov_b32 v95, 0" ::: "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89",
+                     "v90", "v91", "v92", "v93", "v94", "v95");
+        const int hw = wave - SWEEP_FIRST_HELPER;
+        int hposl[HELPER_SLOTS], hpos[HELPER_SLOTS];           // 256 consecutive list positions per wave
+#pragma unroll
+        for (int j = 0; j < HELPER_SLOTS; ++j) { hposl[j] = hw * (HELPER_SLOTS * 64) + j * 64 + lane;  hpos[j] = min(hposl[j], max_keep); }
+        auto helper_turn = [&](auto &take, auto &issue, int c) -> bool {
+            // word c + 1: this batch was issued at index c - 2; the one issued at c - 1 may stay in flight
+#ifdef WSSDL_SWEEP_PROFILE
+            const unsigned long long prof_m0 = __builtin_amdgcn_s_memtime();
+#endif
+            const unsigned long long acc = take();
+#ifdef WSSDL_SWEEP_PROFILE
+            prof_site[2] += __builtin_amdgcn_s_memtime() - prof_m0;
+#endif
+            if (acc != 0ull)
+                asm volatile("ds_or_b64 %0, %1" : : "v"((unsigned)(size_t)&sh.ring[(c + 1) & 7]), "v"(acc) : "memory");
+            if (c + 1 >= SWEEP_AHEAD + 1 && c + 1 < nchunks) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(&sh.hdone[(c + 1) & 7], 1);
+            }
+            // word c + 3 of every box kept in chunks <= c - 2 for which the column's summary has a bit
+            int lim = 0;
+            if (c >= 2 && c + 3 < nchunks) {
+                if (!WSSDL_ASYNC_WAIT(1, &sh.expanded[(c - 1) & 1], c - 1, 0)) return false;          // chunk c - 2
+                if (c >= 3 && !WSSDL_ASYNC_WAIT(1, &sh.expanded[c & 1], c - 2, 0)) return false;      // chunk c - 3 (the other scribe)
+                if (!WSSDL_ASYNC_WAIT(1, &sh.colstored[(c - 1) & 1], c + 4, 1)) return false;         // column c + 3
+                lim = min(lds_peek(&sh.pub[(c - 2) & 7].count), max_keep);
+            }
+            const unsigned *colsum_now = reinterpret_cast<const unsigned *>(sh.colsum[(c + 3) & 3]);
+            unsigned row[HELPER_SLOTS], cw[HELPER_SLOTS];
+#pragma unroll
+            for (int j = 0; j < HELPER_SLOTS; ++j) row[j] = (unsigned)kept_rows[hpos[j]];
+#pragma unroll
+            for (int j = 0; j < HELPER_SLOTS; ++j) row[j] = (hposl[j] < lim) ? row[j] : 0u;
+#pragma unroll
+            for (int j = 0; j < HELPER_SLOTS; ++j) cw[j] = colsum_now[row[j] >> 5];
+            const unsigned long long *src[HELPER_SLOTS];
+#pragma unroll
+            for (int j = 0; j < HELPER_SLOTS; ++j) {
+                const unsigned hit = (unsigned)(hposl[j] < lim) & (cw[j] >> (row[j] & 31u)) & 1u;
+                src[j] = hit ? m + (__umul24(row[j], (unsigned)ncb) + (unsigned)(c + 3)) : zero_word;
+            }
+#pragma unroll
+            for (int j = 0; j < HELPER_SLOTS; ++j) issue(j, src[j]);
+            return true;
+        };
+        for (int c = 0; c + 1 < nchunks; ++c) {
+            const bool ok = (c & 1) ? helper_turn(take_b, issue_b, c) : helper_turn(take_a, issue_a, c);
+            if (!ok) break;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (batches still in flight)
+    }
+#ifdef WSSDL_SWEEP_PROFILE
+    if (lane == 0 && img < 64) {
+        unsigned long long *o = wssdl_sweep_prof[img][wave];
+        o[0] = __builtin_amdgcn_s_memtime() - prof_t0;                   // the role's loop, start to end
+        o[1] = prof_site[0];  o[4] = prof_site[1];  o[5] = prof_site[2];
+        o[2] = (unsigned long long)lds_peek(&sh.resolved);
+        o[3] = __builtin_amdgcn_s_memrealtime() - prof_rt0;
+        o[6] = 0xA51C;                                                   // marks the layout of this form
+    }
+#endif
+    __syncthreads();
+    if (tid == 0) {
+        const int resolved = sh.resolved;
+        int total = 0;
+        if (resolved > 0) total = sh.pub[(resolved - 1) & 7].count;
+        num_keep[img] = (sh.timed_out || sh.abort) ? WSSDL_NMS_TIMED_OUT : min(total, max_keep);
+        if (done_out) done_out[img] = (total >= max_keep || n_dev[img] <= n_limit) ? 1 : 0;
+    }
+}
+
 // (amdgpu_num_vgpr(80): the register allocator stays below v80, which the helpers' asm statements own)
+union SweepSharedAny {
+    SweepShared barrier;
+    SweepAsyncShared async;
+};
+
+// (one kernel per form: with both blocks inlined behind a run-time branch the scalar registers of the two spilled to
+// vector lanes -- 233 against 20 -- inside the resolver's loop)
+template <bool ASYNC>
 __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_num_vgpr(80))) void nms_sweep_pipelined_kernel(SweepArgs A) {
     extern __shared__ unsigned long long sweep_dyn[];        // the kept list
-    __shared__ SweepShared sh;
-    nms_sweep_pipelined_block(A, blockIdx.x, reinterpret_cast<int *>(sweep_dyn), sh);
+    __shared__ SweepSharedAny sh;
+    if (ASYNC) nms_sweep_async_block(A, blockIdx.x, reinterpret_cast<int *>(sweep_dyn), sh.async);
+    else nms_sweep_pipelined_block(A, blockIdx.x, reinterpret_cast<int *>(sweep_dyn), sh.barrier);
 }
 
 // Mask and sweep in ONE launch.  The sweep of an image is a single workgroup walking 64-box chunks
@@ -1323,16 +1700,18 @@ struct SegTable {
     int start[MASK_MAX_SEGS + 1];       // start[s] = (row block, segment) pairs of the segments before s
 };
 
+template <bool ASYNC>
 __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_num_vgpr(80))) void nms_mask_sweep_fused_kernel(MaskArgs M, SweepArgs S, int n_images, int nseg, SegTable table,
                                                                             int *ctl, int fault) {
     extern __shared__ unsigned long long sweep_dyn[];
-    __shared__ SweepShared sh;
+    __shared__ SweepSharedAny sh;
     const int ncb = M.ncb;
     if ((int)blockIdx.x < n_images) {
         // the latency-bound role wins every issue arbitration against mask waves that share its CU (round 4: -1.5 % on the
         // fused launch, full walk 0.448 -> 0.441 ms and early stop 0.1643 -> 0.1636, same box, alternating runs)
         __builtin_amdgcn_s_setprio(3);
-        nms_sweep_pipelined_block(S, blockIdx.x, reinterpret_cast<int *>(sweep_dyn), sh);
+        if (ASYNC) nms_sweep_async_block(S, blockIdx.x, reinterpret_cast<int *>(sweep_dyn), sh.async);
+        else nms_sweep_pipelined_block(S, blockIdx.x, reinterpret_cast<int *>(sweep_dyn), sh.barrier);
         if (threadIdx.x == 0)
             __hip_atomic_store(ctl + (size_t)blockIdx.x * ncb + ncb - 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -1368,8 +1747,10 @@ int launch_nms_sweep(const unsigned long long *mask, const unsigned long long *d
     size_t lds = ((size_t)max_keep + 64) * sizeof(int);
     if (nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ)) {
         const SweepArgs S = {mask, diag_t, summ, n_dev, n_max, ncb, max_keep, order, order_stride_img, keep, num_keep,
-                             boxes, box_stride_img, rois_padded, n_limit, done_in, done_out, nullptr, 0, 0ull, nullptr};
-        hipLaunchKernelGGL(nms_sweep_pipelined_kernel, dim3(n_images), dim3(SWEEP_BLOCK), lds, st, S);
+                             boxes, box_stride_img, rois_padded, n_limit, done_in, done_out, nullptr, 0, 0ull, nullptr,
+                             tuning().nms_sweep_async != 0 ? 1 : 0};
+        if (S.async) hipLaunchKernelGGL(nms_sweep_pipelined_kernel<true>, dim3(n_images), dim3(SWEEP_BLOCK), lds, st, S);
+        else hipLaunchKernelGGL(nms_sweep_pipelined_kernel<false>, dim3(n_images), dim3(SWEEP_BLOCK), lds, st, S);
         return check_launch();
     }
     if (lds > SWEEP_LDS_LIMIT) {
@@ -1447,7 +1828,7 @@ static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n
                          // segment counts: the test of the time-out path
                          fault > 0 ? (unsigned long long)fault * 100ull
                                    : (unsigned long long)(tuning().nms_wait_us > 0 ? tuning().nms_wait_us : 50000) * 100ull,
-                         sparse ? keptpub : nullptr};
+                         sparse ? keptpub : nullptr, tuning().nms_sweep_async != 0 ? 1 : 0};
     const size_t lds_mask = (size_t)(SWEEP_BLOCK / 64) * (5 * 64 * sizeof(float) + 64 * sizeof(nms_float4v));
     SegTable table;
     if (nseg > MASK_MAX_SEGS) return WSSDL_ERR_INVALID_ARGUMENT;
@@ -1458,8 +1839,12 @@ static int launch_nms_fused(const float *boxes, int box_stride_img, const int *n
     const long long blocks = n_images + (vblocks + SWEEP_BLOCK / 64 / MASK_WAVES - 1) / (SWEEP_BLOCK / 64 / MASK_WAVES);
     if (blocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
     const size_t lds_sweep = ((size_t)max_keep + 64) * sizeof(int);
-    hipLaunchKernelGGL(nms_mask_sweep_fused_kernel, dim3((unsigned)blocks), dim3(SWEEP_BLOCK),
-                       lds_sweep > lds_mask ? lds_sweep : lds_mask, st, M, S, n_images, nseg, table, segdone, fault);
+    if (S.async)
+        hipLaunchKernelGGL(nms_mask_sweep_fused_kernel<true>, dim3((unsigned)blocks), dim3(SWEEP_BLOCK),
+                           lds_sweep > lds_mask ? lds_sweep : lds_mask, st, M, S, n_images, nseg, table, segdone, fault);
+    else
+        hipLaunchKernelGGL(nms_mask_sweep_fused_kernel<false>, dim3((unsigned)blocks), dim3(SWEEP_BLOCK),
+                           lds_sweep > lds_mask ? lds_sweep : lds_mask, st, M, S, n_images, nseg, table, segdone, fault);
     return check_launch();
 }
 
