@@ -109,14 +109,17 @@ HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300
 WORKLOADS = {
     "resnet50_joint_b8": dict(net="Resnet_train", depth=50, mode="joint", n_sup=4, n_ws=4,
                               im=(600, 1000), baseline_config=2, fixed_rois=True),
+    # (round 6: every workload's roofline leg runs on a COMMITTED set of its own network's proposals when the file
+    # exists -- saved once with --save-fixed-rois -- so that the PMC passes in profiles/hotpath_traffic.json belong to
+    # exactly the launches the line reports; without the file the set is built from this run's network)
     "resnet18_sup_b2": dict(net="Resnet_train_alter", depth=18, mode="sup", n_sup=2, n_ws=0,
-                            im=(600, 1000), baseline_config=1),
+                            im=(600, 1000), baseline_config=1, fixed_rois="roofline_rois_resnet18_sup_b2_r256.npy"),
     "resnet50_alter": dict(net="Resnet_train_alter", depth=50, mode="alter", n_sup=1, n_ws=2,
-                           im=(600, 1000), baseline_config=3),
+                           im=(600, 1000), baseline_config=3, fixed_rois="roofline_rois_resnet50_alter_weak_r4000_large.npy"),
     "resnet101_1600_test": dict(net="Resnet_train", depth=101, mode="test", n_sup=1, n_ws=0,
-                                im=(1000, 1600), baseline_config=4),
+                                im=(1000, 1600), baseline_config=4, fixed_rois="roofline_rois_resnet101_1600_test_r300.npy"),
     "vgg16_joint": dict(net="VGGnet_train", depth=16, mode="joint", n_sup=1, n_ws=2,
-                        im=(600, 1000), baseline_config=0),
+                        im=(600, 1000), baseline_config=0, fixed_rois="roofline_rois_vgg16_joint_r4128.npy"),
 }
 
 
@@ -236,8 +239,11 @@ def fixed_roi_set(wl, net, blobs, weak_step=False):
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import roofline_leg
-    if wl.get("fixed_rois") and os.path.exists(roofline_leg.ROIS_PATH):
+    if wl.get("fixed_rois") is True and os.path.exists(roofline_leg.ROIS_PATH):
         return roofline_leg.load_rois()
+    if isinstance(wl.get("fixed_rois"), str) and os.path.exists(os.path.join(ROOT, "profiles", wl["fixed_rois"])) \
+            and not os.environ.get("WSSDL_BENCH_GENERATE_ROIS"):
+        return roofline_leg.load_rois(os.path.join(ROOT, "profiles", wl["fixed_rois"]))
     import torch
     from wssdl_bus_amd.fast_rcnn.config import cfg
     from wssdl_bus_amd.rpn_msr.proposal_layer_tf_bus import proposal_layer_padded
@@ -280,12 +286,19 @@ def hbm_traffic(kernel_key, meta):
         return None, "no PMC passes committed"
     tj = json.load(open(tpath))
     want = {k: meta[k] for k in ("N", "H", "W", "C", "R", "argmax_bytes", "kernel_source_id")}
-    have = tj.get("launch", {})
-    if any(have.get(k) != v for k, v in want.items()):
-        return None, "stale: profiles/hotpath_traffic.json was taken for %s, this run is %s" % (have, want)
-    # (the bin-owner backward is two kernels, the walk and the halo merge: their bytes add up)
-    keys = {"roi_pool_bwd": ("roi_pool_bwd_walk_kernel", "walk_merge_kernel")}.get(kernel_key, (kernel_key,))
-    hit = [(k, v) for k, v in tj.get("kernels", {}).items() if any(q in k for q in keys)]
+    # one entry per launch shape (round 6: the default workload's at the top level as before, the other workloads' legs
+    # under "legs"); an entry counts when shape, RoI count and kernel sources are this run's
+    entries = [tj] + list(tj.get("legs", []))
+    entry = next((e for e in entries if all(e.get("launch", {}).get(k) == v for k, v in want.items())), None)
+    if entry is None:
+        shapes = [{k: e.get("launch", {}).get(k) for k in ("N", "C", "R", "kernel_source_id")} for e in entries]
+        return None, "stale: profiles/hotpath_traffic.json holds %s, this run is %s" % (shapes, want)
+    # an op of several kernels: their bytes add up (bin-owner backward = walk + halo merge; split backward = walk +
+    # combine; block-table forward = tables + bin-row order + pooling)
+    keys = {"roi_pool_bwd": ("roi_pool_bwd_walk_kernel", "walk_merge_kernel", "walk_combine_kernel"),
+            "roi_pool_fwd": ("roi_pool_fwd_rows_kernel", "roi_pool_fwd_compact_kernel", "roi_pool_fwd_blocks_kernel",
+                             "blocks_build_kernel", "rows_scatter_kernel")}.get(kernel_key, (kernel_key,))
+    hit = [(k, v) for k, v in entry.get("kernels", {}).items() if any(q in k for q in keys)]
     if hit:
         return int(sum(v["hbm_bytes_per_launch"] for _, v in hit)), "profiles/hotpath_traffic.json (%s)" % " + ".join(k for k, _ in hit)
     return None, "kernel not in profiles/hotpath_traffic.json"

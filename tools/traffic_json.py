@@ -43,11 +43,20 @@ for k, cs in acc.items():
     if h is not None and m is not None and h + m > 0:
         res[k]["l2_hit_rate"] = h / (h + m)
 meta = leg.get("meta", {})
-json.dump(dict(source="rocprofv3 --pmc passes (one counter group per run) of `python3 tools/roofline_leg.py --iters 5`",
-               correction="read = 2 x FETCH_SIZE (gfx950), write = WRITE_SIZE",
-               roi_set=leg.get("roi_set"),
-               launch={k: meta.get(k) for k in ("N", "H", "W", "C", "R", "argmax_bytes", "kernel_source_id",
-                                                "backward_plan")},
-               kernels=res),
-          open(out, "w"), indent=1, sort_keys=True)
-print(out, len(res), "kernels")
+entry = dict(source="rocprofv3 --pmc passes (one counter group per run) of `python3 tools/roofline_leg.py --iters 5`",
+             correction="read = 2 x FETCH_SIZE (gfx950), write = WRITE_SIZE",
+             roi_set=leg.get("roi_set"),
+             launch={k: meta.get(k) for k in ("N", "H", "W", "C", "R", "argmax_bytes", "kernel_source_id",
+                                              "backward_plan", "forward_variant", "backward_variant")},
+             kernels=res)
+# `--leg NAME` (5th argument): add / replace this launch shape under "legs" of an existing file instead of rewriting it
+leg_name = sys.argv[4] if len(sys.argv) > 4 else None
+if leg_name and os.path.exists(out):
+    doc = json.load(open(out))
+    entry["leg"] = leg_name
+    legs = [e for e in doc.get("legs", []) if e.get("leg") != leg_name]
+    doc["legs"] = legs + [entry]
+    json.dump(doc, open(out, "w"), indent=1, sort_keys=True)
+else:
+    json.dump(entry, open(out, "w"), indent=1, sort_keys=True)
+print(out, len(res), "kernels", leg_name or "(top level)")
