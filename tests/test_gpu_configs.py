@@ -241,6 +241,54 @@ def test_config4_resnet50_weak_step(torch_cuda, cfg_guard):
     assert abs(float(mil) - want_mil) <= 1e-5 * max(1.0, abs(want_mil))
 
 
+def test_config4_resnet50_supervised_step(torch_cuda, cfg_guard):
+    """configs[3], supervised half of an alternating iteration at ResNet-50 (round 6: both halves now run as real
+    steps): S = 2 supervised images -> R = 128 * S sampled RoIs, C = 1024, the four supervised loss terms.  RoI-pool
+    output on every RoI and its gradient inside the real autograd graph -- the step's own top gradient and a random
+    one -- bit for bit against the oracle (a launch of this size takes the exact walk: the reference's summation
+    order), and the oracle's losses on the step's own head outputs."""
+    torch = torch_cuda
+    cfg = cfg_guard
+    from wssdl_bus_amd import synthetic
+    from wssdl_bus_amd.fast_rcnn.train_bus import supervised_loss
+    from wssdl_bus_amd.networks.factory_bus import get_network
+    from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
+    cfg.SAMPLING_RNG = "device"
+    assert cfg.ROI_POOL_BWD_OWNER == "auto" and not cfg.ROI_POOL_BWD_EXACT
+    torch.manual_seed(5)
+    net = get_network("Resnet_train_alter", 50).cuda().to(memory_format=torch.channels_last)
+    net.train()
+    S = 2
+    blobs = synthetic.make_batch(S, 0, 600, 1000, seed=5)
+    L = net(blobs["data"], blobs["im_info"], blobs["gt_boxes"], blobs["num_gt_boxes"], is_training=True, is_ws=False)
+    feat, rois, top = L["group2/relu"], L["roi-data"][0], L["roi_pool"]
+    R = rois.shape[0]
+    assert tuple(feat.shape) == (S, 38, 63, 1024) and R == 128 * S and tuple(top.shape) == (R, 7, 7, 1024)
+    assert all(int((rois[:, 0] == i).sum()) == 128 for i in range(S))
+    # the forms this launch takes by default: rows kernel forward, exact walk backward
+    assert op.owner_plan(tuple(feat.shape), R) == -1 and op.split_segments(tuple(feat.shape), R) == 1
+    assert op.prepare_backward(tuple(feat.shape), rois, 7, 7, 1.0 / 16).variant.startswith("exact walk")
+    top.retain_grad()
+    losses = supervised_loss(L, net.weight_decay_params())
+    losses["loss"].backward(retain_graph=True)
+    top_diff = top.grad.clone()
+    assert float(top_diff.abs().sum()) > 0
+    grad_fn = _pool_grad_through_autograd(torch, L, "group2/relu", "roi_pool")
+    et, ea = _check_pool_against_oracle(torch, feat.detach().contiguous(), rois, top, "cuda", grad_fn, top_diff)
+    dense = torch.randn(top.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(55))
+    want = c_oracle.roi_pool_backward(_np(dense), ea, _np(rois), tuple(feat.shape), 7, 7, 1.0 / 16)
+    assert np.array_equal(_np(grad_fn(dense)), want)
+    # the four supervised terms (train_bus.py:184-236) from the oracle on this step's own tensors
+    rd = tuple(_np(t) for t in L["roi-data"])
+    rpn_data = tuple(_np(t) for t in L["rpn-data"])
+    want_l = dict(rpn_cross_entropy=O.loss_rpn_cross_entropy(_np(L["rpn_cls_score_reshape"]), rpn_data[0]),
+                  rpn_loss_box=O.loss_rpn_box(_np(L["rpn_bbox_pred"]), rpn_data),
+                  cross_entropy=O.loss_rcnn_cross_entropy(_np(L["cls_score"]), rd[1]),
+                  loss_box=O.loss_rcnn_box(_np(L["bbox_pred"]), rd[2], rd[3], rd[4]))
+    for k, want_v in want_l.items():
+        assert abs(float(losses[k].detach()) - want_v) <= 1e-5 * max(1.0, abs(want_v)), k
+
+
 def test_config1_vgg16_forward(torch_cuda, cfg_guard):
     """configs[0] wiring (VGGnet_train_bus.py:43-101) on the GPU: conv5_3 is 37x62x512; pool_5 with
     the CPU op's rounding against the oracle; the combined layer outputs have the reference's
