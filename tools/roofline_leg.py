@@ -141,6 +141,9 @@ def main():
                          "and the exact walk bit for bit, the bin-owner form at its tolerance; tests/test_gpu_roi_compact.py)")
     ap.add_argument("--rois", default="", metavar="PATH.npy", help="another RoI set (float32 [R,5]) instead of the fixed one")
     ap.add_argument("--map", default="38,63,1024", help="H,W,C of the feature map the set belongs to")
+    ap.add_argument("--i32", action="store_true",
+                    help="the op pair of the reference's contract (f32 top + i32 arg-max, wssdl_roi_pool_forward / _backward_ws) "
+                         "instead of the training path's 1-byte pair")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
                     help="wssdl_set_tuning(KEY, INT) before the run, e.g. roi_fwd_blocks=1 (repeatable)")
     args = ap.parse_args()
@@ -155,6 +158,9 @@ def main():
     if args.roi_bwd_plan >= 0:
         from wssdl_bus_amd import _lib
         _lib.set_tuning("roi_bwd_plan", args.roi_bwd_plan)
+    if args.i32:
+        from wssdl_bus_amd.fast_rcnn.config import cfg
+        cfg.ROI_POOL_COMPACT_ARGMAX = False
     for kv in args.tune:
         from wssdl_bus_amd import _lib
         key, val = kv.split("=")
