@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("tool,cases", [("nms_fuzz.py", 40), ("roi_pool_fuzz.py", 14), ("layers_fuzz.py", 14),
-                                        ("proposal_fuzz.py", 8), ("image_fuzz.py", 10), ("loss_fuzz.py", 8), ("mil_fuzz.py", 30), ("post_detect_fuzz.py", 20), ("sampler_fuzz.py", 10)])
+                                        ("proposal_fuzz.py", 8), ("roi_blocks_fuzz.py", 6), ("image_fuzz.py", 10), ("loss_fuzz.py", 8), ("mil_fuzz.py", 30), ("post_detect_fuzz.py", 20), ("sampler_fuzz.py", 10)])
 def test_random_cases_against_the_oracle(tool, cases):
     # a child process per tool (they parse their own command line); one GPU process at a time
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "--cases", str(cases), "--seed", "424242"],
