@@ -178,7 +178,7 @@ def test_block_table_forward_vs_oracle(torch_cuda, shape, mode):
     for name, f in maps.items():
         et, ea = c_oracle.roi_pool_forward(f, rois, 7, 7, 1.0 / 16, mode, threads=16)
         ft = torch.from_numpy(f).cuda()
-        for sort, pipe in ((1, 1), (0, 1), (1, 2)):           # (sorted bin rows, waves per bin row)
+        for sort, pipe in ((1, 1), (0, 1), (1, 2), (1, 4), (0, 7)):           # (sorted bin rows, waves per bin row)
             with _lib.tuned(roi_fwd_blocks=1, roi_fwd_blocks_sort=sort, roi_fwd_blocks_parts=pipe):
                 _lib.timeline.reset(True)
                 top, arg8 = op.roi_pool_compact(ft, rt, 7, 7, 1.0 / 16, rounding=mode)

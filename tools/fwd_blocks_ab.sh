@@ -27,7 +27,7 @@ for rep in ${REPS:-1 2}; do
     run vgg profiles/roofline_rois_vgg16_joint_r4128.npy 37,62,512 roi_fwd_blocks=$blk || exit 1
   done
 done
-for parts in 1 2; do
+for parts in ${PARTS:-1 2}; do
 run alter_large profiles/roofline_rois_resnet50_alter_weak_r4000_large.npy 38,63,1024 roi_fwd_blocks=1 roi_fwd_blocks_parts=$parts
 run alter profiles/roofline_rois_resnet50_alter_weak_r4000.npy 38,63,1024 roi_fwd_blocks=1 roi_fwd_blocks_parts=$parts
 run vgg profiles/roofline_rois_vgg16_joint_r4128.npy 37,62,512 roi_fwd_blocks=1 roi_fwd_blocks_parts=$parts

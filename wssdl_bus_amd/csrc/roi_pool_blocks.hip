@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void rows_scatter_kernel(const unsigned *__res
 // ----------------------------------------------------------------- pooling ---
 // One wave = one (roi, ph) bin row x 256 channels, windows from the table of roi_windows_kernel (scalar loads), like
 // roi_pool_fwd_rows_kernel<4, 4, 7, false, true>; blockIdx % 8 <-> channel slice as there.
-template <int RPW, int PARTS /* waves that share a bin row: 1 = all 7 bins, 2 = bins 0..3 / 4..6 */>
+template <int RPW, int PARTS /* waves that share a bin row: 1 = all 7 bins, 2 = bins 0..3 / 4..6, 4 = 0..1 / 2..3 / 4..5 / 6, 7 = a bin each */>
 __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_blocks_kernel(
     const float *__restrict__ bottom, int N, int H, int W, int C, int R, float *__restrict__ top,
     unsigned char *__restrict__ arg8, int slices, const unsigned *__restrict__ table,
@@ -226,9 +226,9 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_blocks_kernel(
     }
     const long long widx = (long long)group * RPW + wave;
     if (widx >= (long long)R * 7 * PARTS) return;
-    const long long idx = PARTS == 2 ? widx >> 1 : widx;
-    const int part = PARTS == 2 ? (int)(widx & 1) : 0;
-    const int pw_lo = part == 0 ? 0 : 4, pw_hi = (PARTS == 2 && part == 0) ? 4 : 7;
+    const long long idx = widx / PARTS;
+    const int part = (int)(widx - idx * PARTS);
+    const int pw_lo = (part * 7 + PARTS - 1) / PARTS, pw_hi = ((part + 1) * 7 + PARTS - 1) / PARTS;
     const int item = order ? (int)order[idx] : (int)idx;
     const unsigned *e = table + (size_t)item * WIN_ENTRY_WORDS;
     const int batch = (int)e[0];
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_blocks_kernel(
     };
 #pragma unroll
     for (int pw = 0; pw < 7; ++pw) {
-        if (PARTS == 2 && (pw < pw_lo || pw >= pw_hi)) continue;
+        if (PARTS > 1 && (pw < pw_lo || pw >= pw_hi)) continue;
         const int ws = wss[pw], we = wes[pw], k = ks[pw];
         if (k < 0) {
             res[pw] = (float4v)(0.0f);
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_blocks_kernel(
     // wave's critical path per bin -- stores and loads share the in-order vmcnt counter)
 #pragma unroll
     for (int pw = 0; pw < 7; ++pw) {
-        if (PARTS == 2 && (pw < pw_lo || pw >= pw_hi)) continue;
+        if (PARTS > 1 && (pw < pw_lo || pw >= pw_hi)) continue;
         const size_t o = o_row + (size_t)pw * C;
         __builtin_nontemporal_store(res[pw], reinterpret_cast<float4v *>(top + o));
         __builtin_nontemporal_store(codes[pw], reinterpret_cast<unsigned *>(arg8 + o));
@@ -433,16 +433,19 @@ extern "C" int wssdl_roi_pool_forward_compact_blocks(const float *bottom, int N,
     if (blocks_bytes < L.bytes) return WSSDL_ERR_WORKSPACE;
     // two waves per bin row (bins 0..3 / 4..6): a wave's chain of dependent reads is what a launch of this size waits
     // for -- 0.118 -> 0.109 ms on VGG-16's 1 + 2 batch, 0.207 -> 0.201 on the alternating weak step
-    const int parts = tuning().roi_fwd_blocks_parts == 1 ? 1 : 2;
+    const int tp = tuning().roi_fwd_blocks_parts;
+    const int parts = (tp == 1 || tp == 4 || tp == 7) ? tp : 2;
     const int slices = C / 256, rpw = 4;
     const long long groups = ((long long)R * 7 * parts + rpw - 1) / rpw;
     const long long nblocks = slices >= 8 ? groups * slices : 8 * ((groups + 8 / slices - 1) / (8 / slices));
     if (nblocks > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
     const unsigned *order = tuning().roi_fwd_blocks_sort != 0 ? L.order : nullptr;
-    if (parts == 2)
-        hipLaunchKernelGGL((roi_pool_fwd_blocks_kernel<4, 2>), dim3((unsigned)nblocks), dim3(256), 0, as_stream(stream), bottom,
-                           N, H, W, C, R, top, argmax8, slices, static_cast<const unsigned *>(table), order, L.values, L.codes,
-                           L.flags);
+#define WSSDL_BLOCKS_LAUNCH(P) \
+    hipLaunchKernelGGL((roi_pool_fwd_blocks_kernel<4, P>), dim3((unsigned)nblocks), dim3(256), 0, as_stream(stream), bottom, \
+                       N, H, W, C, R, top, argmax8, slices, static_cast<const unsigned *>(table), order, L.values, L.codes, L.flags)
+    if (parts == 2) WSSDL_BLOCKS_LAUNCH(2);
+    else if (parts == 4) WSSDL_BLOCKS_LAUNCH(4);
+    else if (parts == 7) WSSDL_BLOCKS_LAUNCH(7);
     else
         hipLaunchKernelGGL((roi_pool_fwd_blocks_kernel<4, 1>), dim3((unsigned)nblocks), dim3(256), 0, as_stream(stream), bottom,
                            N, H, W, C, R, top, argmax8, slices, static_cast<const unsigned *>(table), order, L.values, L.codes,
