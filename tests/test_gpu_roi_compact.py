@@ -215,6 +215,18 @@ def test_block_table_forward_on_the_saved_proposal_sets(torch_cuda, which):
     with _lib.tuned(roi_fwd_blocks=0):
         top0, arg80 = op.roi_pool_compact(f, rt, 7, 7, 1.0 / 16)
     assert torch.equal(top, top0) and torch.equal(arg8, arg80)
+    # the padded blob's dead rows (batch index -1, cfg.PADDED_ROIS): zeros and the empty code, like the rows kernel
+    dead = rt.clone()
+    dead[::3, 0] = -1.0
+    dead[1::7] = torch.tensor([-1.0, 0.0, 0.0, 0.0, 0.0], device="cuda")
+    with _lib.tuned(roi_fwd_blocks=1):
+        top_d, arg8_d = op.roi_pool_compact(f, dead, 7, 7, 1.0 / 16)
+    with _lib.tuned(roi_fwd_blocks=0):
+        top_d0, arg8_d0 = op.roi_pool_compact(f, dead, 7, 7, 1.0 / 16)
+    assert torch.equal(top_d, top_d0) and torch.equal(arg8_d, arg8_d0)
+    assert not bool(top_d[::3].any()) and bool((arg8_d[::3] == 255).all())
+    live = (dead[:, 0] >= 0)
+    assert torch.equal(top_d[live], top[live]) and torch.equal(arg8_d[live], arg8[live])
     n = N - 1
     idx = np.nonzero(rois[:, 0] == n)[0]
     sub = rois[idx].copy()

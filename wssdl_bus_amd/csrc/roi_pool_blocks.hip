@@ -229,7 +229,9 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_blocks_kernel(
     const long long idx = widx / PARTS;
     const int part = (int)(widx - idx * PARTS);
     const int pw_lo = (part * 7 + PARTS - 1) / PARTS, pw_hi = ((part + 1) * 7 + PARTS - 1) / PARTS;
-    const int item = order ? (int)order[idx] : (int)idx;
+    // (clamped: an order built on counters that were not cleared -- the calls out of sequence -- must not turn into a read
+    // outside the window table)
+    const int item = order ? (int)min(order[idx], (unsigned)(R * 7 - 1)) : (int)idx;
     const unsigned *e = table + (size_t)item * WIN_ENTRY_WORDS;
     const int batch = (int)e[0];
     const int hs = (int)(e[1] & 0xffu), he = (int)((e[1] >> 8) & 0xffu);
