@@ -35,6 +35,15 @@ if args.build:
     cmd = [b.hipcc()] + b.FLAGS + ["-DWSSDL_SWEEP_PROFILE"] + ["-D" + d for d in args.define] + [os.path.join(b.CSRC, s) for s in b.SOURCES] + ["-o", PROFILE_LIB]
     print(" ".join(cmd))
     subprocess.check_call(cmd)
+    # the helpers' reserved registers (v80-v95) must hold in THIS build too: the stamps add register pressure, and a
+    # build whose allocator went above v79 corrupts in-flight addresses (round 6: such a build ended in a GPU memory
+    # access fault) -- refuse it here, like wssdl_bus_amd.build does for the product
+    from wssdl_bus_amd import isa_check
+    try:
+        isa_check.check_library(PROFILE_LIB)
+    except isa_check.IsaCheckError as e:
+        os.remove(PROFILE_LIB)
+        sys.exit("profile build REFUSED: " + str(e))
     sys.exit(0)
 
 os.environ["WSSDL_BUS_HIP_LIB"] = PROFILE_LIB          # read by wssdl_bus_amd._lib at import
@@ -98,6 +107,9 @@ def report(p, img, head):
         print("    wave %2d %-8s work %6.0f  wait %6.0f cycles per chunk (%.0f %% waiting)   own loads %4.0f per turn; last at the barrier %3.0f %% of the chunks, longest turn %5d (chunk %3d)" % (
             w, ROLES[w], work / max(iters, 1), wait / max(iters, 1), 100.0 * wait / max(work + wait, 1.0), mid / turns,
             100.0 * float(p[img, w, 5]) / max(iters, 1), int(p[img, w, 6]), int(p[img, w, 7])))
+        if ROLES[w] == "helper" and float(p[img, w, 28:32].sum()) > 0:
+            h = [float(v) / max(iters, 1) for v in p[img, w, 28:32]]
+            print("            helper turn by section, cycles per chunk: take + OR %4.0f, list entries %4.0f, summary words %4.0f, addresses + issue %4.0f" % tuple(h))
 
 
 if args.bench:

@@ -1134,6 +1134,11 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
 #ifdef WSSDL_SWEEP_PROFILE
     unsigned long long prof_mid = 0ull;      // helpers: cycles in take() (the wait for the batch); stagers: in the wait for their rows
 #endif
+#ifdef WSSDL_SWEEP_PROFILE_HELPER
+    // (a second macro: with these stamps the register allocator of ROCm 7.2 goes above v79 -- the build is refused by the
+    // ISA check, tools/nms_sweep_profile.py --build --define WSSDL_SWEEP_PROFILE_HELPER -- so they stay out of the profile build)
+    unsigned prof_helper[4] = {0u, 0u, 0u, 0u};      // a helper turn by section (see helper_turn)
+#endif
     auto helper_turn = [&](auto &take, auto &issue, int c) {
         const int lim = (c >= 1 && c + 3 < nchunks) ? min(sh.pub[(c - 1) & 1].base, max_keep) : 0;
         helper_live = helper_live || wave_first < lim;
@@ -1150,6 +1155,10 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
 #endif
         if (acc != 0ull)
             asm volatile("ds_or_b64 %0, %1" : : "v"((unsigned)(size_t)&sh.ring[(c + 1) & 7]), "v"(acc) : "memory");
+#ifdef WSSDL_SWEEP_PROFILE_HELPER
+        const unsigned long long prof_h1 = __builtin_amdgcn_s_memtime();
+        prof_helper[0] += (unsigned)(prof_h1 - prof_m0);          // take + OR into the ring
+#endif
         // issue word c+3 of every box in the kept list (chunks <= c-2) for which the column's summary has a
         // bit (the others are zero, and were not even stored); 32-bit word offsets (n_max * pitch < 2^31
         // checked by the launcher).  (A lane per CHUNK, walking the bits of kept & summary, needs no list -- but
@@ -1161,8 +1170,18 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
         for (int j = 0; j < HELPER_SLOTS; ++j) row[j] = (unsigned)kept_rows[hpos[j]];
 #pragma unroll
         for (int j = 0; j < HELPER_SLOTS; ++j) row[j] = (hposl[j] < lim) ? row[j] : 0u;
+#ifdef WSSDL_SWEEP_PROFILE_HELPER
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long prof_h2 = __builtin_amdgcn_s_memtime();
+        prof_helper[1] += (unsigned)(prof_h2 - prof_h1);          // the list entries (LDS)
+#endif
 #pragma unroll
         for (int j = 0; j < HELPER_SLOTS; ++j) cw[j] = colsum_now[row[j] >> 5];
+#ifdef WSSDL_SWEEP_PROFILE_HELPER
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long prof_h3 = __builtin_amdgcn_s_memtime();
+        prof_helper[2] += (unsigned)(prof_h3 - prof_h2);          // the summary words (LDS, dependent on the entries)
+#endif
         const unsigned long long *src[HELPER_SLOTS];
 #pragma unroll
         for (int j = 0; j < HELPER_SLOTS; ++j) {
@@ -1171,6 +1190,9 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
         }
 #pragma unroll
         for (int j = 0; j < HELPER_SLOTS; ++j) issue(j, src[j]);
+#ifdef WSSDL_SWEEP_PROFILE_HELPER
+        prof_helper[3] += (unsigned)(__builtin_amdgcn_s_memtime() - prof_h3);  // addresses + the four loads issued
+#endif
     };
     int count = 0, last = -1;
 #ifdef WSSDL_SWEEP_PROFILE
@@ -1272,7 +1294,10 @@ __device__ __forceinline__ void nms_sweep_pipelined_block(const SweepArgs &A, in
         unsigned long long *o = wssdl_sweep_prof[img][wave];
         o[0] = prof_work;  o[1] = prof_wait;  o[2] = (unsigned long long)(last + 1);
         o[3] = __builtin_amdgcn_s_memrealtime() - prof_rt0;  o[4] = prof_mid;  o[5] = prof_last;  o[6] = prof_max;  o[7] = prof_maxc;
-        for (int k = 0; k < 24; ++k) o[8 + k] = prof_lds[wave][k];
+        for (int k = 0; k < 20; ++k) o[8 + k] = prof_lds[wave][k];
+#ifdef WSSDL_SWEEP_PROFILE_HELPER
+        for (int k = 0; k < 4; ++k) o[28 + k] = prof_helper[k];
+#endif
     }
 #endif
     if (scribe && last >= 0) {
