@@ -342,7 +342,9 @@ WSSDL_API int wssdl_roi_pool_forward_compact_windows(const float *bottom, int N,
  * `blocks` = wssdl_roi_pool_forward_blocks_bytes() bytes, 256-byte aligned (0: shape not supported -- 7 x 7 bins,
  * C % 256 == 0, H, W in 4..255).  wssdl_roi_pool_forward_blocks_auto = 1 where the library suggests this form for
  * the launch shape ("roi_fwd_blocks": -1 that rule, 0 never, 1 wherever supported; "roi_fwd_blocks_sort" = 0 keeps
- * the bin rows in RoI order). */
+ * the bin rows in RoI order; "roi_fwd_blocks_parts" = 1, 2 (default), 4 or 7 waves per bin row).  The order array is
+ * only as good as the call sequence: built on counters that wssdl_roi_pool_forward_windows_blocks did not clear it is
+ * not a permutation, and rows of `top` stay unwritten (its entries are clamped, so nothing is read out of range). */
 WSSDL_API size_t wssdl_roi_pool_forward_blocks_bytes(int R, int N, int H, int W, int C, int pooled_h, int pooled_w);
 WSSDL_API int wssdl_roi_pool_forward_blocks_auto(int R, int N, int H, int W, int C, int pooled_h, int pooled_w);
 WSSDL_API int wssdl_roi_pool_forward_windows_blocks(const float *rois, int R, int N, int H, int W, int C, int pooled_h,

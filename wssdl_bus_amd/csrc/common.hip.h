@@ -47,7 +47,7 @@ struct Tuning {
     int roi_bwd_owner = -1;     // owner plan id of the bin-owner backward that wssdl_roi_pool_backward_owner_plan suggests (-1: its rule)
     int roi_fwd_variant = 0;    // shape of the compact RoI-pool forward (0: automatic)
     int roi_fwd_blocks = -1;    // block-table forward (roi_pool_blocks.hip): -1 by launch shape, 0 never, 1 wherever supported
-    int roi_fwd_blocks_parts = 0; // its pooling kernel: waves per bin row (1 or 2; 0: by launch size)
+    int roi_fwd_blocks_parts = 0; // its pooling kernel: waves per bin row (1, 2, 4 or 7; anything else = 2, the measured best)
     int roi_fwd_blocks_sort = 1; // 0: its bin rows in RoI order instead of (image, first window row) order
     int roi_bwdc_variant = 0;   // shape of the tile-owner fallback backward
     int roi_bwd_cg = 0;         // channels per workgroup of the fallback backwards (0: automatic)
