@@ -200,7 +200,7 @@ def test_block_table_forward_vs_oracle(torch_cuda, shape, mode):
 def test_block_table_forward_on_the_saved_proposal_sets(torch_cuda, which):
     """Every RoI of the saved proposal sets the block-table forward is meant for (the alternating weak step's and
     VGG-16's own proposals): top and arg-max codes equal to the rows kernel's, which the tests above tie to the oracle,
-    and -- on one image's worth -- to the C oracle directly."""
+    and to the C oracle directly on all of them."""
     torch = torch_cuda
     from wssdl_bus_amd import _lib
     from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
@@ -227,15 +227,19 @@ def test_block_table_forward_on_the_saved_proposal_sets(torch_cuda, which):
     assert not bool(top_d[::3].any()) and bool((arg8_d[::3] == 255).all())
     live = (dead[:, 0] >= 0)
     assert torch.equal(top_d[live], top[live]) and torch.equal(arg8_d[live], arg8[live])
-    n = N - 1
-    idx = np.nonzero(rois[:, 0] == n)[0]
-    sub = rois[idx].copy()
-    sub[:, 0] = 0
-    et, ea = c_oracle.roi_pool_forward(f[n:n + 1].cpu().numpy(), sub, 7, 7, 1.0 / 16, "cuda", threads=16)
-    it = torch.from_numpy(idx).cuda()
-    assert np.array_equal(top[it].cpu().numpy(), et)
-    arg = op.expand_argmax(arg8[it].contiguous(), torch.from_numpy(sub).cuda(), (1, H, W, C), 7, 7, 1.0 / 16)
-    assert np.array_equal(arg.cpu().numpy(), ea)
+    # ... and against the C oracle directly, EVERY RoI of the set (image by image: the oracle's outputs for one image at a time)
+    checked = 0
+    for n in range(N):
+        idx = np.nonzero(rois[:, 0] == n)[0]
+        sub = rois[idx].copy()
+        sub[:, 0] = 0
+        et, ea = c_oracle.roi_pool_forward(f[n:n + 1].cpu().numpy(), sub, 7, 7, 1.0 / 16, "cuda", threads=16)
+        it = torch.from_numpy(idx).cuda()
+        assert np.array_equal(top[it].cpu().numpy(), et), n
+        arg = op.expand_argmax(arg8[it].contiguous(), torch.from_numpy(sub).cuda(), (1, H, W, C), 7, 7, 1.0 / 16)
+        assert np.array_equal(arg.cpu().numpy(), ea), n
+        checked += len(idx)
+    assert checked == len(rois)
 
 
 def _lib_windows_bytes(R, H, W, C):
