@@ -215,6 +215,20 @@ def test_block_table_forward_on_the_saved_proposal_sets(torch_cuda, which):
     with _lib.tuned(roi_fwd_blocks=0):
         top0, arg80 = op.roi_pool_compact(f, rt, 7, 7, 1.0 / 16)
     assert torch.equal(top, top0) and torch.equal(arg8, arg80)
+    # the switch of the host layer: 'auto' = the library's rule by launch shape (all three sets qualify), False = never
+    from wssdl_bus_amd.fast_rcnn.config import cfg
+    assert cfg.ROI_POOL_FWD_BLOCKS == "auto" and _lib.lib().wssdl_roi_pool_forward_blocks_auto(len(rois), N, H, W, C, 7, 7) == 1
+    for setting, expect in (("auto", True), (False, False), (True, True)):
+        cfg.ROI_POOL_FWD_BLOCKS = setting
+        try:
+            _lib.timeline.reset(True)
+            t2, a2 = op.roi_pool_compact(f, rt, 7, 7, 1.0 / 16)
+            torch.cuda.synchronize()
+            assert ("roi_pool_forward_blocks_prepare" in _lib.timeline.summary()) == expect, setting
+            assert torch.equal(t2, top) and torch.equal(a2, arg8)
+        finally:
+            _lib.timeline.reset(False)
+            cfg.ROI_POOL_FWD_BLOCKS = "auto"
     # the padded blob's dead rows (batch index -1, cfg.PADDED_ROIS): zeros and the empty code, like the rows kernel
     dead = rt.clone()
     dead[::3, 0] = -1.0

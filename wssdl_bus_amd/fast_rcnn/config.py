@@ -109,6 +109,12 @@ __C.ROI_POOL_FLAG_CHECK = "deferred"
 # index -1) and nothing between the backbone and the loss copies to the host: the hot path can be
 # captured in a hipGraph.  The per-RoI head then runs on the padded row count (batch-norm masked to the
 # live rows).  False (default): the blob is compacted, which costs one read-back of N counts per step.
+# RoI-pool forward of the training path on launches with many proposals per image (round 6): 'auto' = the library's
+# rule (wssdl_roi_pool_forward_blocks_auto: R >= 2048 and R >= 1200 x images -- the alternating weak step, the
+# reference's default 1 + 2 batch) -> block-maximum tables of the step's feature map + bin rows walked in (image, first
+# window row) order, 1.6-1.8 x faster there, the same bits; True = wherever the shape is supported, False = never (the
+# rows kernel).  The tables are 3.75 x the feature map, allocated per call.
+__C.ROI_POOL_FWD_BLOCKS = 'auto'
 # RoI-pool backward of the training path on launches with few images (<= 4) and many RoIs per image (>= 1000):
 # 'auto' = the library's rule (wssdl_roi_pool_backward_split_segments: 4 segments there, the exact walk
 # everywhere else), an int = that many segments, 0 = always the exact walk.  The split form is deterministic but

@@ -244,8 +244,11 @@ def roi_pool_compact(data, rois, pooled_height, pooled_width, spatial_scale, rou
             table = torch.empty((nwin,), dtype=torch.uint8, device=data.device)
             # many proposals per image (large, overlapping windows): block-maximum tables of this step's feature map,
             # four table reads per bin instead of a scan of its cells (csrc/roi_pool_blocks.hip; same bits)
+            want_blocks = cfg.get("ROI_POOL_FWD_BLOCKS", "auto")
+            if want_blocks == "auto":
+                want_blocks = L.wssdl_roi_pool_forward_blocks_auto(R, N, H, W, C, int(pooled_height), int(pooled_width))
             nblk = L.wssdl_roi_pool_forward_blocks_bytes(R, N, H, W, C, int(pooled_height), int(pooled_width)) \
-                if L.wssdl_roi_pool_forward_blocks_auto(R, N, H, W, C, int(pooled_height), int(pooled_width)) else 0
+                if want_blocks else 0
             if nblk:
                 blocks = torch.empty((nblk,), dtype=torch.uint8, device=data.device)
                 with _lib.timed("roi_pool_forward_windows", dict(R=R)):
