@@ -163,12 +163,24 @@ def test_padded_step_has_no_host_sync_and_matches_compact_losses(torch_cuda, cfg
     assert torch.equal(live, compact[compact[:, 0] >= 1])
 
 
-def test_hot_path_chain_is_graph_capturable(torch_cuda, cfg_guard):
+@pytest.mark.parametrize("fwd_blocks", [0, 1])
+def test_hot_path_chain_is_graph_capturable(torch_cuda, cfg_guard, fwd_blocks):
     """proposal layer -> padded blob -> proposal targets (device sampling) -> RoI pool forward ->
     backward prepare -> RoI pool backward, captured into ONE hipGraph and replayed: identical
-    outputs to the eager calls (include/wssdl_bus_hip.h promises capturable entry points)."""
+    outputs to the eager calls (include/wssdl_bus_hip.h promises capturable entry points).
+    fwd_blocks = 1: the forward takes the block-table form (round 6: tables + bin-row order + pooling, no memset,
+    no host step), same outputs."""
     torch = torch_cuda
     cfg = cfg_guard
+    from wssdl_bus_amd import _lib
+    _lib.set_tuning("roi_fwd_blocks", fwd_blocks)
+    try:
+        _hot_path_chain_capture(torch, cfg, fwd_blocks)
+    finally:
+        _lib.set_tuning("roi_fwd_blocks", -1)
+
+
+def _hot_path_chain_capture(torch, cfg, fwd_blocks):
     from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op as op
     from wssdl_bus_amd.rpn_msr import proposal_target_layer_tf_bus as ptl
     from wssdl_bus_amd.rpn_msr.proposal_layer_tf_bus import proposal_layer
@@ -210,6 +222,13 @@ def test_hot_path_chain_is_graph_capturable(torch_cuda, cfg_guard):
     for a, b in zip(eager, captured):
         assert torch.equal(a, b)
     assert tuple(captured[0].shape) == (128 + 2000, 5)
+    if fwd_blocks:
+        from wssdl_bus_amd import _lib
+        _lib.timeline.reset(True)
+        chain()
+        torch.cuda.synchronize()
+        assert "roi_pool_forward_blocks_prepare" in _lib.timeline.summary()
+        _lib.timeline.reset(False)
 
 
 @pytest.mark.parametrize("C,per,relu", [(2048, 16, True), (512, 49, True), (1024, 49, False), (64, 16, True)])
