@@ -430,6 +430,21 @@ WSSDL_API int wssdl_roi_pool_backward_compact_owner(const float *top_diff, const
                             int pooled_w, float spatial_scale, int rounding, float *bottom_diff,
                             void *workspace, size_t workspace_bytes, int owner_plan,
                             void *scratch, size_t scratch_bytes, wssdl_stream_t stream);
+/* The owner form with SEGMENTS (round 6), for launches with few (image, channel) pairs -- the alternating weak step's two
+ * images, the reference's default 1 + 2 batch -- where one wave per (image, tile, 128 channels) leaves most of the chip
+ * waiting for the longest streams: a tile's stream is cut into `segments` pieces walked by a wave each, every piece into
+ * a region buffer of its own ([segments][N * tiles][region cells][C] f32 = ..._owner_split_scratch_bytes), and a merge
+ * pass writes bottom_diff = the sum over segments of own cells + neighbours' halos, in a fixed order.  Same lists
+ * (wssdl_roi_pool_backward_owner_prepare), deterministic, the owner form's tolerance (every (bin, cell) pair applied
+ * exactly once).  wssdl_roi_pool_backward_owner_segments suggests the count by launch shape (1 = the plain owner form);
+ * "roi_bwd_owner_segments" overrides it. */
+WSSDL_API int wssdl_roi_pool_backward_owner_segments(int R, int N, int H, int W, int C);
+WSSDL_API size_t wssdl_roi_pool_backward_owner_split_scratch_bytes(int N, int H, int W, int C, int owner_plan, int segments);
+WSSDL_API int wssdl_roi_pool_backward_compact_owner_split(const float *top_diff, const uint8_t *argmax8,
+                            const float *rois, int R, int N, int H, int W, int C, int pooled_h,
+                            int pooled_w, float spatial_scale, int rounding, float *bottom_diff,
+                            void *workspace, size_t workspace_bytes, int owner_plan, int segments,
+                            void *scratch, size_t scratch_bytes, wssdl_stream_t stream);
 /* The bin-owner form reading the reference op's OWN arg-max layout (i32 flat index, roi_pooling_op_gpu.cu.cc:71-79): list
  * building + walk + halo merge in one call, owner plans 0 and 1.  Opt-in: RoiPoolGrad's declared contract
  * (wssdl_roi_pool_backward / _ws) stays the exact walk, bit for bit; this one is deterministic within the owner form's

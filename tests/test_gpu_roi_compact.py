@@ -508,6 +508,21 @@ def test_owner_walk_vs_oracle(torch_cuda, shape, mode):
         assert np.all(np.abs(a - want_r) <= 1e-6 * mag + 1e-30), (shape, mode, owner)
         assert np.abs(a - want_r).max() <= 1e-5 * scale, (shape, mode, owner)
         assert not op.flags_raised()
+        # the same lists walked by several waves per tile stream (round 6, ..._compact_owner_split): every (bin, cell) pair
+        # still applied exactly once, every region cell of every segment written, the merge pass sums them in a fixed order
+        if C % 4 == 0:
+            for nseg in ((2, 3) if owner in (0, 8, 9) else (2,)):
+                plan.owner_segments = nseg
+                got = op.roi_pool_grad_compact(shape, rt, arg8, it, 7, 7, 1.0 / 16, rounding=mode, plan=plan).cpu().numpy()
+                assert np.array_equal(got, want_i), (shape, mode, owner, nseg, int((got != want_i).sum()))
+                a = op.roi_pool_grad_compact(shape, rt, arg8, rl, 7, 7, 1.0 / 16, rounding=mode, plan=plan)
+                b = op.roi_pool_grad_compact(shape, rt, arg8, rl, 7, 7, 1.0 / 16, rounding=mode, plan=plan)
+                assert torch.equal(a, b), (shape, mode, owner, nseg)
+                a = a.cpu().numpy()
+                assert np.all(np.abs(a - want_r) <= 1e-6 * mag + 1e-30), (shape, mode, owner, nseg)
+                assert np.abs(a - want_r).max() <= 1e-5 * scale, (shape, mode, owner, nseg)
+            plan.owner_segments = 1
+            assert not op.flags_raised()
 
 
 @pytest.mark.parametrize("shape", [(3, 38, 63, 1024), (2, 25, 40, 256)])
@@ -600,9 +615,16 @@ def test_owner_rule_and_autograd(torch_cuda):
     assert L.wssdl_roi_pool_backward_owner_plan(8512, 8, 38, 63, 1024) == 8      # the default workload
     assert L.wssdl_roi_pool_backward_owner_plan(4000, 2, 38, 63, 1024) == 8      # alternating weak step
     assert L.wssdl_roi_pool_backward_owner_plan(4128, 3, 38, 63, 1024) == 8      # the reference's default 1 + 2 batch
-    assert L.wssdl_roi_pool_backward_owner_plan(4128, 3, 37, 62, 512) == -1      # VGG-16 (1536 pairs): the split form
-    assert L.wssdl_roi_pool_backward_owner_plan(2000, 1, 38, 63, 1024) == -1
-    assert L.wssdl_roi_pool_backward_owner_plan(4000, 2, 38, 63, 256) == -1      # ResNet-18: the split form
+    # round 6: from 512 to 2047 (image, channel) pairs the owner form with TWO waves per tile stream
+    assert L.wssdl_roi_pool_backward_owner_plan(4128, 3, 37, 62, 512) == 8       # VGG-16 (1536 pairs)
+    assert L.wssdl_roi_pool_backward_owner_plan(2000, 1, 38, 63, 1024) == 8      # one weak image x 1024
+    assert L.wssdl_roi_pool_backward_owner_plan(4000, 2, 38, 63, 256) == 9       # ResNet-18's weak step (512 pairs)
+    assert L.wssdl_roi_pool_backward_owner_plan(2000, 1, 38, 63, 256) == -1      # 256 pairs: the split form
+    assert L.wssdl_roi_pool_backward_owner_segments(4128, 3, 37, 62, 512) == 2
+    assert L.wssdl_roi_pool_backward_owner_segments(4000, 2, 38, 63, 256) == 2
+    assert L.wssdl_roi_pool_backward_owner_segments(4000, 2, 38, 63, 1024) == 1  # 2048 pairs and more: one wave per stream
+    assert L.wssdl_roi_pool_backward_owner_segments(8512, 8, 38, 63, 1024) == 1
+    assert L.wssdl_roi_pool_backward_owner_split_scratch_bytes(3, 37, 62, 512, 8, 2) == 2 * 3 * 10 * 13 * 6 * 7 * 512 * 4
     assert L.wssdl_roi_pool_backward_owner_plan(1024, 8, 38, 63, 1024) == -1     # supervised-only step: the exact walk
     assert L.wssdl_roi_pool_backward_owner_plan(300, 1, 63, 100, 1024) == -1
     assert L.wssdl_roi_pool_backward_owner_plan(8512, 8, 38, 63, 96) == -1       # C % 128 != 0

@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--owner", default="", help="owner plans (bin-owner form, wssdl_roi_pool_backward_compact_owner) to time "
                     "after the exact plans, e.g. 0,1,4: checked against plan 11 by the largest difference relative to "
                     "max |bottom_diff| and for repeatability")
+    ap.add_argument("--owner-segments", default="1", help="waves per tile stream of the owner plans to time, e.g. 1,2,4 "
+                    "(round 6: wssdl_roi_pool_backward_compact_owner_split)")
     ap.add_argument("--one-owner", default="", help="like --one for an owner plan (the form to put under rocprofv3 --pmc)")
     ap.add_argument("--dup", type=int, default=1, help="repeat the set's images DUP times as further images (N x DUP images, "
                     "R x DUP RoIs): time(DUP = 2) - time(DUP = 1) is the bulk rate without the launch's ramp and tail")
@@ -172,7 +174,9 @@ def main():
                                   moved_TBps=round(mb / ms / 1e9, 3), frac_moved=round(mb / ms / 1e9 / 8.0, 3))), flush=True)
             assert repeatable and (same if seg == 1 else rel <= 1e-5), (p, seg)
     for o in (int(x) for x in args.owner.split(",") if x != ""):
+      for oseg in (int(x) for x in args.owner_segments.split(",") if x != ""):
         plan = op.roi_pool_grad_prepare_owner(shape, rois, 7, 7, 1.0 / 16, o)
+        plan.owner_segments = oseg
         ms_prep = timeit(lambda: op.roi_pool_grad_prepare_owner(shape, rois, 7, 7, 1.0 / 16, o), 10)
         got = op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan)
         rel = float((got - ref).abs().max()) / scale
@@ -180,10 +184,10 @@ def main():
         repeatable = bool(torch.equal(got, again))
         del got, again
         ms = timeit(lambda: op.roi_pool_grad_compact(shape, rois, arg8, diff, 7, 7, 1.0 / 16, plan=plan), args.iters)
-        print(json.dumps(dict(owner=o, walk_plus_merge_ms=round(ms, 4), prepare_ms=round(ms_prep, 4),
+        print(json.dumps(dict(owner=o, owner_segments=oseg, walk_plus_merge_ms=round(ms, 4), prepare_ms=round(ms_prep, 4),
                               max_diff_over_max_abs=rel, repeatable=repeatable,
                               moved_TBps=round(mb / ms / 1e9, 3), frac_moved=round(mb / ms / 1e9 / 8.0, 3))), flush=True)
-        assert repeatable and rel <= 1e-5, o
+        assert repeatable and rel <= 1e-5, (o, oseg)
     assert not op.flags_raised()
 
 

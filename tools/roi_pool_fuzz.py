@@ -76,6 +76,7 @@ for k in range(args.cases):
                 it = torch.from_numpy(ints).cuda()
                 for o in rs.choice(n_own, size=2, replace=False):
                     plan = op.roi_pool_grad_prepare_owner(f.shape, rt, ph, pw, 1.0 / 16, int(o), rounding=mode)
+                    plan.owner_segments = int(rs.randint(1, 5))          # round 6: 1-4 waves per tile stream
                     gi = op.roi_pool_grad_compact(f.shape, rt, arg8, it, ph, pw, 1.0 / 16, rounding=mode, plan=plan)
                     ga = op.roi_pool_grad_compact(f.shape, rt, arg8, dt, ph, pw, 1.0 / 16, rounding=mode, plan=plan)
                     gb = op.roi_pool_grad_compact(f.shape, rt, arg8, dt, ph, pw, 1.0 / 16, rounding=mode, plan=plan)

@@ -84,6 +84,9 @@ SYMBOLS = {
     "wssdl_roi_pool_backward_owner_prepare": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _i, _vp]),
     "wssdl_roi_pool_backward_compact_owner": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _i,
                                                    _vp, _sz, _vp]),
+    "wssdl_roi_pool_backward_owner_segments": (_i, [_i, _i, _i, _i, _i]),
+    "wssdl_roi_pool_backward_owner_split_scratch_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "wssdl_roi_pool_backward_compact_owner_split": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _i, _i, _vp, _sz, _vp]),
     "wssdl_roi_pool_backward_owner_i32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _sz, _i, _vp, _sz, _vp]),
     "wssdl_roi_argmax_expand": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "wssdl_image_prep_workspace_bytes": (_sz, []),

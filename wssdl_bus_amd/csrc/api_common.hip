@@ -18,6 +18,7 @@ static int *tuning_field(const char *key) {
     Tuning &t = g_tuning;
     if (!strcmp(key, "roi_bwd_plan")) return &t.roi_bwd_plan;
     if (!strcmp(key, "roi_bwd_owner")) return &t.roi_bwd_owner;
+    if (!strcmp(key, "roi_bwd_owner_segments")) return &t.roi_bwd_owner_segments;
     if (!strcmp(key, "roi_fwd_variant")) return &t.roi_fwd_variant;
     if (!strcmp(key, "roi_fwd_blocks")) return &t.roi_fwd_blocks;
     if (!strcmp(key, "roi_fwd_blocks_sort")) return &t.roi_fwd_blocks_sort;

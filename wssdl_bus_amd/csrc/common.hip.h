@@ -45,6 +45,7 @@ inline int load_base_anchors(const double *host, int A, BaseAnchors *out) {
 struct Tuning {
     int roi_bwd_plan = -1;      // plan id of the list-driven RoI-pool backward (-1: by launch size)
     int roi_bwd_owner = -1;     // owner plan id of the bin-owner backward that wssdl_roi_pool_backward_owner_plan suggests (-1: its rule)
+    int roi_bwd_owner_segments = 0; // segments of the bin-owner backward that wssdl_roi_pool_backward_owner_segments suggests (0: its rule)
     int roi_fwd_variant = 0;    // shape of the compact RoI-pool forward (0: automatic)
     int roi_fwd_blocks = -1;    // block-table forward (roi_pool_blocks.hip): -1 by launch shape, 0 never, 1 wherever supported
     int roi_fwd_blocks_parts = 0; // its pooling kernel: waves per bin row (1, 2, 4 or 7; anything else = 2, the measured best)

@@ -128,11 +128,13 @@ int walk_split_segments(int R, int N, int H, int W, int C);
 int owner_plan_count();
 int owner_plan_auto(int R, int N, int H, int W, int C);
 bool owner_supported(int R, int N, int H, int W, int C, int PH, int PW);
-size_t owner_scratch_bytes(int N, int H, int W, int C, int plan);
+size_t owner_scratch_bytes(int N, int H, int W, int C, int plan, int nseg = 1);
+int owner_split_segments(int R, int N, int H, int W, int C);
 int owner_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, int PW, float scale, int rounding,
                   void *workspace, size_t workspace_bytes, int plan, hipStream_t st);
 int launch_owner(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH, int PW,
                  float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, float *halo, hipStream_t st,
-                 bool i32 = false /* arg8 points at the i32 arg-max (owner plans 0 and 1) */);
+                 bool i32 = false /* arg8 points at the i32 arg-max (owner plans 0 and 1) */,
+                 int nseg = 1 /* > 1: a tile's stream walked by nseg waves, halo = nseg region buffers (round 6) */);
 
 }  // namespace wssdl

@@ -1021,6 +1021,34 @@ extern "C" int wssdl_roi_pool_backward_compact_owner(const float *top_diff, cons
                         owner_plan, static_cast<float *>(scratch), as_stream(stream));
 }
 
+extern "C" int wssdl_roi_pool_backward_owner_segments(int R, int N, int H, int W, int C) {
+    return owner_split_segments(R, N, H, W, C);
+}
+
+extern "C" size_t wssdl_roi_pool_backward_owner_split_scratch_bytes(int N, int H, int W, int C, int owner_plan, int segments) {
+    return owner_scratch_bytes(N, H, W, C, owner_plan, segments);
+}
+
+extern "C" int wssdl_roi_pool_backward_compact_owner_split(const float *top_diff, const uint8_t *argmax8, const float *rois,
+                                                           int R, int N, int H, int W, int C, int pooled_h, int pooled_w,
+                                                           float spatial_scale, int rounding, float *bottom_diff,
+                                                           void *workspace, size_t workspace_bytes, int owner_plan,
+                                                           int segments, void *scratch, size_t scratch_bytes,
+                                                           wssdl_stream_t stream) {
+    if (N < 0 || R < 0 || !compact_supported(H, W, C, pooled_h, pooled_w)) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (rounding != WSSDL_ROI_ROUND_CUDA && rounding != WSSDL_ROI_ROUND_CPU) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (N == 0) return WSSDL_OK;
+    if (!bottom_diff || (R > 0 && (!top_diff || !argmax8 || !rois))) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (!workspace || !owner_supported(R, N, H, W, C, pooled_h, pooled_w) || segments < 1) return WSSDL_ERR_INVALID_ARGUMENT;
+    const size_t need = owner_scratch_bytes(N, H, W, C, owner_plan, segments);
+    if (need == 0) return WSSDL_ERR_INVALID_ARGUMENT;
+    if (!scratch || scratch_bytes < need || (reinterpret_cast<uintptr_t>(scratch) & 15) ||
+        (reinterpret_cast<uintptr_t>(bottom_diff) & 15))
+        return WSSDL_ERR_WORKSPACE;
+    return launch_owner(top_diff, argmax8, R, N, H, W, C, pooled_h, pooled_w, bottom_diff, workspace, workspace_bytes,
+                        owner_plan, static_cast<float *>(scratch), as_stream(stream), false, segments);
+}
+
 extern "C" int wssdl_roi_pool_backward_owner_i32(const float *top_diff, const int32_t *argmax, const float *rois, int R, int N,
                                                  int H, int W, int C, int pooled_h, int pooled_w, float spatial_scale,
                                                  float *bottom_diff, void *workspace, size_t workspace_bytes, int owner_plan,

@@ -691,13 +691,18 @@ __global__ __launch_bounds__(64, MINW) void roi_pool_bwd_walk_kernel(
     if (lane_ok) {
         float *img = ((OWN || seg == 0) ? bottom_diff : partial + (size_t)(seg - 1) * seg_stride) +
                      (size_t)n * H * W * C;
-        float *halo = OWN ? partial + (size_t)item * (TH * TW) * C : nullptr;
+        // OWN with segments (round 6, wssdl_roi_pool_backward_compact_owner_split): a tile's stream is cut into nseg
+        // pieces as in the split form, each walked by a wave of its own into a region of its own; EVERY cell of the
+        // region then goes to the segment's slice of the halo buffer, [seg][item][region cell][C], and
+        // walk_merge_split_kernel writes bottom_diff = sum over segments of (own cells + the neighbours' halos).
+        float *halo = OWN ? partial + ((size_t)seg * items + item) * (TH * TW) * C : nullptr;
+        const bool all_to_halo = OWN && nseg > 1;
 #pragma unroll
         for (int i = 0; i < TH * TW; ++i) {
             const int h = h0 + i / TW, w = w0 + i % TW;
             if (h < H && w < W) {
                 float *dst = img + ((size_t)h * W + w) * C + c0;
-                if (OWN && (i / TW >= own_sh || i % TW >= own_sw)) dst = halo + (size_t)i * C + c0;
+                if (OWN && (all_to_halo || i / TW >= own_sh || i % TW >= own_sw)) dst = halo + (size_t)i * C + c0;
                 if (CPL == 2) {
                     float2v o;
                     o.x = acc[(i * CPL) * 64 + lane];
@@ -752,6 +757,44 @@ __global__ __launch_bounds__(256) void walk_merge_kernel(float *__restrict__ bot
             v.x = v.x + a.x;  v.y = v.y + a.y;  v.z = v.z + a.z;  v.w = v.w + a.w;
         }
         out[((size_t)h * W + w) * C4 + c] = v;
+    }
+}
+
+// bin-owner form with segments: bottom_diff (written whole, no read) = for every cell, over the segments in order: the
+// owning tile's region cell + the left, upper and upper-left neighbours' halo cells.  One thread = 4 channels of a cell.
+__global__ __launch_bounds__(256) void walk_merge_split_kernel(float *__restrict__ bottom_diff, const float *__restrict__ halo,
+                                                                int N, int H, int W, int C4, int tiles_h, int tiles_w, int RH,
+                                                                int RW, int SH, int SW, int nseg) {
+    const int HH = RH - SH, HW = RW - SW;
+    const int tiles = tiles_h * tiles_w, items = N * tiles;
+    const long long cell = blockIdx.x;                           // (image, h, w)
+    const int n = (int)(cell / ((long long)H * W)), hw = (int)(cell - (long long)n * H * W);
+    const int h = hw / W, w = hw - h * W;
+    const int ty = h / SH, tx = w / SW, lh = h - ty * SH, lw = w - tx * SW;
+    const int item = n * tiles + ty * tiles_w + tx;
+    const size_t reg = (size_t)RH * RW * C4;
+    const float4v *hb = reinterpret_cast<const float4v *>(halo);
+    const bool left = lw < HW && tx > 0, up = lh < HH && ty > 0;
+    for (int c = threadIdx.x; c < C4; c += 256) {
+        float4v v = (float4v)(0.0f);
+        for (int s = 0; s < nseg; ++s) {
+            const float4v *hs = hb + (size_t)s * items * reg;
+            const float4v o = hs[(size_t)item * reg + (size_t)(lh * RW + lw) * C4 + c];
+            v.x = v.x + o.x;  v.y = v.y + o.y;  v.z = v.z + o.z;  v.w = v.w + o.w;
+            if (left) {
+                const float4v a = hs[(size_t)(item - 1) * reg + (size_t)(lh * RW + lw + SW) * C4 + c];
+                v.x = v.x + a.x;  v.y = v.y + a.y;  v.z = v.z + a.z;  v.w = v.w + a.w;
+            }
+            if (up) {
+                const float4v a = hs[(size_t)(item - tiles_w) * reg + (size_t)((lh + SH) * RW + lw) * C4 + c];
+                v.x = v.x + a.x;  v.y = v.y + a.y;  v.z = v.z + a.z;  v.w = v.w + a.w;
+            }
+            if (left && up) {
+                const float4v a = hs[(size_t)(item - tiles_w - 1) * reg + (size_t)((lh + SH) * RW + lw + SW) * C4 + c];
+                v.x = v.x + a.x;  v.y = v.y + a.y;  v.z = v.z + a.z;  v.w = v.w + a.w;
+            }
+        }
+        reinterpret_cast<float4v *>(bottom_diff)[((size_t)n * H * W + hw) * C4 + c] = v;
     }
 }
 
@@ -1068,18 +1111,36 @@ int owner_plan_auto(int R, int N, int H, int W, int C) {
     // loses a little (0.257 against 0.245) and the plain 4x4-tile plan 1 a lot in the bench's leg (0.40 against 0.28): windows of
     // 4-5 cells do not fit a 6x6 region and are listed in chains.  From 2048 pairs on plan 8 (6x7 regions, lean decode) wins on
     // every set measured, large proposals included: alternating weak step 0.288 -> 0.223 on 21 x 17-cell RoIs.)
-    if (R < 1536 || N < 1 || (C & 127) || pairs < 2048) return -1;
-    return 8;
+    // Round 6: below 2048 pairs the owner form runs with TWO waves per tile stream (owner_split_segments) and then beats the
+    // split form it used to lose to or tie with (profiles/r06_owner_split_ab.log; owner 8 / 9 x 2 segments against split
+    // plan 7 x 8 segments): VGG-16's own proposals 0.199 against 0.265 ms, 3 x 512 / 1 x 1024 / 2 x 512 / 4 x 256 on the
+    // default set's small RoIs 0.150 / 0.131 / 0.135 / 0.135 against 0.207 / 0.182 / 0.181 / 0.183, 2 x 256 and 1 x 512
+    // 0.086 / 0.085 (plan 9) against 0.103 / 0.102.  Below 512 pairs nothing was measured: the split form / exact walk stay.
+    if (R < 1536 || N < 1 || (C & 127) || pairs < 512) return -1;
+    return pairs >= 1024 ? 8 : 9;
 }
 
 bool owner_supported(int R, int N, int H, int W, int C, int PH, int PW) {
     return walk_supported(R, N, H, W, C, PH, PW) && (C & 3) == 0;
 }
 
-size_t owner_scratch_bytes(int N, int H, int W, int C, int plan) {
-    if (plan < 0 || plan >= OWNER_PLANS || N < 1 || H < 1 || W < 1 || C < 1) return 0;
+size_t owner_scratch_bytes(int N, int H, int W, int C, int plan, int nseg) {
+    if (plan < 0 || plan >= OWNER_PLANS || N < 1 || H < 1 || W < 1 || C < 1 || nseg < 1 || nseg > WALK_MAX_SEGMENTS) return 0;
     const OwnerPlan &p = kOwnerPlans[plan];
-    return (size_t)N * cdiv(H, p.sh) * cdiv(W, p.sw) * p.rh * p.rw * (size_t)C * sizeof(float);
+    return (size_t)nseg * N * cdiv(H, p.sh) * cdiv(W, p.sw) * p.rh * p.rw * (size_t)C * sizeof(float);
+}
+
+// How many segments the owner form cuts a tile's stream into (1: the plain owner form).  The owner walk is one wave per
+// (image, tile, 128 channels): 2 images x 1024 channels are 2080 waves of very unequal length on 1024 SIMDs, 3 x 512
+// are 1560 -- such launches wait for their longest chains, and several waves per stream shorten them; what it costs is
+// a region buffer per segment and a merge pass over all of it.  Measured: profiles/r06_owner_split_ab.log.
+int owner_split_segments(int R, int N, int H, int W, int C) {
+    const int v = tuning().roi_bwd_owner_segments;
+    if (v >= 1 && v <= WALK_MAX_SEGMENTS) return v;
+    // two from 512 to 2047 pairs (see owner_plan_auto); from 2048 pairs on a second wave per stream only adds the merge:
+    // 2 x 1024 0.266 -> 0.279 ms, 3 x 1024 0.329 -> 0.346, 3 x 768 0.210 -> 0.216; three and more segments lose everywhere
+    // but 8 x 4 segments on 512 pairs (0.087, a tie with 9 x 2)
+    return (long long)N * C < 2048 ? 2 : 1;
 }
 
 template <int RH, int RW, int SH, int SW>
@@ -1123,9 +1184,10 @@ int owner_prepare(const float *rois, int R, int N, int H, int W, int C, int PH, 
 template <int ID, int RH, int RW, int SH, int SW, int DEPTH, int MINW, int CPL, int AUX>
 static int launch_owner_t(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH,
                           int PW, float *bottom_diff, void *workspace, size_t workspace_bytes, float *halo, hipStream_t st,
-                          bool i32) {
+                          bool i32, int nseg) {
     const int tiles_h = cdiv(H, SH), tiles_w = cdiv(W, SW), tiles = tiles_h * tiles_w;
     const int items = N * tiles;
+    if (nseg < 1 || nseg > WALK_MAX_SEGMENTS || (i32 && nseg != 1)) return WSSDL_ERR_INVALID_ARGUMENT;
     WalkWs ws;
     if (carve_walk(workspace, R, N, tiles_h, tiles_w, walk_record_bound(R, N, H, W, PH, PW, SH, SW), &ws) > workspace_bytes)
         return WSSDL_ERR_WORKSPACE;
@@ -1147,9 +1209,16 @@ static int launch_owner_t(const float *top_diff, const unsigned char *arg8, int 
                            ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff, 1, halo, 0ull, q, SH, SW);
     }
     if (!i32)
-    hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<RH, RW, DEPTH, MINW, CPL, false, true, AUX>), dim3((unsigned)blocks, 1u), dim3(64),
+    hipLaunchKernelGGL((roi_pool_bwd_walk_kernel<RH, RW, DEPTH, MINW, CPL, false, true, AUX>), dim3((unsigned)blocks, (unsigned)nseg), dim3(64),
                        0, st, top_diff, arg8, reinterpret_cast<const unsigned *>(ws.slots), ws.tile_off, ws.tile_slots,
-                       ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff, 1, halo, 0ull, q, SH, SW);
+                       ws.order, items, tiles_w, tiles, G, H, W, C, total_elems, bottom_diff, nseg, halo, 0ull, q, SH, SW);
+    if (nseg > 1) {
+        const long long cells = (long long)N * H * W;
+        if (cells > 0x7fffffffLL) return WSSDL_ERR_INVALID_ARGUMENT;
+        hipLaunchKernelGGL(walk_merge_split_kernel, dim3((unsigned)cells), dim3(256), 0, st, bottom_diff, halo, N, H, W, C / 4,
+                           tiles_h, tiles_w, RH, RW, SH, SW, nseg);
+        return check_launch();
+    }
     constexpr int HH = RH - SH, HW = RW - SW;
     constexpr int ncell = SH * SW - (SH - HH) * (SW - HW);
     if (ncell > 0)
@@ -1159,11 +1228,12 @@ static int launch_owner_t(const float *top_diff, const unsigned char *arg8, int 
 }
 
 int launch_owner(const float *top_diff, const unsigned char *arg8, int R, int N, int H, int W, int C, int PH, int PW,
-                 float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, float *halo, hipStream_t st, bool i32) {
+                 float *bottom_diff, void *workspace, size_t workspace_bytes, int plan, float *halo, hipStream_t st, bool i32,
+                 int nseg) {
     switch (plan) {
 #define WSSDL_X(ID, RH, RW, SH, SW, D, MW, CPL, AUX) \
         case ID: return launch_owner_t<ID, RH, RW, SH, SW, D, MW, CPL, AUX>(top_diff, arg8, R, N, H, W, C, PH, PW, bottom_diff, workspace, \
-                                                                workspace_bytes, halo, st, i32);
+                                                                workspace_bytes, halo, st, i32, nseg);
         WSSDL_OWNER_PLANS(WSSDL_X)
 #undef WSSDL_X
         default: return WSSDL_ERR_INVALID_ARGUMENT;

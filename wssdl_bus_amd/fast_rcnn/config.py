@@ -130,6 +130,10 @@ __C.ROI_POOL_BWD_SPLIT = 'auto'
 # (179 MB at 8 x 38 x 63 x 1024, 2.3 x bottom_diff; only the halo cells are touched).  train_bus prints the form the
 # first backward of a run takes (BackwardPlan.variant).
 __C.ROI_POOL_BWD_OWNER = 'auto'
+# waves per tile stream of the bin-owner form: 'auto' = the library's rule (wssdl_roi_pool_backward_owner_segments: more
+# than one on launches with few (image, channel) pairs, whose longest streams the whole chip would otherwise wait for),
+# an int = that many, 1 = the plain owner form.  Same lists, deterministic, the owner form's tolerance.
+__C.ROI_POOL_BWD_OWNER_SEGMENTS = 'auto'
 # True: the backward is ALWAYS the exact walk -- the reference's f32 summation order (roi, ph, pw), bit for bit
 # (roi_pooling_op_gpu.cu.cc:132-186) -- whatever the two keys above say.  The default training gradient is
 # tolerance-parity (north_star: 1e-5; measured <= 1e-6 of the tensor's scale), not bit-parity; every forward output

@@ -293,6 +293,7 @@ class BackwardPlan(object):
     def __init__(self, workspace, nbytes, plan, owner=-1):
         # owner >= 0: the lists were built for that plan of the bin-owner form (roi_pool_grad_prepare_owner)
         self.workspace, self.nbytes, self.plan, self.owner = workspace, nbytes, plan, owner
+        self.owner_segments = 1        # > 1: the owner form with that many waves per tile stream (round 6)
         self.segments, self.variant = 1, "exact walk: the reference's summation order, bit for bit"
 
 
@@ -339,6 +340,16 @@ def owner_plan(shape, R, pooled_height=7, pooled_width=7):
     return int(v)
 
 
+def owner_segments(shape, R):
+    """Waves per tile stream of the bin-owner form for this launch: cfg.ROI_POOL_BWD_OWNER_SEGMENTS = 'auto' (the
+    library's rule, wssdl_roi_pool_backward_owner_segments) or an int; 1 = the plain owner form."""
+    v = cfg.get("ROI_POOL_BWD_OWNER_SEGMENTS", "auto")
+    N, H, W, C = shape
+    if v == "auto":
+        return max(1, int(_lib.lib().wssdl_roi_pool_backward_owner_segments(int(R), N, H, W, C)))
+    return max(1, int(v))
+
+
 def roi_pool_grad_prepare_owner(shape, rois, pooled_height, pooled_width, spatial_scale, owner, rounding=None):
     """Lists of the bin-owner form (every bin listed once, by the tile of its window's first cell)."""
     N, H, W, C = shape
@@ -366,7 +377,9 @@ def prepare_backward(shape, rois, pooled_height, pooled_width, spatial_scale, ro
     if own >= 0:
         plan = roi_pool_grad_prepare_owner(shape, rois, pooled_height, pooled_width, spatial_scale, own, rounding)
         plan.segments = 1
-        plan.variant = "bin-owner walk, owner plan %d: deterministic, not bit-ordered (<= 1e-6 of the exact walk)" % own
+        plan.owner_segments = owner_segments(shape, R)
+        plan.variant = "bin-owner walk, owner plan %d%s: deterministic, not bit-ordered (<= 1e-6 of the exact walk)" % (
+            own, (", %d waves per tile stream" % plan.owner_segments) if plan.owner_segments > 1 else "")
         return plan
     segs = split_segments(shape, R)
     plan = roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scale, rounding, segments=segs)
@@ -404,6 +417,19 @@ def roi_pool_grad_compact(shape, rois, arg8, grad, pooled_height, pooled_width, 
     R = rois.shape[0]
     if plan is None and use_workspace:
         plan = roi_pool_grad_prepare(shape, rois, pooled_height, pooled_width, spatial_scale, rounding)
+    if plan is not None and plan.owner >= 0 and getattr(plan, "owner_segments", 1) > 1:
+        nseg = int(plan.owner_segments)
+        with torch.cuda.device(grad.device):
+            nscr = L.wssdl_roi_pool_backward_owner_split_scratch_bytes(N, H, W, C, plan.owner, nseg)
+            scratch = torch.empty((nscr,), dtype=torch.uint8, device=grad.device)
+            with _lib.timed("roi_pool_backward", dict(N=N, H=H, W=W, C=C, R=R, argmax_bytes=1, owner=plan.owner,
+                                                      owner_segments=nseg)):
+                _lib.check(L.wssdl_roi_pool_backward_compact_owner_split(
+                    _lib.ptr(grad), _lib.ptr(arg8), _lib.ptr(rois), R, N, H, W, C,
+                    int(pooled_height), int(pooled_width), float(spatial_scale), mode, _lib.ptr(out),
+                    _lib.ptr(plan.workspace), plan.nbytes, plan.owner, nseg, _lib.ptr(scratch), nscr,
+                    _lib.stream()), "wssdl_roi_pool_backward_compact_owner_split")
+        return out
     if plan is not None and plan.owner >= 0:
         with torch.cuda.device(grad.device):
             nscr = L.wssdl_roi_pool_backward_owner_scratch_bytes(N, H, W, C, plan.owner)
