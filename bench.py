@@ -295,7 +295,7 @@ def hbm_traffic(kernel_key, meta):
         return None, "stale: profiles/hotpath_traffic.json holds %s, this run is %s" % (shapes, want)
     # an op of several kernels: their bytes add up (bin-owner backward = walk + halo merge; split backward = walk +
     # combine; block-table forward = tables + bin-row order + pooling)
-    keys = {"roi_pool_bwd": ("roi_pool_bwd_walk_kernel", "walk_merge_kernel", "walk_combine_kernel"),
+    keys = {"roi_pool_bwd": ("roi_pool_bwd_walk_kernel", "walk_merge_kernel", "walk_merge_split_kernel", "walk_combine_kernel"),
             "roi_pool_fwd": ("roi_pool_fwd_rows_kernel", "roi_pool_fwd_compact_kernel", "roi_pool_fwd_blocks_kernel",
                              "blocks_build_kernel", "rows_scatter_kernel")}.get(kernel_key, (kernel_key,))
     hit = [(k, v) for k, v in entry.get("kernels", {}).items() if any(q in k for q in keys)]
