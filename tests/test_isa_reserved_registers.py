@@ -41,6 +41,10 @@ def test_a_violation_is_caught(monkeypatch):
     monkeypatch.setattr(isa_check, "kernel_listings", lambda lib, tmp: both(bad))
     with pytest.raises(isa_check.IsaCheckError, match="outside the helpers"):
         isa_check.check_library("unused")
+    monkeypatch.setattr(isa_check, "kernel_listings",
+                        lambda lib, tmp: both(good + ["\tbuffer_load_dwordx4 v[78:81], v2, s[4:7], 0 offen"]))   # a tuple across the boundary
+    with pytest.raises(isa_check.IsaCheckError, match="reaches into"):
+        isa_check.check_library("unused")
     monkeypatch.setattr(isa_check, "kernel_listings", lambda lib, tmp: both(good[1:]))          # a batch load went missing
     with pytest.raises(isa_check.IsaCheckError, match="multiples"):
         isa_check.check_library("unused")

@@ -32,6 +32,17 @@ def _llvm_dirs():
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 KERNELS = ("nms_sweep_pipelined_kernel", "nms_mask_sweep_fused_kernel")
 RESERVED = re.compile(r"\bv(8[0-9]|9[0-5])\b|\bv\[(8[0-9]|9[0-5]):(8[0-9]|9[0-5])\]")
+ANY_RANGE = re.compile(r"\bv\[(\d+):(\d+)\]")
+
+
+def _straddles(line):
+    """a register range that reaches into v80-v95 from outside (v[78:81]: a tuple the allocator placed across the
+    boundary) -- RESERVED only sees ranges that lie inside"""
+    for a, b in ANY_RANGE.findall(line):
+        a, b = int(a), int(b)
+        if b >= 80 and a <= 95 and not (80 <= a <= 95 and 80 <= b <= 95):
+            return True
+    return False
 
 
 class IsaCheckError(RuntimeError):
@@ -91,6 +102,8 @@ def check_library(lib_path):
     for k, lines in listings.items():
         loads = zeroed = ors = 0
         for line in lines:
+            if _straddles(line):
+                raise IsaCheckError("%s: a register range reaches into the reserved v80-v95: %s" % (k, line.strip()))
             if not RESERVED.search(line):
                 continue
             words = line.replace(",", " ").split()
