@@ -146,9 +146,14 @@ def main():
                          "instead of the training path's 1-byte pair")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
                     help="wssdl_set_tuning(KEY, INT) before the run, e.g. roi_fwd_blocks=1 (repeatable)")
+    ap.add_argument("--window-table-min-rois", type=int, default=-1,
+                    help="experiment: the smallest RoI list that gets a window table (and with it the block-table forward)")
     args = ap.parse_args()
     import torch
     assert torch.cuda.is_available()
+    if args.window_table_min_rois >= 0:
+        from wssdl_bus_amd.roi_pooling_layer import roi_pooling_op
+        roi_pooling_op._WINDOW_TABLE_MIN_ROIS = args.window_table_min_rois
     if args.check:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from test_gpu_roi_compact import roofline_set_parity
