@@ -82,7 +82,8 @@ WSSDL_API const char *wssdl_last_error(void);
  * NMS as two launches instead of the fused one), "topk_sort" (order of the proposal candidates: 1 sorted runs +
  * cross ranks, the default; 0 the select + sample sort), "nms_wait_us" (how long a sweep of the fused launch waits for
  * the mask blocks before it reports WSSDL_NMS_TIMED_OUT; default 50000), "roi_fwd_blocks" / "roi_fwd_blocks_sort" /
- * "roi_fwd_blocks_parts" (block-table forward, see there).  Results do not depend on
+ * "roi_fwd_blocks_parts" (block-table forward, see there), "roi_fwd_one_bin" (forward launches of fewer than 32768 bin rows x
+ * 256-channel slices: waves per bin row, 7 = one wave per bin, the default; 0 = the sliced kernel).  Results do not depend on
  * any of them.  One more key is a fault injector for tests, not a knob: "nms_fused_fault" (> 0: the fused
  * NMS launch withholds image 0's progress counts and that image's sweep gives up after this many microseconds,
  * reporting WSSDL_NMS_TIMED_OUT).  Unknown key -> WSSDL_ERR_INVALID_ARGUMENT. */

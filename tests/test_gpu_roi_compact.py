@@ -61,6 +61,14 @@ def test_compact_pair_vs_oracle(torch_cuda, shape, mode):
         assert np.array_equal(top.cpu().numpy(), et), fwd
         arg = op.expand_argmax(arg8, rt, shape, 7, 7, 1.0 / 16, rounding=mode)
         assert np.array_equal(arg.cpu().numpy(), ea), fwd
+    # a launch this small: waves per bin row (round 6; 7 = one wave per bin, the default where C % 256 == 0; 0 = the sliced
+    # kernel; + 100 = whatever the launch size), both arg-max layouts
+    for split in (0, 4, 7, 104, 107):
+        with _lib.tuned(roi_fwd_one_bin=split):
+            top_s, arg8_s = op.roi_pool_compact(ft, rt, 7, 7, 1.0 / 16, rounding=mode)
+            top_i, arg_i = op.roi_pool(ft, rt, 7, 7, 1.0 / 16, rounding=mode)
+        assert torch.equal(top_s, top) and torch.equal(arg8_s, arg8), split
+        assert torch.equal(top_i, top) and torch.equal(arg_i, arg), split
     # the i32 pair of the reference contract gives the same tensors
     top_i, arg_i = op.roi_pool(ft, rt, 7, 7, 1.0 / 16, rounding=mode)
     assert torch.equal(top_i, top) and torch.equal(arg_i, arg)
@@ -114,6 +122,23 @@ def test_compact_other_pooled_sizes_and_unsupported_shapes(torch_cuda):
         want = c_oracle.roi_pool_backward(d, ea, rois, shape, ph, pw, scale)
         got = op.roi_pool_grad_compact(shape, rt, arg8, torch.from_numpy(d).cuda(), ph, pw, scale, rounding="cuda")
         assert np.array_equal(got.cpu().numpy(), want), (ph, pw)
+    # other pooled sizes on the one-wave-per-bin forward (256-channel waves)
+    shape2 = (2, 20, 24, 256)
+    f2 = np.maximum(rs.normal(size=shape2), 0).astype(np.float32)
+    rois2 = rois.copy()
+    rois2[::2, 0] = 1
+    f2t, r2t = torch.from_numpy(f2).cuda(), torch.from_numpy(rois2).cuda()
+    for ph, pw, scale in ((6, 6, 1.0 / 3), (14, 14, 1.0 / 16), (3, 11, 1.0 / 8), (2, 2, 1.0 / 16), (7, 7, 1.0 / 16)):
+        if not op.compact_supported(20, 24, 256, ph, pw):
+            continue
+        et, ea = c_oracle.roi_pool_forward(f2, rois2, ph, pw, scale, "cuda")
+        for split in (7, 4, 0):
+            with _lib.tuned(roi_fwd_one_bin=split):
+                top, arg8 = op.roi_pool_compact(f2t, r2t, ph, pw, scale, rounding="cuda")
+                top_i, arg_i = op.roi_pool(f2t, r2t, ph, pw, scale, rounding="cuda")
+            assert np.array_equal(top.cpu().numpy(), et), (ph, pw, split)
+            assert np.array_equal(op.expand_argmax(arg8, r2t, shape2, ph, pw, scale, rounding="cuda").cpu().numpy(), ea), (ph, pw, split)
+            assert np.array_equal(top_i.cpu().numpy(), et) and np.array_equal(arg_i.cpu().numpy(), ea), (ph, pw, split)
     # empty RoI list, and an all-empty gradient
     top, arg8 = op.roi_pool_compact(ft, rt[:0], 7, 7, 1.0 / 16)
     assert top.shape == (0, 7, 7, 32) and arg8.shape == (0, 7, 7, 32)

@@ -20,6 +20,7 @@ static int *tuning_field(const char *key) {
     if (!strcmp(key, "roi_bwd_owner")) return &t.roi_bwd_owner;
     if (!strcmp(key, "roi_bwd_owner_segments")) return &t.roi_bwd_owner_segments;
     if (!strcmp(key, "roi_fwd_variant")) return &t.roi_fwd_variant;
+    if (!strcmp(key, "roi_fwd_one_bin")) return &t.roi_fwd_one_bin;
     if (!strcmp(key, "roi_fwd_blocks")) return &t.roi_fwd_blocks;
     if (!strcmp(key, "roi_fwd_blocks_sort")) return &t.roi_fwd_blocks_sort;
     if (!strcmp(key, "roi_fwd_blocks_parts")) return &t.roi_fwd_blocks_parts;

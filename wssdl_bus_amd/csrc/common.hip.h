@@ -46,6 +46,7 @@ struct Tuning {
     int roi_bwd_plan = -1;      // plan id of the list-driven RoI-pool backward (-1: by launch size)
     int roi_bwd_owner = -1;     // owner plan id of the bin-owner backward that wssdl_roi_pool_backward_owner_plan suggests (-1: its rule)
     int roi_bwd_owner_segments = 0; // segments of the bin-owner backward that wssdl_roi_pool_backward_owner_segments suggests (0: its rule)
+    int roi_fwd_one_bin = 7;    // small forward launches: waves per bin row (7 = one bin each, 4), 0 = the sliced kernel; + 100: any launch
     int roi_fwd_variant = 0;    // shape of the compact RoI-pool forward (0: automatic)
     int roi_fwd_blocks = -1;    // block-table forward (roi_pool_blocks.hip): -1 by launch shape, 0 never, 1 wherever supported
     int roi_fwd_blocks_parts = 0; // its pooling kernel: waves per bin row (1, 2, 4 or 7; anything else = 2, the measured best)

@@ -191,7 +191,8 @@ struct LaneVec<2> {
 template <int CPL, int RPW /* waves per workgroup */, int PWS /* PW when known at compile time, else 0 */,
           bool WHOLE_ROI /* a wave walks all PH bin rows of one RoI instead of one bin row */,
           bool TAB /* the windows come from the table of roi_windows_kernel (PH = PWS = 7, one bin row per wave) */,
-          bool I32 = false /* i32 flat-index arg-max instead of the 1-byte codes */>
+          bool I32 = false /* i32 flat-index arg-max instead of the 1-byte codes */,
+          int SPLIT = 0 /* > 0: SPLIT waves share a bin row, ceil(PW / SPLIT) bins each (small launches: more, shorter waves) */>
 __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
     const float *__restrict__ bottom, int N, int H, int W, int C, const float *__restrict__ rois,
     int R, int PH, int PW, float scale, int rounding, float *__restrict__ top,
@@ -217,7 +218,11 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
         group = (q << (3 - sh)) + (xcd >> sh);
     }
     // item = one RoI (WHOLE_ROI) or one (roi, ph) bin row
-    const long long item = (long long)group * RPW + wave;
+    static_assert(SPLIT == 0 || (PWS == 0 && !WHOLE_ROI && !TAB), "split bin rows: the generic bin loop, no table");
+    const long long witem = (long long)group * RPW + wave;
+    const int per_wave = SPLIT > 0 ? (PW + SPLIT - 1) / SPLIT : PW;
+    const int pw_first = SPLIT > 0 ? (int)(witem % SPLIT) * per_wave : 0, pw_last = min(PW, pw_first + per_wave);
+    const long long item = SPLIT > 0 ? witem / SPLIT : witem;
     const long long items = WHOLE_ROI ? (long long)R : (long long)R * PH;
     if (item >= items) return;
     const int r = WHOLE_ROI ? (int)item : ((PWS > 0 && PH == PWS) ? (int)(item / (PWS > 0 ? PWS : 1)) : (int)(item / PH));
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
 #pragma unroll
         for (int pw = 0; pw < PWS; ++pw) store_bin(pw, res[pw], mi[pw]);
     } else {
-        for (int pw = 0; pw < PW; ++pw) {
+        for (int pw = pw_first; pw < pw_last; ++pw) {
             vec mv;
             unsigned mi[CPL];
             pool_bin(__builtin_amdgcn_readlane(my_ws, pw), __builtin_amdgcn_readlane(my_we, pw), mv, mi);
@@ -818,9 +823,33 @@ static int forward_compact(const float *bottom, int N, int H, int W, int C, cons
     // wave-uniform kernel, 256 (or 128) channels per wave.  Variants: 0 = automatic, 1 = one bin row per
     // wave with a store per bin, 2 = 128-channel waves, 3 = 7 one-row waves per workgroup, 4 = one bin
     // row per wave, 5 = a whole RoI per wave, 9 = the sliced round-1 form
-    // a test-sized RoI list (R = 300: 8400 one-row waves) is latency-bound and runs faster on the sliced
-    // kernel, which spreads a bin row over more lanes: 0.067 against 0.087 ms at 63 x 100 x 1024
+    // a test-sized RoI list (R = 300: 8400 one-row waves) is latency-bound: 0.087 ms on one-row waves, 0.067 on the sliced
+    // kernel (which spreads a bin row over more lanes), 0.056-0.062 on one wave per bin (below) at 63 x 100 x 1024
     const bool small_launch = variant == 0 && !table && (long long)R * pooled_h * cdiv(C, 256) < 32768;
+    // Small launches (round 6): one wave per BIN.  A launch of R * PH * C / 256 < 32768 one-row waves leaves SIMDs idle and each
+    // wave walks a chain of 7 bins; split seven ways the waves are 7 x as many and a seventh as long.  Same scan per bin, same
+    // bits.  R x C sweep against the sliced kernel (profiles/r06_small_forward_one_bin_sweep.log): 0.45-0.86 x the time
+    // everywhere below the bound, 0.96-1.02 x at it, 1.3 x beyond (where the rows kernel takes over).  "roi_fwd_one_bin":
+    // 7 (default) / 4 = waves per bin row, 0 = the sliced kernel, + 100 = also beyond the bound (experiments).
+    const int split = tuning().roi_fwd_one_bin;
+    if ((small_launch || (split >= 100 && variant == 0 && !table)) && split > 0 && C % 256 == 0 && (long long)H * W * C * 4 < 0x7fffffffLL) {
+        // SPLIT waves per bin row: R * PH * SPLIT * C / 256 waves with ceil(PW / SPLIT) bins each
+        const int slices = C / 256;
+        if ((slices >= 8 && slices % 8 == 0) || (slices < 8 && 8 % slices == 0)) {
+            const int sp = split % 100 >= 7 ? 7 : 4;
+            const long long items = (long long)R * pooled_h * sp;
+            const long long groups = (items + 3) / 4;
+            const long long blocks = slices >= 8 ? groups * slices : 8 * ((groups + 8 / slices - 1) / (8 / slices));
+            if (blocks <= 0x7fffffffLL) {
+#define WSSDL_FWD_SPLIT(SP) \
+    hipLaunchKernelGGL((roi_pool_fwd_rows_kernel<4, 4, 0, false, false, false, SP>), dim3((unsigned)blocks), dim3(256), 0, st, bottom, N, H, \
+                       W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top, argmax8, overflow, slices, nullptr)
+                if (sp == 7) WSSDL_FWD_SPLIT(7); else WSSDL_FWD_SPLIT(4);
+#undef WSSDL_FWD_SPLIT
+                return check_launch();
+            }
+        }
+    }
     if (variant != 9 && !small_launch) {
         const int cpl = (variant == 2 || C % 256 != 0) ? 2 : 4;
         const int slices = cdiv(C, 64 * cpl);
@@ -877,8 +906,19 @@ int wssdl::launch_fwd_rows_i32(const float *bottom, int N, int H, int W, int C, 
     if ((reinterpret_cast<uintptr_t>(bottom) & 15) || (reinterpret_cast<uintptr_t>(top) & 15) ||
         (reinterpret_cast<uintptr_t>(argmax) & 15))
         return WSSDL_ROWS_I32_UNSUPPORTED;
-    // (a test-sized RoI list is latency-bound and faster on the sliced kernel, as on the 1-byte path)
-    if ((long long)R * pooled_h * cdiv(C, 256) < 32768) return WSSDL_ROWS_I32_UNSUPPORTED;
+    // (a test-sized RoI list: one wave per bin, as on the 1-byte path; the sliced kernel where that form does not apply)
+    if ((long long)R * pooled_h * cdiv(C, 256) < 32768) {
+        const int sl = C / 256;
+        if (tuning().roi_fwd_one_bin <= 0 || C % 256 != 0 || !((sl >= 8 && sl % 8 == 0) || (sl < 8 && 8 % sl == 0)))
+            return WSSDL_ROWS_I32_UNSUPPORTED;
+        const long long groups7 = ((long long)R * pooled_h * 7 + 3) / 4;
+        const long long blocks7 = sl >= 8 ? groups7 * sl : 8 * ((groups7 + 8 / sl - 1) / (8 / sl));
+        if (blocks7 > 0x7fffffffLL) return WSSDL_ROWS_I32_UNSUPPORTED;
+        hipLaunchKernelGGL((roi_pool_fwd_rows_kernel<4, 4, 0, false, false, true, 7>), dim3((unsigned)blocks7), dim3(256), 0, st, bottom, N,
+                           H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, rounding, top, reinterpret_cast<unsigned char *>(argmax),
+                           nullptr, sl, nullptr);
+        return check_launch();
+    }
     const int cpl = (C % 256 != 0) ? 2 : 4;
     const int slices = cdiv(C, 64 * cpl);
     if (!((slices >= 8 && slices % 8 == 0) || (slices < 8 && 8 % slices == 0))) return WSSDL_ROWS_I32_UNSUPPORTED;
