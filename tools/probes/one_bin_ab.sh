@@ -13,7 +13,7 @@ print(sys.argv[1], sys.argv[2], 'fwd', round(o['roi_pool_forward']['avg_ms'],4))
 PY
 }
 for rep in 1 2; do
-for b in 0 7 4; do
+for b in 7; do
 run r101 profiles/roofline_rois_resnet101_1600_test_r300.npy 63,100,1024 roi_fwd_one_bin=$b || exit 1
 run r18 profiles/roofline_rois_resnet18_sup_b2_r256.npy 38,63,256 roi_fwd_one_bin=$b || exit 1
 done

@@ -127,7 +127,10 @@ def run(rois_np, N, H, W, C, iters=20, warmup=3, seed=3):
                 backward_variant=(plan.variant if plan is not None else "i32 pair"),
                 backward_segments=segs, kernel_source_id=kernel_source_id(),
                 forward_variant=("block tables (k = 2, 3, 4) + bin rows in (image, first window row) order: 3 launches"
-                                 if prep is not None else "rows kernel"))
+                                 if prep is not None else
+                                 "one wave per bin (small launch)" if (compact and R * 7 * ((C + 255) // 256) < 32768 and C % 256 == 0
+                                                                       and _lib.get_tuning("roi_fwd_one_bin") > 0) else
+                                 "rows kernel" if R * 7 * ((C + 255) // 256) >= 32768 else "sliced kernel (small launch)"))
     return out, meta
 
 

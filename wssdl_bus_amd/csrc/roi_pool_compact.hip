@@ -288,6 +288,23 @@ __global__ __launch_bounds__(64 * RPW) void roi_pool_fwd_rows_kernel(
             const int so_row = h * W * cell_bytes;
             const unsigned rcode = I32 ? (unsigned)(h * W + ws) : (unsigned)(h - hs) << 4;      // code of (h, ws)
             int w = ws;
+            if constexpr (SPLIT > 0) {
+                for (; w + 3 < we; w += 4) {      // experiment: four cells in flight on the short waves of a small launch
+                    const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
+                    const vec v1 = LaneVec<CPL>::load(rs, voff, so_row + (w + 1) * cell_bytes);
+                    const vec v2 = LaneVec<CPL>::load(rs, voff, so_row + (w + 2) * cell_bytes);
+                    const vec v3 = LaneVec<CPL>::load(rs, voff, so_row + (w + 3) * cell_bytes);
+                    const unsigned code0 = rcode + (unsigned)(w - ws);
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) if (v0[k] > mv[k]) { mv[k] = v0[k];  mi[k] = code0; }
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) if (v1[k] > mv[k]) { mv[k] = v1[k];  mi[k] = code0 + 1u; }
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) if (v2[k] > mv[k]) { mv[k] = v2[k];  mi[k] = code0 + 2u; }
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) if (v3[k] > mv[k]) { mv[k] = v3[k];  mi[k] = code0 + 3u; }
+                }
+            }
             for (; w + 1 < we; w += 2) {          // two cells in flight
                 const vec v0 = LaneVec<CPL>::load(rs, voff, so_row + w * cell_bytes);
                 const vec v1 = LaneVec<CPL>::load(rs, voff, so_row + (w + 1) * cell_bytes);
