@@ -17,7 +17,12 @@ from wssdl_bus_amd.nms.hip_nms import hip_nms  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=400)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT", help="wssdl_set_tuning before the run, e.g. nms_grid=1")
+ap.add_argument("--high-thresholds", action="store_true", help="thresholds 0.6 ... 0.95 mostly (where the grid NMS applies)")
 args = ap.parse_args()
+for kv in args.tune:
+    from wssdl_bus_amd import _lib
+    _lib.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 rs = np.random.RandomState(args.seed)
 bad = n_ref = 0
 for k in range(args.cases):
@@ -35,7 +40,7 @@ for k in range(args.cases):
         d[4:6, 2:4] = d[4:6, 0:2] - 3
         d[6] = d[7]
     d[:, 4] = (rs.permutation(n) + 1).astype(np.float32) / np.float32(n + 1)
-    thresh = float(rs.choice([0.05, 0.3, 0.5, 0.7, 0.95]))
+    thresh = float(rs.choice([0.6, 0.65, 0.7, 0.8, 0.95, 0.5] if args.high_thresholds else [0.05, 0.3, 0.5, 0.7, 0.95]))
     rule = "nms_new" if k % 4 == 0 else "nms"
     want = (c_oracle.nms_new if rule == "nms_new" else c_oracle.cpu_nms)(d, thresh)
     # ... and, where oracle/_ref is built, the reference's own compiled Cython says the same (cpu_nms.pyx / utils/nms.pyx)

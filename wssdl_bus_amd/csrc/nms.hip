@@ -272,33 +272,7 @@ int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int to
 }
 
 // ------------------------------------------------------------------ nms mask ---
-// cpu_nms.pyx:11-15 define max(a, b) = a if a >= b else b (min likewise).  For finite operands
-// v_max_f32 / v_min_f32 return the same value up to the sign of a zero result, and a zero
-// result only ever feeds `x - zero` or `zero + 1.0f` here, which do not depend on that sign;
-// one instruction instead of compare + hazard nop + select (the kernel is VALU-bound).  NaN
-// coordinates (not a valid input) would differ.
-// (inline asm: __builtin_fmaxf would add a v_max x, x canonicalisation per operand in IEEE mode)
-__device__ __forceinline__ float fmax_ref(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float fmin_ref(float a, float b) {
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float fmax0_ref(float a) {      // max(0.0f, a)
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
-    return r;
-}
-
-__device__ __forceinline__ float box_area_ref(float x1, float y1, float x2, float y2) {
-    float w = x2 - x1;  w = w + 1.0f;       // numpy f32: (x2 - x1 + 1) * (y2 - y1 + 1), cpu_nms.pyx:24
-    float h = y2 - y1;  h = h + 1.0f;
-    return w * h;
-}
+// (fmax_ref / fmin_ref / fmax0_ref / box_area_ref: nms.hip.h, shared with nms_grid.hip)
 
 // ---- shared by the mask kernel and the sweeps (the sweep section explains them) ----
 constexpr int SWEEP_BLOCK = 1024;
@@ -327,8 +301,6 @@ static bool nms_sweep_is_pipelined(int n_max, int max_keep, const void *diag_t, 
 
 constexpr int MASK_WAVES = 4;
 
-typedef float nms_float4v __attribute__((ext_vector_type(4)));
-typedef float nms_float2v __attribute__((ext_vector_type(2)));
 
 constexpr int MASK_SEG = 16;     // column blocks per workgroup
 
@@ -1881,6 +1853,12 @@ int launch_nms_two_pass(const float *boxes, int box_stride_img, const int *n_dev
     const int probe = done ? nms_probe_size(n_max, max_keep) : n_max;
     const int NO_LIMIT = 0x7fffffff;
     int rc;
+    // round 6, opt-in ("nms_grid"): neighbour lists from a spatial join + the greedy rule's fixed point (nms_grid.hip);
+    // its scratch is the matrix
+    const size_t matrix_bytes_img = sizeof(unsigned long long) * (size_t)n_max * nms_mask_pitch(n_max);
+    if (tuning().nms_grid != 0 && nms_grid_supported(n_max, n_images, thresh, max_keep, matrix_bytes_img))
+        return launch_nms_grid(boxes, box_stride_img, n_dev, n_max, n_images, thresh, mask, matrix_bytes_img, max_keep, order,
+                               order_stride_img, keep, num_keep, rois_padded, st);
     // (the sweeps hold one workgroup slot each -- one CU each, at 128 VGPRs -- for the whole launch and wait for
     // mask blocks that need the other slots: at most a quarter of the device's CUs, and never more than 64)
     if (probe >= n_max && tuning().nms_fused != 0 && nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) &&
@@ -1991,6 +1969,9 @@ static int nms_entry(const float *dets, int n, double thresh, int max_keep, int3
                        w.n_sorted, n, w.boxes);
     rc = check_launch();
     if (rc) return rc;
+    if (rule == 0 && tuning().nms_grid != 0 && nms_grid_supported(n, 1, thresh, max_keep, mask_bytes))
+        return launch_nms_grid(w.boxes, n * 4, w.n_sorted, n, 1, thresh, w.mask, mask_bytes, max_keep, w.order, n, keep, num_keep,
+                               nullptr, st);
     rc = launch_nms_mask(w.boxes, n * 4, w.n_sorted, n, 1, thresh, w.mask, w.cand, w.summ, st, 0x7fffffff, 0, nullptr, max_keep,
                          rule);
     if (rc) return rc;

@@ -42,6 +42,38 @@ int order_runs_of(int M);
 int launch_order_rank(const unsigned long long *sorted_runs, int M, int n_images, int topn, int *sorted_index, int *n_sorted,
                       const float *boxes, float *sorted_boxes, hipStream_t st);
 
+typedef float nms_float4v __attribute__((ext_vector_type(4)));
+typedef float nms_float2v __attribute__((ext_vector_type(2)));
+
+// cpu_nms.pyx:11-15 define max(a, b) = a if a >= b else b (min likewise).  For finite operands
+// v_max_f32 / v_min_f32 return the same value up to the sign of a zero result, and a zero
+// result only ever feeds `x - zero` or `zero + 1.0f` here, which do not depend on that sign;
+// one instruction instead of compare + hazard nop + select (the kernel is VALU-bound).  NaN
+// coordinates (not a valid input) would differ.
+// (inline asm: __builtin_fmaxf would add a v_max x, x canonicalisation per operand in IEEE mode)
+__device__ __forceinline__ float fmax_ref(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fmin_ref(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fmax0_ref(float a) {      // max(0.0f, a)
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+
+__device__ __forceinline__ float box_area_ref(float x1, float y1, float x2, float y2) {
+    float w = x2 - x1;  w = w + 1.0f;       // numpy f32: (x2 - x1 + 1) * (y2 - y1 + 1), cpu_nms.pyx:24
+    float h = y2 - y1;  h = h + 1.0f;
+    return w * h;
+}
+
+
 // boxes: per image [n_max, 4] f32 in score order (image stride box_stride_img floats);
 // mask: per image [n_max, nms_mask_pitch(n_max)] u64, upper triangle written -- every word when the sweep
 // for (n_max, max_keep) is the general one; only the non-zero words and the band next to the diagonal
@@ -80,5 +112,13 @@ int launch_nms_two_pass(const float *boxes, int box_stride_img, const int *n_dev
                         unsigned long long *summ, int max_keep, const int *order, int order_stride_img,
                         int *keep, int *num_keep, float *rois_padded, int *kept_scratch, int *done,
                         hipStream_t st);
+
+// The same keep lists without the serial walk (nms_grid.hip, round 6): neighbour lists from a spatial join, then the
+// greedy rule iterated to its fixed point.  `ws` = the suppression-matrix workspace (ws_bytes_per_image per image, the
+// matrix's own size is enough from n_max = 2048 on); only the rule of cpu_nms.pyx, thresholds in [0.6, 1).
+bool nms_grid_supported(int n_max, int n_images, double thresh, int max_keep, size_t ws_bytes_per_image);
+int launch_nms_grid(const float *boxes, int box_stride_img, const int *n_dev, int n_max, int n_images, double thresh,
+                    void *ws, size_t ws_bytes_per_image, int max_keep, const int *order, int order_stride_img, int *keep,
+                    int *num_keep, float *rois_padded, hipStream_t st);
 
 }  // namespace wssdl
