@@ -17,8 +17,8 @@ from wssdl_bus_amd.nms.hip_nms import hip_nms  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=400)
 ap.add_argument("--seed", type=int, default=0)
-ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT", help="wssdl_set_tuning before the run, e.g. nms_grid=1")
-ap.add_argument("--high-thresholds", action="store_true", help="thresholds 0.6 ... 0.95 mostly (where the grid NMS applies)")
+ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT", help="wssdl_set_tuning before the run, e.g. nms_fused=0")
+ap.add_argument("--high-thresholds", action="store_true", help="thresholds 0.6 ... 0.95 mostly (the RPN range)")
 args = ap.parse_args()
 for kv in args.tune:
     from wssdl_bus_amd import _lib

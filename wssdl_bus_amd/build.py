@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.environ.get("WSSDL_BUS_HIP_LIB") or os.path.join(HERE, "libwssdl_bus_hip.so")
-SOURCES = ["api_common.hip", "bbox_overlaps.hip", "nms.hip", "nms_grid.hip", "proposal.hip", "anchor_target.hip",
+SOURCES = ["api_common.hip", "bbox_overlaps.hip", "nms.hip", "proposal.hip", "anchor_target.hip",
            "roi_targets.hip", "roi_pool.hip", "roi_pool_compact.hip", "roi_pool_blocks.hip", "roi_pool_walk.hip", "mil.hip", "image.hip", "loss.hip",
            "post_detect.hip", "order_sort.hip"]
 HEADERS = ["common.hip.h", "nms.hip.h", "select.hip.h", "order_sort.hip.h", "roi_pool.hip.h", os.path.join("..", "..", "include", "wssdl_bus_hip.h")]

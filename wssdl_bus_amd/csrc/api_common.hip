@@ -28,7 +28,6 @@ static int *tuning_field(const char *key) {
     if (!strcmp(key, "roi_bwd_cg")) return &t.roi_bwd_cg;
     if (!strcmp(key, "nms_one_pass")) return &t.nms_one_pass;
     if (!strcmp(key, "nms_fused")) return &t.nms_fused;
-    if (!strcmp(key, "nms_grid")) return &t.nms_grid;
     if (!strcmp(key, "nms_sparse")) return &t.nms_sparse;
     if (!strcmp(key, "nms_wait_us")) return &t.nms_wait_us;
     if (!strcmp(key, "nms_sweep_async")) return &t.nms_sweep_async;

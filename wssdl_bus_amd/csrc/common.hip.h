@@ -56,7 +56,6 @@ struct Tuning {
     int nms_one_pass = 0;       // 1: the proposal layer never uses the probe pass
     int topk_sort = 1;          // order of the proposal candidates: 1 sorted runs + cross ranks (order_sort.hip),
                                 //    0 the select + sample sort of nms.hip
-    int nms_grid = 0;           // 1: NMS by spatial join + fixed point of the greedy rule (nms_grid.hip) where it applies (thresh >= 0.6)
     int nms_fused = 1;          // 0: mask and sweep of a one-pass NMS as two launches instead of the fused one
     int nms_sparse = 16;        // fused launch: far column segments of a row block the sweep has resolved are computed for its kept rows
                                 //    only when it kept at most this many of its 64 boxes (0: never)

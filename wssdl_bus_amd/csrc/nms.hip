@@ -272,7 +272,7 @@ int launch_rank_topk(const unsigned long long *keys, int M, int n_images, int to
 }
 
 // ------------------------------------------------------------------ nms mask ---
-// (fmax_ref / fmin_ref / fmax0_ref / box_area_ref: nms.hip.h, shared with nms_grid.hip)
+// (fmax_ref / fmin_ref / fmax0_ref / box_area_ref: nms.hip.h)
 
 // ---- shared by the mask kernel and the sweeps (the sweep section explains them) ----
 constexpr int SWEEP_BLOCK = 1024;
@@ -1853,12 +1853,6 @@ int launch_nms_two_pass(const float *boxes, int box_stride_img, const int *n_dev
     const int probe = done ? nms_probe_size(n_max, max_keep) : n_max;
     const int NO_LIMIT = 0x7fffffff;
     int rc;
-    // round 6, opt-in ("nms_grid"): neighbour lists from a spatial join + the greedy rule's fixed point (nms_grid.hip);
-    // its scratch is the matrix
-    const size_t matrix_bytes_img = sizeof(unsigned long long) * (size_t)n_max * nms_mask_pitch(n_max);
-    if (tuning().nms_grid != 0 && nms_grid_supported(n_max, n_images, thresh, max_keep, matrix_bytes_img))
-        return launch_nms_grid(boxes, box_stride_img, n_dev, n_max, n_images, thresh, mask, matrix_bytes_img, max_keep, order,
-                               order_stride_img, keep, num_keep, rois_padded, st);
     // (the sweeps hold one workgroup slot each -- one CU each, at 128 VGPRs -- for the whole launch and wait for
     // mask blocks that need the other slots: at most a quarter of the device's CUs, and never more than 64)
     if (probe >= n_max && tuning().nms_fused != 0 && nms_sweep_is_pipelined(n_max, max_keep, diag_t, summ) &&
@@ -1969,9 +1963,6 @@ static int nms_entry(const float *dets, int n, double thresh, int max_keep, int3
                        w.n_sorted, n, w.boxes);
     rc = check_launch();
     if (rc) return rc;
-    if (rule == 0 && tuning().nms_grid != 0 && nms_grid_supported(n, 1, thresh, max_keep, mask_bytes))
-        return launch_nms_grid(w.boxes, n * 4, w.n_sorted, n, 1, thresh, w.mask, mask_bytes, max_keep, w.order, n, keep, num_keep,
-                               nullptr, st);
     rc = launch_nms_mask(w.boxes, n * 4, w.n_sorted, n, 1, thresh, w.mask, w.cand, w.summ, st, 0x7fffffff, 0, nullptr, max_keep,
                          rule);
     if (rc) return rc;

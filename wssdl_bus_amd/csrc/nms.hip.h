@@ -113,12 +113,4 @@ int launch_nms_two_pass(const float *boxes, int box_stride_img, const int *n_dev
                         int *keep, int *num_keep, float *rois_padded, int *kept_scratch, int *done,
                         hipStream_t st);
 
-// The same keep lists without the serial walk (nms_grid.hip, round 6): neighbour lists from a spatial join, then the
-// greedy rule iterated to its fixed point.  `ws` = the suppression-matrix workspace (ws_bytes_per_image per image, the
-// matrix's own size is enough from n_max = 2048 on); only the rule of cpu_nms.pyx, thresholds in [0.6, 1).
-bool nms_grid_supported(int n_max, int n_images, double thresh, int max_keep, size_t ws_bytes_per_image);
-int launch_nms_grid(const float *boxes, int box_stride_img, const int *n_dev, int n_max, int n_images, double thresh,
-                    void *ws, size_t ws_bytes_per_image, int max_keep, const int *order, int order_stride_img, int *keep,
-                    int *num_keep, float *rois_padded, hipStream_t st);
-
 }  // namespace wssdl
